@@ -1,0 +1,575 @@
+/*
+ * dwt_oracle.c -- CPU restatement of libdwt's lifting DWT hot path (plain C99).
+ *
+ * TEST INFRASTRUCTURE ONLY (see dwt_oracle.h).  Parity status: PINNED against the
+ * reference compiled from its own sources (oracle/_ref/libdwt_ref.so) and the
+ * committed fixtures under tests/golden/.
+ *
+ * Build WITHOUT floating-point contraction (-ffp-contract=off): the reference is
+ * built by gcc without -mfma (arch.mk:15,38-39), so every `x += c*(a+b)` rounds
+ * the sum, the product and the accumulation separately.
+ *
+ * The reference realises the lifting through prolog / main / epilog / short
+ * variants and 17 loop schedules (src/libdwt.c:10551-10742); they all compute the
+ * same thing, which is restated here once per wavelet as whole-line sweeps with
+ * whole-sample symmetric reflection at both ends.
+ */
+#include "dwt_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- constants: src/inline.h:309-315 and :331-335 (stored as float there) ---- */
+static const float C97_P1 = 1.58613434342059;
+static const float C97_U1 = -0.0529801185729;
+static const float C97_P2 = -0.8829110755309;
+static const float C97_U2 = 0.4435068520439;
+static const float C97_S1 = 1.1496043988602;
+static const float C97_S2 = 1 / 1.1496043988602; /* double division, then rounded: inline.h:315 */
+static const float C53_P1 = 0.5;
+static const float C53_U1 = 0.25;
+static const float C53_S1 = 1.41421356237309504880;
+static const float C53_S2 = 0.70710678118654752440;
+
+/* ---- integer helpers: src/inline.h:443-461 ---- */
+int oracle_ceil_div_pow2(int i, int j)
+{
+	return (i + (1 << j) - 1) >> j;
+}
+
+int oracle_ceil_log2(int x)
+{
+	/* smallest n with (1<<n) >= x; 0 for x <= 1 */
+	int n = 0;
+	while (n < 31 && (1 << n) < x)
+		n++;
+	return n;
+}
+
+static int g_threads = 0;
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+	return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+
+void oracle_set_threads(int n)
+{
+	g_threads = n;
+}
+
+/* whole-sample symmetric reflection of index i into [0,N-1], N >= 2 */
+static inline int refl(int i, int N)
+{
+	const int period = 2 * (N - 1);
+	i %= period;
+	if (i < 0)
+		i += period;
+	return i < N ? i : period - i;
+}
+
+/* one lifting sweep over samples of given parity: a[i] += c*(a[i-1]+a[i+1]) */
+static inline void sweep_s(float *a, int N, int parity, float c)
+{
+	for (int i = parity; i < N; i += 2) {
+		const float l = a[refl(i - 1, N)];
+		const float r = a[refl(i + 1, N)];
+		a[i] += c * (l + r);
+	}
+}
+
+/* ---- 1-D CDF 9/7 float, forward (interleaved result: even = L, odd = H) ----
+ * src/libdwt.c:10744-10800 calls accel_lift_op4s_s(tmp,1,N,-p1,u1,-p2,u2,s1,+1):
+ * predict1, update1, predict2, update2 (:2331-2341), then even*=zeta, odd*=1/zeta
+ * (:2344-2353); ends use 2*c*neighbour (:9545,:9873), equal to c*(x+x) in fp32. */
+void oracle_line_cdf97_f_s(float *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * C97_S1; /* :10757-10762 */
+		return;
+	}
+	const float alpha = -C97_P1, beta = C97_U1, gamma = -C97_P2, delta = C97_U2;
+	const float zeta = C97_S1;
+	const float inv_zeta = 1 / zeta; /* float division, as `1/zeta` at :2327 */
+	sweep_s(a, N, 1, alpha);
+	sweep_s(a, N, 0, beta);
+	sweep_s(a, N, 1, gamma);
+	sweep_s(a, N, 0, delta);
+	for (int i = 0; i < N; i += 2)
+		a[i] *= zeta;
+	for (int i = 1; i < N; i += 2)
+		a[i] *= inv_zeta;
+}
+
+/* ---- 1-D CDF 9/7 float, inverse (input interleaved) ----
+ * src/libdwt.c:11530-11571: accel_lift_op4s_s(tmp,0,N,-u2,p2,-u1,p1,s1,-1);
+ * descale first (even*=1/zeta, odd*=zeta, :2292-2300) then four sweeps
+ * even(-u2), odd(p2), even(-u1), odd(p1) (:2303-2315). */
+void oracle_line_cdf97_i_s(float *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * C97_S2; /* :11546 */
+		return;
+	}
+	const float zeta = C97_S1;
+	const float inv_zeta = 1 / zeta;
+	for (int i = 0; i < N; i += 2)
+		a[i] *= inv_zeta;
+	for (int i = 1; i < N; i += 2)
+		a[i] *= zeta;
+	sweep_s(a, N, 0, -C97_U2);
+	sweep_s(a, N, 1, C97_P2);
+	sweep_s(a, N, 0, -C97_U1);
+	sweep_s(a, N, 1, C97_P1);
+}
+
+/* ---- 1-D CDF 5/3 int32: src/libdwt.c:10950-10984 (statement order kept) ---- */
+void oracle_line_cdf53_f_i(int *a, int N)
+{
+	if (N < 2)
+		return;
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] -= (a[i - 1] + a[i + 1]) >> 1;
+	if (N & 1)
+		a[N - 1] += (a[N - 2] + 1) >> 1;
+	else
+		a[N - 1] -= a[N - 2];
+	a[0] += (a[1] + 1) >> 1;
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] += ((a[i - 1] + a[i + 1]) + 2) >> 2;
+}
+
+/* src/libdwt.c:11749-11783 */
+void oracle_line_cdf53_i_i(int *a, int N)
+{
+	if (N < 2)
+		return;
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] -= ((a[i - 1] + a[i + 1]) + 2) >> 2;
+	a[0] -= (a[1] + 1) >> 1;
+	if (N & 1)
+		a[N - 1] -= (a[N - 2] + 1) >> 1;
+	else
+		a[N - 1] += a[N - 2];
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] += (a[i - 1] + a[i + 1]) >> 1;
+}
+
+/* ---- 1-D CDF 5/3 float: src/libdwt.c:10986-11030 ---- */
+void oracle_line_cdf53_f_s(float *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * C53_S1;
+		return;
+	}
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] -= C53_P1 * (a[i - 1] + a[i + 1]);
+	if (N & 1)
+		a[N - 1] += 2 * C53_U1 * a[N - 2];
+	else
+		a[N - 1] -= 2 * C53_P1 * a[N - 2];
+	a[0] += 2 * C53_U1 * a[1];
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] += C53_U1 * (a[i - 1] + a[i + 1]);
+	for (int i = 0; i < N; i += 2)
+		a[i] = a[i] * C53_S1;
+	for (int i = 1; i < N; i += 2)
+		a[i] = a[i] * C53_S2;
+}
+
+/* src/libdwt.c:11785-11829 */
+void oracle_line_cdf53_i_s(float *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * C53_S2;
+		return;
+	}
+	for (int i = 0; i < N; i += 2)
+		a[i] = a[i] * C53_S2;
+	for (int i = 1; i < N; i += 2)
+		a[i] = a[i] * C53_S1;
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] -= C53_U1 * (a[i - 1] + a[i + 1]);
+	a[0] -= 2 * C53_U1 * a[1];
+	if (N & 1)
+		a[N - 1] -= 2 * C53_U1 * a[N - 2];
+	else
+		a[N - 1] += 2 * C53_P1 * a[N - 2];
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] += C53_P1 * (a[i - 1] + a[i + 1]);
+}
+
+/* ---- strided line drivers (gather -> lift -> Mallat scatter) ----
+ * The gather/scatter is dwt_util_memcpy_stride_{s,i} (src/system.c:102-164). */
+typedef void (*line_fn)(void *a, int N);
+
+enum wavelet { W97S, W53I, W53S };
+
+static void lift_fwd(enum wavelet w, void *tmp, int N)
+{
+	switch (w) {
+	case W97S: oracle_line_cdf97_f_s((float *)tmp, N); break;
+	case W53I: oracle_line_cdf53_f_i((int *)tmp, N); break;
+	case W53S: oracle_line_cdf53_f_s((float *)tmp, N); break;
+	}
+}
+
+static void lift_inv(enum wavelet w, void *tmp, int N)
+{
+	switch (w) {
+	case W97S: oracle_line_cdf97_i_s((float *)tmp, N); break;
+	case W53I: oracle_line_cdf53_i_i((int *)tmp, N); break;
+	case W53S: oracle_line_cdf53_i_s((float *)tmp, N); break;
+	}
+}
+
+/* element access: 4-byte elements at arbitrary byte strides (possibly unaligned) */
+static inline unsigned ld32(const char *p)
+{
+	unsigned v;
+	memcpy(&v, p, 4);
+	return v;
+}
+
+static inline void st32(char *p, unsigned v)
+{
+	memcpy(p, &v, 4);
+}
+
+/* forward line: src -> (dst_l, dst_h); *_ex_stride_* at :10744, :10950, :10986 */
+static void fwd_line(enum wavelet w, const char *src, char *dst_l, char *dst_h,
+	unsigned *tmp, int N, long stride)
+{
+	if (N < 2) {
+		/* float kernels scale the lone sample; the int kernel leaves it (:10961) */
+		if (N == 1 && w != W53I) {
+			tmp[0] = ld32(src);
+			lift_fwd(w, tmp, 1);
+			st32(dst_l, tmp[0]);
+		}
+		return;
+	}
+	for (int i = 0; i < N; i++)
+		tmp[i] = ld32(src + i * stride);
+	lift_fwd(w, tmp, N);
+	const int nl = (N + 1) >> 1, nh = N >> 1;
+	for (int i = 0; i < nl; i++)
+		st32(dst_l + i * stride, tmp[2 * i]);
+	for (int i = 0; i < nh; i++)
+		st32(dst_h + i * stride, tmp[2 * i + 1]);
+}
+
+/* inverse line: (src_l, src_h) -> dst; :11530, :11749, :11785 */
+static void inv_line(enum wavelet w, const char *src_l, const char *src_h, char *dst,
+	unsigned *tmp, int N, long stride)
+{
+	if (N < 2) {
+		if (N == 1 && w != W53I) {
+			tmp[0] = ld32(src_l);
+			lift_inv(w, tmp, 1);
+			st32(dst, tmp[0]);
+		}
+		return;
+	}
+	const int nl = (N + 1) >> 1, nh = N >> 1;
+	for (int i = 0; i < nl; i++)
+		tmp[2 * i] = ld32(src_l + i * stride);
+	for (int i = 0; i < nh; i++)
+		tmp[2 * i + 1] = ld32(src_h + i * stride);
+	lift_inv(w, tmp, N);
+	for (int i = 0; i < N; i++)
+		st32(dst + i * stride, tmp[i]);
+}
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+static unsigned *alloc_tmp(int n, int threads)
+{
+	unsigned *t = (unsigned *)malloc((size_t)threads * (size_t)(n + 8) * sizeof(unsigned));
+	if (!t) {
+		fprintf(stderr, "oracle: out of memory\n");
+		abort();
+	}
+	return t;
+}
+
+static inline int thread_id(void)
+{
+#ifdef _OPENMP
+	return omp_get_thread_num();
+#else
+	return 0;
+#endif
+}
+
+/* dwt_zero_padding_f_stride_* (src/libdwt.c:12079-12131): zero [ceil(N/2),N_dst_L)
+ * after dst_l and [floor(N/2),N_dst_H) after dst_h */
+static void zero_pad_f(char *dst_l, char *dst_h, int N, int n_dst_l, int n_dst_h, long stride)
+{
+	if (n_dst_l || n_dst_h) {
+		for (int i = (N + 1) >> 1; i < n_dst_l; i++)
+			st32(dst_l + i * stride, 0);
+		for (int i = N >> 1; i < n_dst_h; i++)
+			st32(dst_h + i * stride, 0);
+	}
+}
+
+/* dwt_zero_padding_i_stride_* (src/libdwt.c:12161-12215) */
+static void zero_pad_i(char *dst, int N, int n_dst, long stride)
+{
+	for (int i = N; i < n_dst; i++)
+		st32(dst + i * stride, 0);
+}
+
+/* Generic forward driver.  `skip_single` models the `lines_x > 1` / `lines_y > 1`
+ * guards that only the CDF 9/7 float drivers have (:12837, :12867); the 5/3
+ * drivers run their line kernels unconditionally (:16343-16359, :16507-16523).
+ * src/dst follow the _s2 convention (:12709,:12742): a pass reads `src`, writes
+ * `dst`, and afterwards src = dst. */
+static void fwd_2d(enum wavelet w, int skip_single, const void *src0, void *dst,
+	int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	const int so_min = imin(sox, soy), so_max = imax(sox, soy);
+	const int threads = oracle_max_threads();
+	unsigned *tmp_all = alloc_tmp(so_max, threads);
+	const int j_limit = oracle_ceil_log2(decompose_one ? so_max : so_min);
+	const char *src = (const char *)src0;
+	char *d = (char *)dst;
+
+	if (*j_max_ptr < 0 || *j_max_ptr > j_limit)
+		*j_max_ptr = j_limit;
+
+	for (int j = 0; j < *j_max_ptr; j++) {
+		const int so_src_x = oracle_ceil_div_pow2(sox, j), so_src_y = oracle_ceil_div_pow2(soy, j);
+		const int so_dst_x = oracle_ceil_div_pow2(sox, j + 1), so_dst_y = oracle_ceil_div_pow2(soy, j + 1);
+		const int si_src_x = oracle_ceil_div_pow2(six, j), si_src_y = oracle_ceil_div_pow2(siy, j);
+
+		if (!skip_single || so_src_x > 1) {
+#pragma omp parallel for schedule(static) num_threads(threads)
+			for (int y = 0; y < so_src_y; y++) {
+				unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+				fwd_line(w, src + (long)y * stride_x, d + (long)y * stride_x,
+					d + (long)y * stride_x + (long)so_dst_x * stride_y,
+					tmp, si_src_x, stride_y);
+			}
+			src = d;
+		}
+		if (!skip_single || so_src_y > 1) {
+#pragma omp parallel for schedule(static) num_threads(threads)
+			for (int x = 0; x < so_src_x; x++) {
+				unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+				fwd_line(w, src + (long)x * stride_y, d + (long)x * stride_y,
+					d + (long)so_dst_y * stride_x + (long)x * stride_y,
+					tmp, si_src_y, stride_x);
+			}
+			src = d;
+		}
+		if (zero_padding) {
+			for (int y = 0; y < so_src_y; y++)
+				zero_pad_f(d + (long)y * stride_x, d + (long)y * stride_x + (long)so_dst_x * stride_y,
+					si_src_x, so_dst_x, so_src_x - so_dst_x, stride_y);
+			for (int x = 0; x < so_src_x; x++)
+				zero_pad_f(d + (long)x * stride_y, d + (long)so_dst_y * stride_x + (long)x * stride_y,
+					si_src_y, so_dst_y, so_src_y - so_dst_y, stride_x);
+		}
+	}
+	free(tmp_all);
+}
+
+/* Generic inverse driver.  `cols_first`: the int 5/3 inverse undoes columns before
+ * rows (:18178-18195); the float drivers run rows then columns (:17098-17154,
+ * :18333-18349). */
+static void inv_2d(enum wavelet w, int skip_single, int cols_first, void *ptr,
+	int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	const int so_min = imin(sox, soy), so_max = imax(sox, soy);
+	const int threads = oracle_max_threads();
+	unsigned *tmp_all = alloc_tmp(so_max, threads);
+	char *p = (char *)ptr;
+	int j = oracle_ceil_log2(decompose_one ? so_max : so_min);
+
+	if (j_max >= 0 && j_max < j)
+		j = j_max;
+
+	for (; j > 0; j--) {
+		const int so_src_x = oracle_ceil_div_pow2(sox, j), so_src_y = oracle_ceil_div_pow2(soy, j);
+		const int so_dst_x = oracle_ceil_div_pow2(sox, j - 1), so_dst_y = oracle_ceil_div_pow2(soy, j - 1);
+		const int si_dst_x = oracle_ceil_div_pow2(six, j - 1), si_dst_y = oracle_ceil_div_pow2(siy, j - 1);
+
+		for (int pass = 0; pass < 2; pass++) {
+			const int do_rows = cols_first ? (pass == 1) : (pass == 0);
+			if (do_rows) {
+				if (!skip_single || so_dst_x > 1) {
+#pragma omp parallel for schedule(static) num_threads(threads)
+					for (int y = 0; y < so_dst_y; y++) {
+						unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+						inv_line(w, p + (long)y * stride_x,
+							p + (long)y * stride_x + (long)so_src_x * stride_y,
+							p + (long)y * stride_x, tmp, si_dst_x, stride_y);
+					}
+				}
+			} else {
+				if (!skip_single || so_dst_y > 1) {
+#pragma omp parallel for schedule(static) num_threads(threads)
+					for (int x = 0; x < so_dst_x; x++) {
+						unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+						inv_line(w, p + (long)x * stride_y,
+							p + (long)so_src_y * stride_x + (long)x * stride_y,
+							p + (long)x * stride_y, tmp, si_dst_y, stride_x);
+					}
+				}
+			}
+		}
+		if (zero_padding) {
+			for (int y = 0; y < so_dst_y; y++)
+				zero_pad_i(p + (long)y * stride_x, si_dst_x, so_dst_x, stride_y);
+			for (int x = 0; x < so_dst_x; x++)
+				zero_pad_i(p + (long)x * stride_y, si_dst_y, so_dst_y, stride_x);
+		}
+	}
+	free(tmp_all);
+}
+
+void oracle_cdf97_2f_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	fwd_2d(W97S, 1, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding);
+}
+
+void oracle_cdf97_2f_s2(const void *src, void *dst, int stride_x, int stride_y, int sox, int soy,
+	int six, int siy, int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	fwd_2d(W97S, 1, src, dst, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding);
+}
+
+void oracle_cdf97_2i_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	inv_2d(W97S, 1, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
+}
+
+void oracle_cdf97_2i_s2(const void *src, void *dst, int stride_x, int stride_y, int sox, int soy,
+	int six, int siy, int j_max, int decompose_one, int zero_padding)
+{
+	/* :18001-18008: copy the inner size_i region of src into dst, then in place */
+	for (int y = 0; y < siy; y++)
+		for (int x = 0; x < six; x++)
+			st32((char *)dst + (long)y * stride_x + (long)x * stride_y,
+				ld32((const char *)src + (long)y * stride_x + (long)x * stride_y));
+	inv_2d(W97S, 1, 0, dst, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
+}
+
+void oracle_cdf53_2f_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	fwd_2d(W53I, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding);
+}
+
+void oracle_cdf53_2i_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	inv_2d(W53I, 0, 1, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
+}
+
+void oracle_cdf53_2f_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	fwd_2d(W53S, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding);
+}
+
+void oracle_cdf53_2i_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	inv_2d(W53S, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
+}
+
+/* ---- 3-D single level, interleaved in place: x lines, then y, then z ----
+ * src/volume-dwt.c:677-725 (forward) applies fdwt1_single_cdf97_horizontal_min5_s
+ * (src/dwt-simple.c:2166-2193 = prolog :580 + main :981 + epilog :1469), which is
+ * the same lifting as the 2-D path without the de-interleave.  The inverse
+ * (src/volume-dwt.c:1115-1163) runs the axes in the same x, y, z order. */
+static void line3_s(char *base, long stride, int N, float *tmp, int inverse)
+{
+	for (int i = 0; i < N; i++)
+		memcpy(&tmp[i], base + i * stride, 4);
+	if (inverse)
+		oracle_line_cdf97_i_s(tmp, N);
+	else
+		oracle_line_cdf97_f_s(tmp, N);
+	for (int i = 0; i < N; i++)
+		memcpy(base + i * stride, &tmp[i], 4);
+}
+
+static void vol3(void *ptr, long sx, long sy, long sz, int nx, int ny, int nz, int inverse)
+{
+	const int threads = oracle_max_threads();
+	const int nmax = imax(nx, imax(ny, nz));
+	float *tmp_all = (float *)alloc_tmp(nmax, threads);
+	char *p = (char *)ptr;
+
+#pragma omp parallel for schedule(static) num_threads(threads)
+	for (int z = 0; z < nz; z++)
+		for (int y = 0; y < ny; y++)
+			line3_s(p + y * sy + z * sz, sx, nx, tmp_all + (size_t)thread_id() * (nmax + 8), inverse);
+#pragma omp parallel for schedule(static) num_threads(threads)
+	for (int z = 0; z < nz; z++)
+		for (int x = 0; x < nx; x++)
+			line3_s(p + x * sx + z * sz, sy, ny, tmp_all + (size_t)thread_id() * (nmax + 8), inverse);
+#pragma omp parallel for schedule(static) num_threads(threads)
+	for (int y = 0; y < ny; y++)
+		for (int x = 0; x < nx; x++)
+			line3_s(p + x * sx + y * sy, sz, nz, tmp_all + (size_t)thread_id() * (nmax + 8), inverse);
+	free(tmp_all);
+}
+
+void oracle_cdf97_3f_s(void *ptr, long sx, long sy, long sz, int nx, int ny, int nz)
+{
+	vol3(ptr, sx, sy, sz, nx, ny, nz, 0);
+}
+
+void oracle_cdf97_3i_s(void *ptr, long sx, long sy, long sz, int nx, int ny, int nz)
+{
+	vol3(ptr, sx, sy, sz, nx, ny, nz, 1);
+}
+
+/* ---- libdwt's synthetic test patterns ---- */
+/* float, type 0: x,y made 1-based, x >>= rand, 2xy/(float)(x^2+y^2+1)
+ * (src/libdwt.c:1209-1217, filled by :1338) */
+void oracle_test_image_fill_s(void *ptr, int stride_x, int stride_y, int size_x, int size_y, int rnd)
+{
+	for (int y = 0; y < size_y; y++)
+		for (int x = 0; x < size_x; x++) {
+			int xx = x + 1, yy = y + 1;
+			xx >>= rnd;
+			const float v = 2 * xx * yy / (float)(xx * xx + yy * yy + 1);
+			memcpy((char *)ptr + (long)y * stride_x + (long)x * stride_y, &v, 4);
+		}
+}
+
+/* int, type 0: 0-based, 255*(2xy)/(x^2+y^2+1) in integer arithmetic
+ * (src/libdwt.c:1152-1155, filled by :1270) */
+void oracle_test_image_fill_i(void *ptr, int stride_x, int stride_y, int size_x, int size_y, int rnd)
+{
+	for (int y = 0; y < size_y; y++)
+		for (int x = 0; x < size_x; x++) {
+			int xx = x;
+			xx >>= rnd;
+			const int v = 255 * (2 * xx * y) / (xx * xx + y * y + 1);
+			memcpy((char *)ptr + (long)y * stride_x + (long)x * stride_y, &v, 4);
+		}
+}

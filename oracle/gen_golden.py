@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference library itself.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container, where /root/reference exists:
+
+    make -C oracle ref && python oracle/gen_golden.py
+
+Every fixture is DATA: a seeded/synthetic input image, the forward coefficients the
+reference (oracle/_ref/libdwt_ref.so, libdwt 2015-02-18-dev built with its own
+release flags) produced for it, the level count it returned, and its inverse of
+those coefficients.  The whole allocated frame (including margins of sparse frames
+and pitch padding) is stored, so tests also pin what the reference leaves untouched.
+The reference has no golden vectors of its own: these files are what
+pins the oracle and the HIP path on the GPU box, where /root/reference is absent.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oraclelib import Reference  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# (name, size_o (x,y), size_i (x,y) or None, j, decompose_one, zero_padding, pitch_pad_elems, input kind)
+CASES_2D = [
+    ("8x8_rand", (8, 8), None, -1, 0, 0, 0, "rand"),
+    ("16x16_pat", (16, 16), None, -1, 0, 0, 0, "pattern"),
+    ("64x64_rand_j3", (64, 64), None, 3, 0, 0, 0, "rand"),
+    ("64x64_pat_full", (64, 64), None, -1, 0, 0, 3, "pattern"),
+    ("37x53_rand", (37, 53), None, -1, 0, 0, 0, "rand"),
+    ("53x37_rand_j2", (53, 37), None, 2, 0, 0, 1, "rand"),
+    ("64x5_rand", (64, 5), None, -1, 0, 0, 0, "rand"),
+    ("5x64_rand_d1", (5, 64), None, -1, 1, 0, 0, "rand"),
+    ("1x64_rand", (1, 64), None, -1, 1, 0, 0, "rand"),
+    ("64x1_rand", (64, 1), None, -1, 1, 0, 0, "rand"),
+    ("2x2_rand", (2, 2), None, -1, 0, 0, 0, "rand"),
+    ("3x3_rand", (3, 3), None, -1, 0, 0, 0, "rand"),
+    ("4x4_rand", (4, 4), None, -1, 0, 0, 0, "rand"),
+    ("2x7_rand_d1", (2, 7), None, -1, 1, 0, 0, "rand"),
+    ("100x100_pat_full", (100, 100), None, -1, 0, 0, 0, "pattern"),
+    ("129x65_rand_j4", (129, 65), None, 4, 0, 0, 7, "rand"),
+    ("sparse_64x64_50x40", (64, 64), (50, 40), -1, 0, 0, 0, "rand"),
+    ("sparse_64x64_50x40_zp", (64, 64), (50, 40), -1, 0, 1, 0, "rand"),
+    ("sparse_37x53_30x53_zp_j2", (37, 53), (30, 53), 2, 0, 1, 2, "rand"),
+    ("sparse_33x17_20x9", (33, 17), (20, 9), -1, 0, 0, 0, "rand"),
+    ("sparse_40x24_1x1_zp", (40, 24), (1, 1), 2, 0, 1, 0, "rand"),
+    ("256x192_rand_j5", (256, 192), None, 5, 0, 0, 0, "rand"),
+]
+
+WAVELETS = {
+    "cdf97_s": ("cdf97_2f_s", "cdf97_2i_s", np.float32),
+    "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i", np.int32),
+    "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32),
+}
+
+
+def make_input(ref, kind, dt, h, w_alloc, w, seed):
+    rng = np.random.default_rng(seed)
+    if dt == np.float32:
+        buf = rng.random((h, w_alloc), dtype=np.float32)
+    else:
+        buf = rng.integers(-32768, 32768, size=(h, w_alloc), dtype=np.int32)
+    if kind == "pattern":
+        if dt == np.float32:
+            ref.fill_s(buf[:, :w])
+        else:
+            ref.fill_i(buf[:, :w])
+    return buf
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = Reference()
+    manifest = {"generator": "oracle/gen_golden.py", "reference": "libdwt 2015-02-18-dev (oracle/_ref/libdwt_ref.so)",
+                "files": {}}
+    for wname, (ff, fi, dt) in WAVELETS.items():
+        arrays = {}
+        meta = []
+        for idx, (name, so, si, j, d1, zp, pad, kind) in enumerate(CASES_2D):
+            w, h = so
+            buf = make_input(ref, kind, dt, h, w + pad, w, seed=1000 + idx)
+            src = buf.copy()
+            jret = ref.fwd(ff, buf[:, :w], j, size_o=so, size_i=si, decompose_one=d1, zero_padding=zp)
+            fwd = buf.copy()
+            ref.inv(fi, buf[:, :w], jret, size_o=so, size_i=si, decompose_one=d1, zero_padding=zp)
+            inv = buf.copy()
+            arrays[f"{name}.in"] = src
+            arrays[f"{name}.fwd"] = fwd
+            arrays[f"{name}.inv"] = inv
+            meta.append({"name": name, "size_o": so, "size_i": si or so, "j_in": j, "j_out": jret,
+                         "decompose_one": d1, "zero_padding": zp, "pitch_elems": w + pad, "input": kind})
+        # out-of-place entries (_s2) for the float 9/7 pair
+        if wname == "cdf97_s":
+            for idx, (name, so, j) in enumerate([("s2_64x48_rand", (64, 48), -1), ("s2_37x53_rand_j2", (37, 53), 2),
+                                                 ("s2_1x9_rand", (1, 9), -1)]):
+                w, h = so
+                rng = np.random.default_rng(2000 + idx)
+                src = rng.random((h, w), dtype=np.float32)
+                dst = np.full((h, w), 7.0, np.float32)
+                jret = ref.call2("cdf97_2f_s2", src, dst, j)
+                rec = np.full((h, w), 3.0, np.float32)
+                ref.call2("cdf97_2i_s2", dst, rec, jret)
+                arrays[f"{name}.in"] = src
+                arrays[f"{name}.fwd"] = dst
+                arrays[f"{name}.inv"] = rec
+                meta.append({"name": name, "size_o": so, "size_i": so, "j_in": j, "j_out": jret, "s2": True,
+                             "dst_fill": 7.0, "rec_fill": 3.0})
+        path = os.path.join(OUT, f"{wname}.npz")
+        np.savez_compressed(path, **arrays)
+        sha = hashlib.sha256(open(path, "rb").read()).hexdigest()
+        manifest["files"][f"{wname}.npz"] = {"sha256": sha, "cases": meta}
+        print(path, os.path.getsize(path), "bytes", len(meta), "cases")
+
+    # 3-D single-level float 9/7 (volume-dwt.c sep_horizontal), interleaved layout
+    import ctypes as C
+
+    class Vol(C.Structure):
+        _fields_ = [("size_x", C.c_int), ("size_y", C.c_int), ("size_z", C.c_int), ("stride_x", C.c_size_t),
+                    ("stride_y", C.c_size_t), ("stride_z", C.c_size_t), ("data", C.c_void_p)]
+
+    arrays, meta = {}, []
+    for idx, shp in enumerate([(8, 8, 8), (5, 5, 5), (9, 7, 6), (17, 33, 20)]):
+        rng = np.random.default_rng(3000 + idx)
+        v = rng.random(shp, dtype=np.float32)
+        b = v.copy()
+        vs = Vol(shp[2], shp[1], shp[0], b.strides[2], b.strides[1], b.strides[0], b.ctypes.data)
+        ref.lib.cdf97_3f_ip_sep_horizontal_s(C.byref(vs))
+        f = b.copy()
+        ref.lib.cdf97_3i_ip_sep_horizontal_s(C.byref(vs))
+        name = "vol_%dx%dx%d" % shp
+        arrays[f"{name}.in"] = v
+        arrays[f"{name}.fwd"] = f
+        arrays[f"{name}.inv"] = b.copy()
+        meta.append({"name": name, "shape_zyx": shp})
+    path = os.path.join(OUT, "cdf97_3d_s.npz")
+    np.savez_compressed(path, **arrays)
+    manifest["files"]["cdf97_3d_s.npz"] = {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "cases": meta}
+    print(path, os.path.getsize(path), "bytes")
+
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

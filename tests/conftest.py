@@ -1,0 +1,54 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oraclelib import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    from oraclelib import Reference, have_reference
+    if not have_reference():
+        pytest.skip("reference library not built here (oracle/_ref absent and no /root/reference)")
+    return Reference()
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def golden_cases(wname):
+    """[(meta, in, fwd, inv)] for one fixture file; loaded lazily at collection."""
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)
+    z = np.load(os.path.join(GOLDEN, wname + ".npz"))
+    out = []
+    for m in man["files"][wname + ".npz"]["cases"]:
+        n = m["name"]
+        out.append((m, z[n + ".in"], z[n + ".fwd"], z[n + ".inv"]))
+    return out
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)

@@ -1,0 +1,156 @@
+"""CPU-only: pins the oracle (oracle/dwt_oracle.c) against the committed golden
+vectors (generated from the reference itself by oracle/gen_golden.py), against the
+reference library where it is built, and against closed-form known answers."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits, golden_cases
+from oraclelib import ENTRIES
+
+WAVELETS = {
+    "cdf97_s": ("cdf97_2f_s", "cdf97_2i_s"),
+    "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i"),
+    "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s"),
+}
+
+
+def test_manifest_hashes(manifest):
+    for fn, info in manifest["files"].items():
+        sha = hashlib.sha256(open(os.path.join(GOLDEN, fn), "rb").read()).hexdigest()
+        assert sha == info["sha256"], fn
+
+
+def _params():
+    for w in WAVELETS:
+        for case in golden_cases(w):
+            yield pytest.param(w, case, id=f"{w}-{case[0]['name']}")
+
+
+@pytest.mark.parametrize("wname,case", list(_params()))
+def test_oracle_matches_golden(oracle, wname, case):
+    meta, src, fwd, inv = case
+    ff, fi = WAVELETS[wname]
+    w = meta["size_o"][0]
+    if meta.get("s2"):
+        dst = np.full_like(src, meta["dst_fill"])
+        j = oracle.call2("cdf97_2f_s2", src.copy(), dst, meta["j_in"])
+        assert j == meta["j_out"]
+        assert np.array_equal(bits(dst), bits(fwd))
+        rec = np.full_like(src, meta["rec_fill"])
+        oracle.call2("cdf97_2i_s2", dst, rec, j)
+        assert np.array_equal(bits(rec), bits(inv))
+        return
+    buf = src.copy()
+    kw = dict(size_o=tuple(meta["size_o"]), size_i=tuple(meta["size_i"]),
+              decompose_one=meta["decompose_one"], zero_padding=meta["zero_padding"])
+    j = oracle.fwd(ff, buf[:, :w], meta["j_in"], **kw)
+    assert j == meta["j_out"]
+    assert np.array_equal(bits(buf), bits(fwd))
+    oracle.inv(fi, buf[:, :w], j, **kw)
+    assert np.array_equal(bits(buf), bits(inv))
+
+
+def test_oracle_3d_matches_golden(oracle):
+    for meta, src, fwd, inv in golden_cases("cdf97_3d_s"):
+        v = src.copy()
+        oracle.vol("cdf97_3f_s", v)
+        assert np.array_equal(bits(v), bits(fwd)), meta
+        oracle.vol("cdf97_3i_s", v)
+        assert np.array_equal(bits(v), bits(inv)), meta
+
+
+@pytest.mark.parametrize("wname", list(WAVELETS))
+def test_oracle_bitwise_equals_reference(oracle, reference, wname):
+    """Seeded sweep against the compiled reference (skipped where it is absent)."""
+    ff, fi = WAVELETS[wname]
+    dt = ENTRIES[ff][1]
+    rng = np.random.default_rng(42)
+    for (h, w) in [(16, 16), (31, 47), (1, 33), (33, 1), (2, 5), (128, 96), (250, 250)]:
+        for j, d1 in [(-1, 0), (2, 0), (-1, 1)]:
+            if dt == np.float32:
+                a = rng.random((h, w), dtype=np.float32) * 2 - 1
+            else:
+                a = rng.integers(-32768, 32768, size=(h, w), dtype=np.int32)
+            b = a.copy()
+            jo = oracle.fwd(ff, a, j, decompose_one=d1)
+            jr = reference.fwd(ff, b, j, decompose_one=d1)
+            assert jo == jr
+            assert np.array_equal(bits(a), bits(b)), (h, w, j, d1)
+            oracle.inv(fi, a, jo, decompose_one=d1)
+            reference.inv(fi, b, jr, decompose_one=d1)
+            assert np.array_equal(bits(a), bits(b)), (h, w, j, d1)
+
+
+def test_reference_accel_variants_agree(reference):
+    """The reference's SSE schedule (accel 12, 4 workers: examples/simple-perf/
+    simple.c:15-16) is bit-identical to its plain loop (accel 0)."""
+    rng = np.random.default_rng(5)
+    a = rng.random((200, 264), dtype=np.float32)
+    b = a.copy()
+    reference.lib.dwt_util_set_accel(0)
+    reference.lib.dwt_util_set_num_workers(1)
+    reference.fwd("cdf97_2f_s", a, 4)
+    reference.lib.dwt_util_set_accel(12)
+    reference.lib.dwt_util_set_num_workers(4)
+    reference.fwd("cdf97_2f_s", b, 4)
+    reference.lib.dwt_util_set_accel(0)
+    reference.lib.dwt_util_set_num_workers(1)
+    assert np.array_equal(bits(a), bits(b))
+
+
+def test_known_answers_constant_image(oracle):
+    """constant c => H subbands ~ 0 and LL ~ c*2^J for 9/7 (DC gain sqrt2
+    per 1-D pass); int 5/3: H == 0 exactly and LL == c."""
+    c, J, n = 3.0, 3, 64
+    a = np.full((n, n), c, np.float32)
+    assert oracle.fwd("cdf97_2f_s", a, J) == J
+    ll = n >> J
+    assert np.allclose(a[:ll, :ll], c * 2 ** J, rtol=2e-6)
+    mask = np.ones_like(a, bool)
+    mask[:ll, :ll] = False
+    assert np.abs(a[mask]).max() < 1e-5 * c
+    b = np.full((n, n), 77, np.int32)
+    oracle.fwd("cdf53_2f_i", b, J)
+    assert np.all(b[:ll, :ll] == 77) and np.all(b[mask] == 0)
+
+
+def test_roundtrip_and_linearity(oracle):
+    rng = np.random.default_rng(11)
+    a = rng.random((96, 80), dtype=np.float32)
+    b = rng.random((96, 80), dtype=np.float32)
+    ta, tb, tab = a.copy(), b.copy(), (a + b).astype(np.float32)
+    for t in (ta, tb, tab):
+        oracle.fwd("cdf97_2f_s", t, -1)
+    assert np.allclose(ta + tb, tab, atol=2e-4)
+    oracle.inv("cdf97_2i_s", ta, -1)
+    assert np.abs(ta - a).max() < 1e-4  # reference's own criterion is 1e-3 (libdwt.c:1604)
+    i = rng.integers(-32768, 32768, size=(75, 131), dtype=np.int32)
+    t = i.copy()
+    j = oracle.fwd("cdf53_2f_i", t, -1)
+    oracle.inv("cdf53_2i_i", t, j)
+    assert np.array_equal(t, i)
+
+
+def test_level_count_clamp(oracle):
+    a = np.zeros((40, 100), np.float32)
+    assert oracle.fwd("cdf97_2f_s", a.copy(), -1) == 6            # ceil_log2(40)
+    assert oracle.fwd("cdf97_2f_s", a.copy(), -1, decompose_one=1) == 7  # ceil_log2(100)
+    assert oracle.fwd("cdf97_2f_s", a.copy(), 99) == 6
+    assert oracle.fwd("cdf97_2f_s", a.copy(), 2) == 2
+
+
+def test_test_patterns_match_reference(oracle, reference):
+    for shape in [(17, 23), (64, 64)]:
+        a = np.zeros(shape, np.float32)
+        b = np.zeros(shape, np.float32)
+        oracle.fill_s(a)
+        reference.fill_s(b)
+        assert np.array_equal(bits(a), bits(b))
+        ai = np.zeros(shape, np.int32)
+        bi = np.zeros(shape, np.int32)
+        oracle.fill_i(ai)
+        reference.fill_i(bi)
+        assert np.array_equal(ai, bi)

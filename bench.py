@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X lifting-DWT path.
+
+Metric (BASELINE.json): Gsamples/s of the 2-D forward float CDF 9/7, 8192x8192,
+5 levels, device resident -- also quoted as a fraction of the 8 TB/s HBM3E peak via
+the algorithmic bytes of SURVEY.md s8(d) (10.656 B per input sample).
+
+A "step" is one pass of the hot path over one batch of `--images` distinct synthetic
+8192^2 images resident in HBM (out-of-place entry dwt_cdf97_2f_s2 semantics, one
+kernel launch per level for the whole batch).  With N GPUs every rank transforms its
+own batch (independent images: no data-path collective); value = all ranks' samples
+divided by the slowest rank's time ("scaling": "weak").
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes(w, h, levels, itemsize=4):
+    """per level one read + one write of that level's input region."""
+    total = 0
+    for j in range(levels):
+        total += 2 * itemsize * (-(-w // (1 << j))) * (-(-h // (1 << j)))
+    return total
+
+
+def cpu_baseline(size, levels):
+    """libdwt's own CPU path on the host cores (rank 0, N=1 only): oracle/_ref when it
+    was built (kind "reference"), else the bit-identical restatement (kind "port").
+    Bounded sample: ONE size x size image, min over 3 runs after 1 warm-up, following
+    dwt_util_perf_cdf97_2_s (src/libdwt.c:21444-21476; M=1)."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    import oraclelib
+
+    kind = "reference"
+    try:
+        if not os.path.exists(oraclelib.REF_SO):
+            raise FileNotFoundError
+        lib = oraclelib.Reference()
+        lib.lib.dwt_util_set_accel(0)
+        lib.lib.dwt_util_set_num_workers(1)
+    except Exception:
+        kind = "port"
+        lib = oraclelib.Oracle()
+    rng = np.random.default_rng(1234)
+    # pitch as dwt_util_get_stride(.,2) would pick it (power-of-two pitches alias in cache)
+    pitch_elems = size + 144 if size % 1024 == 0 else size
+    buf = np.zeros((size, pitch_elems), np.float32)
+    src = rng.random((size, size), dtype=np.float32)
+    best = None
+    for it in range(4):
+        buf[:, :size] = src
+        t0 = time.perf_counter()
+        lib.fwd("cdf97_2f_s", buf[:, :size], levels)
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+    return {"value": size * size / best / 1e9, "unit": "Gsamples/s", "cores": cores, "kind": kind,
+            "sample": f"1 image {size}x{size} float, {levels} levels, dwt_cdf97_2f_s accel 0, "
+                      f"{cores} OpenMP threads, pitch {pitch_elems * 4} B, min of 3 runs ({best:.3f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--images", type=int, default=4, help="distinct images per step and per GPU")
+    ap.add_argument("--inplace", action="store_true", help="time the in-place entry dwt_cdf97_2f_s instead of _s2")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")  # RCCL on ROCm; used for the barrier and the max-reduce only
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libdwt_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    os.environ["DWT_HIP_DEVICE"] = str(local_rank)
+
+    import libdwt_amd as dwt
+
+    dwt.dwt_util_init()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        dwt.set_option(k, int(v))
+    stream = torch.cuda.current_stream()
+    dwt.set_stream(stream.cuda_stream)
+
+    n, J, nb = args.size, args.levels, args.images
+    dev = torch.device("cuda", local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
+    dst = src.clone() if args.inplace else torch.empty_like(src)
+    img_bytes = n * n * 4
+
+    def step():
+        if args.inplace:
+            for k in range(nb):
+                dwt.dwt_cdf97_2f_s(dst[k], n * 4, 4, n, n, n, n, J)
+        else:
+            dwt.transform2d_batch("cdf97_s", 0, src, dst, img_bytes, nb, n * 4, n, n, J)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dwt.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches = dwt.prof_read()
+    dwt.prof_enable(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples = world * nb * n * n * args.steps
+    value = samples / elapsed / 1e9
+    alg = algorithmic_bytes(n, n, J)
+    # dominant kernel: the level-0 sweep; per launch it reads and writes the whole
+    # level-0 region of every image of the batch once
+    images_per_launch = 1 if args.inplace else nb
+    l0_bytes = 2 * 4 * n * n * images_per_launch
+    l0_ms = k_ms / max(k_launches, 1)
+    achieved = l0_bytes / (l0_ms * 1e-3) / 1e9 if k_launches else None
+
+    if rank == 0:
+        out = {
+            "metric": "Gsamples/s (= % HBM3E BW) CDF 9/7 2-D fwd float, 8192^2 5-level",
+            "value": round(value, 3),
+            "unit": "Gsamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, "
+                                   f"{nb} device-resident images per step per GPU, "
+                                   + ("in-place entry dwt_cdf97_2f_s" if args.inplace else "out-of-place entry (dwt_cdf97_2f_s2 semantics, batched)"),
+                       "entry": "dwt_cdf97_2f_s" if args.inplace else "dwt_cdf97_2f_s2",
+                       "images_per_step_per_gpu": nb, "parallelism": f"batch-sharded x{world}"},
+            "hbm_frac_algorithmic": round(value * 1e9 * alg / (n * n) / (HBM_PEAK_GBS * 1e9) / world, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "traffic": None, "kernel": "k_fwd_sweep<Cdf97S> level 0",
+                         "bytes_per_launch": l0_bytes, "avg_launch_ms": round(l0_ms, 5), "launches": k_launches},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, J)
+            except Exception as e:  # the checker is optional equipment of the bench
+                out["cpu_baseline"] = {"value": None, "unit": "Gsamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/*
+ * libdwt.h -- drop-in declarations for the hot-path subset of libdwt's C API, served
+ * by the MI355X backend (libdwt_amd/libdwt_hip.so).
+ *
+ * Written fresh: only the prototypes (names, argument order and meaning, in/out
+ * conventions, error behaviour) follow the reference so that a program written
+ * against xbarin02/libdwt -- e.g. its examples/simple/simple.c and
+ * examples/simple-int/simple.c -- compiles and links unchanged.  Each block cites
+ * the reference declaration it replaces (paths relative to the reference tree).
+ *
+ * Image addressing everywhere: element (y,x) lives at
+ *     (char *)ptr + y*stride_x + x*stride_y
+ * i.e. stride_x is the ROW pitch and stride_y the ELEMENT pitch, both in bytes
+ * (src/inline.h:180-189).  "size_o_big" is the outer allocated frame, "size_i_big"
+ * the inner image nested at its origin.
+ *
+ * `ptr` may be host memory (any strides; staged through HBM) or device memory
+ * (see libdwt_hip.h).  Failures are logged and abort(), as dwt_util_error does in
+ * the reference (src/libdwt.c:20410-20421); nothing falls back to a CPU path.
+ */
+#ifndef LIBDWT_H
+#define LIBDWT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 2-D multi-level transforms, Mallat layout ---------------------------------- */
+
+/* Forward float CDF 9/7, in place.  *j_max_ptr: requested levels in, levels done out;
+ * negative or too large means "as many as possible".  src/libdwt.h:562-573. */
+void dwt_cdf97_2f_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+
+/* Inverse float CDF 9/7, in place.  j_max < 0 undoes a full decomposition.
+ * src/libdwt.h:867-878. */
+void dwt_cdf97_2i_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+
+/* Out-of-place variants: first level reads src, everything lands in dst.
+ * src/libdwt.h:667-679, 962-974. */
+void dwt_cdf97_2f_s2(const void *src, void *dst, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void dwt_cdf97_2i_s2(const void *src, void *dst, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+
+/* Reversible int32 CDF 5/3.  src/libdwt.h:686, 981. */
+void dwt_cdf53_2f_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void dwt_cdf53_2i_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+
+/* Float CDF 5/3.  src/libdwt.h:722, 1053. */
+void dwt_cdf53_2f_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void dwt_cdf53_2i_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+
+/* ---- lifecycle and backend knobs (src/libdwt.h:1667-1745, 1974-1986) -------------- */
+void dwt_util_init(void);   /* brings the device up (the reference loads BCE firmware here) */
+void dwt_util_finish(void); /* releases device workspace */
+void dwt_util_abort(void);
+
+/* Acceleration selector.  The reference's values 0..16 choose among CPU loop
+ * schedules that all give the same coefficients (src/libdwt.h:1703-1720); here 0
+ * (default) runs the fused tile-sweep kernels and 1 the exact line-pass kernels;
+ * any other value is accepted and treated as 0. */
+void dwt_util_set_accel(int accel_type);
+int dwt_util_get_accel(void);
+/* Accepted for source compatibility; the device schedules its own waves. */
+void dwt_util_set_num_threads(int num_threads);
+int dwt_util_get_num_threads(void);
+int dwt_util_get_max_threads(void);
+void dwt_util_set_num_workers(int num_workers);
+int dwt_util_get_num_workers(void);
+
+/* ---- image helpers used by the examples (host memory) ---------------------------- */
+/* src/libdwt.h:2231, 2242 (next prime >= min_stride on x86_64; eight layouts) */
+int dwt_util_get_opt_stride(int min_stride);
+int dwt_util_get_stride(int min_stride, int opt);
+/* src/libdwt.h:2847 */
+size_t dwt_util_image_size(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y);
+/* src/libdwt.c:1437, 1482 */
+void dwt_util_alloc_image(void **pptr, int stride_x, int stride_y, int size_o_big_x, int size_o_big_y);
+void dwt_util_free_image(void **pptr);
+/* synthetic test patterns, src/libdwt.c:1338, 1270 */
+void dwt_util_test_image_fill_s(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand);
+void dwt_util_test_image_fill_i(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand);
+/* src/libdwt.c:21154, 21235 */
+void dwt_util_copy_s(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+void dwt_util_copy_i(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+/* returns 0 when equal: float within 1e-3 absolute and finite, int exactly
+ * (src/libdwt.c:1593-1620, 1531-1558) */
+int dwt_util_compare_s(void *ptr1, void *ptr2, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+int dwt_util_compare_i(void *ptr1, void *ptr2, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+/* log-magnitude view of a transform, src/libdwt.c:21075, 21020 */
+void dwt_util_conv_show_s(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+void dwt_util_conv_show_i(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+/* ASCII PGM writers, src/libdwt.h:1755, 1783; return 0 on success */
+int dwt_util_save_to_pgm_s(const char *filename, float max_value, const void *ptr, int stride_x, int stride_y,
+	int size_i_big_x, int size_i_big_y);
+int dwt_util_save_to_pgm_i(const char *filename, int max_value, const void *ptr, int stride_x, int stride_y,
+	int size_i_big_x, int size_i_big_y);
+
+/* ---- timers (src/libdwt.h:1589-1658) --------------------------------------------- */
+enum dwt_timer_types {
+	DWT_TIME_CLOCK_GETTIME,
+	DWT_TIME_CLOCK_GETTIME_REALTIME,
+	DWT_TIME_CLOCK_GETTIME_MONOTONIC,
+	DWT_TIME_CLOCK_GETTIME_MONOTONIC_RAW,
+	DWT_TIME_CLOCK_GETTIME_PROCESS_CPUTIME_ID,
+	DWT_TIME_CLOCK_GETTIME_THREAD_CPUTIME_ID,
+	DWT_TIME_CLOCK,
+	DWT_TIME_TIMES,
+	DWT_TIME_GETRUSAGE,
+	DWT_TIME_GETRUSAGE_SELF,
+	DWT_TIME_GETRUSAGE_CHILDREN,
+	DWT_TIME_GETRUSAGE_THREAD,
+	DWT_TIME_GETTIMEOFDAY,
+	DWT_TIME_IOCTL_RTC,
+	DWT_TIME_AUTOSELECT
+};
+typedef int64_t dwt_clock_t;
+int dwt_util_clock_available(int type);
+int dwt_util_clock_autoselect(void);
+dwt_clock_t dwt_util_get_frequency(int type);
+dwt_clock_t dwt_util_get_clock(int type);
+
+/* ---- logging and identification (src/libdwt.h:2154-2224, 1577-1582) --------------- */
+enum dwt_util_loglevel { LOG_NONE = 0, LOG_DBG, LOG_INFO, LOG_WARN, LOG_ERR, LOG_TEST };
+int dwt_util_log(enum dwt_util_loglevel level, const char *format, ...);
+void dwt_util_error(const char *format, ...);
+const char *dwt_util_version(void);
+const char *dwt_util_arch(void);
+const char *dwt_util_node(void);
+const char *dwt_util_appname(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,92 @@
+/*
+ * libdwt_hip.h -- C-ABI of the MI355X (gfx950) backend behind libdwt's 2-D entry
+ * points.  Plain C: pointers, ints and sizes only.
+ *
+ * The functions declared in include/libdwt.h (dwt_cdf97_2f_s & co.) are thin C
+ * wrappers over dwt_hip_transform2d(); this header is what a foreign-function
+ * binding (cgo, JNI, ctypes ...) or the reference's own sources would bind when they
+ * want the device path directly, keep images resident in HBM, run batches, pick a
+ * stream or read kernel timings.  See INTEGRATION.md.
+ *
+ * Pointer rule for every transform entry: `src`/`dst`/`ptr` may be ordinary host
+ * memory (any byte strides; staged through HBM, result copied back) or device
+ * memory (hipMalloc / dwt_hip_malloc / a torch tensor's data_ptr; requires
+ * stride_y == 4 and stride_x % 4 == 0; transformed in HBM, nothing crosses PCIe).
+ *
+ * Error rule: every int function returns 0 on success and non-zero on failure with
+ * a message retrievable by dwt_hip_last_error().  There is NO CPU fallback: without
+ * a usable gfx950 device every transform entry fails.
+ */
+#ifndef LIBDWT_HIP_H
+#define LIBDWT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* wavelet/type selectors; the 2-D drivers they replace are cited in libdwt.h */
+enum dwt_hip_wavelet {
+	DWT_HIP_CDF97_S = 0, /* float CDF 9/7: dwt_cdf97_2f_s / dwt_cdf97_2i_s (src/libdwt.c:12776, 17040) */
+	DWT_HIP_CDF53_I = 1, /* int32 CDF 5/3: dwt_cdf53_2f_i / dwt_cdf53_2i_i (src/libdwt.c:16304, 18142) */
+	DWT_HIP_CDF53_S = 2  /* float CDF 5/3: dwt_cdf53_2f_s / dwt_cdf53_2i_s (src/libdwt.c:16470, 18296) */
+};
+
+/* Lifecycle.  dwt_hip_init picks the device from DWT_HIP_DEVICE, else LOCAL_RANK,
+ * else 0; it is idempotent.  Replaces the BCE firmware load of dwt_util_init
+ * (src/libdwt.c:19158-19181). */
+int dwt_hip_init(void);
+void dwt_hip_finish(void);
+int dwt_hip_device_count(void);
+const char *dwt_hip_device_name(void);
+const char *dwt_hip_last_error(void);
+
+/* Run on this hipStream_t (NULL = the default stream). */
+void dwt_hip_set_stream(void *hip_stream);
+void dwt_hip_sync(void);
+
+/* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).
+ * Names: "generic" (1 = force the exact line-pass kernels), "cpt" (0/4/8),
+ * "tile_pairs" (0 = auto), "waves" (1..4), "xcd_swizzle" (0/1). */
+int dwt_hip_set_option(const char *name, int value);
+int dwt_hip_get_option(const char *name);
+
+/* Multi-level 2-D transform, Mallat layout, all arguments as in libdwt's drivers
+ * (src/libdwt.h:562-573, 867-878, 667-679, 962-974).  src == dst selects the
+ * in-place entries, src != dst the `_s2` out-of-place entries.  `*j` is in/out for
+ * forward (clamped as the reference does) and in for inverse. */
+int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst,
+	int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int *j, int decompose_one, int zero_padding);
+
+/* Batch of independent equally sized dense images resident in HBM, `batch_stride`
+ * bytes apart; one launch per level covers the whole batch. */
+int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *dst,
+	size_t batch_stride, int batch, int stride_x, int size_x, int size_y, int *j);
+
+/* Single-level 3-D CDF 9/7 float over the interleaved in-place layout of
+ * cdf97_3f_ip_sep_horizontal_s / cdf97_3i_ip_sep_horizontal_s
+ * (src/volume-dwt.c:677, 1115); `levels` > 1 re-applies it on the LLL lattice
+ * (strides doubled) as SURVEY.md s8 a11 describes.  Device pointer, dense x. */
+int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z,
+	int size_x, int size_y, int size_z, int levels);
+
+/* Device memory helpers so that C callers need no HIP headers. */
+void *dwt_hip_malloc(size_t bytes);
+void dwt_hip_free(void *dev_ptr);
+int dwt_hip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
+int dwt_hip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
+int dwt_hip_is_device_pointer(const void *p);
+
+/* Kernel timing with HIP events on the stream the kernels run on.  While enabled,
+ * every launch of the level-0 sweep kernel (the dominant kernel) is bracketed by
+ * an event pair; dwt_hip_prof_read synchronises and returns the summed duration
+ * and the number of launches since the last reset. */
+void dwt_hip_prof_enable(int on);
+int dwt_hip_prof_read(double *level0_ms_sum, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

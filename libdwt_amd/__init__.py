@@ -1,0 +1,314 @@
+"""libdwt_amd -- Python mirror of libdwt's 2-D DWT entry points over the MI355X backend.
+
+The product is the C-ABI shared library ``libdwt_amd/libdwt_hip.so`` (C host code +
+hand-written gfx950 HIP kernels; headers in ``include/``).  This module is only a
+ctypes binding with the reference's function names and argument order
+(``src/libdwt.h:562-573`` etc.), so tests read like programs written against libdwt:
+
+    import libdwt_amd as dwt
+    dwt.dwt_util_init()
+    j = dwt.dwt_cdf97_2f_s(img, stride_x, 4, w, h, w, h, -1, 0, 0)   # returns levels done
+    dwt.dwt_cdf97_2i_s(img, stride_x, 4, w, h, w, h, j, 0, 0)
+
+``img`` may be a numpy array (host memory: staged through HBM), a torch tensor
+(host or device), or a raw address (``int``) -- e.g. from ``dwt_hip_malloc``.
+
+There is no CPU fallback anywhere: if the library is missing, importing this module
+raises; if no gfx950 device is usable, every transform raises ``DwtError``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdwt_hip.so")
+
+CDF97_S, CDF53_I, CDF53_S = 0, 1, 2
+
+
+class DwtError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C libdwt_amd/csrc` (hipcc, gfx950). libdwt_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+_I, _P, _S = C.c_int, C.c_void_p, C.c_size_t
+_FWD = [_P, _I, _I, _I, _I, _I, _I, C.POINTER(_I), _I, _I]
+_INV = [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I]
+_FWD2 = [_P, _P] + _FWD[1:]
+_INV2 = [_P, _P] + _INV[1:]
+
+# libdwt entry points (void functions: they log + abort() on failure, like the
+# reference).  The Python wrappers below go through dwt_hip_transform2d instead so
+# that a failure surfaces as an exception rather than killing the interpreter.
+for _n, _sig in (("dwt_cdf97_2f_s", _FWD), ("dwt_cdf97_2i_s", _INV), ("dwt_cdf97_2f_s2", _FWD2),
+                 ("dwt_cdf97_2i_s2", _INV2), ("dwt_cdf53_2f_i", _FWD), ("dwt_cdf53_2i_i", _INV),
+                 ("dwt_cdf53_2f_s", _FWD), ("dwt_cdf53_2i_s", _INV)):
+    getattr(lib, _n).argtypes = _sig
+    getattr(lib, _n).restype = None
+
+lib.dwt_hip_init.restype = _I
+lib.dwt_hip_device_count.restype = _I
+lib.dwt_hip_device_name.restype = C.c_char_p
+lib.dwt_hip_last_error.restype = C.c_char_p
+lib.dwt_hip_set_stream.argtypes = [_P]
+lib.dwt_hip_set_option.argtypes = [C.c_char_p, _I]
+lib.dwt_hip_set_option.restype = _I
+lib.dwt_hip_get_option.argtypes = [C.c_char_p]
+lib.dwt_hip_get_option.restype = _I
+lib.dwt_hip_transform2d.argtypes = [_I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_I), _I, _I]
+lib.dwt_hip_transform2d.restype = _I
+lib.dwt_hip_transform2d_batch.argtypes = [_I, _I, _P, _P, _S, _I, _I, _I, _I, C.POINTER(_I)]
+lib.dwt_hip_transform2d_batch.restype = _I
+lib.dwt_hip_transform3d.argtypes = [_I, _P, _S, _S, _I, _I, _I, _I]
+lib.dwt_hip_transform3d.restype = _I
+lib.dwt_hip_malloc.argtypes = [_S]
+lib.dwt_hip_malloc.restype = _P
+lib.dwt_hip_free.argtypes = [_P]
+lib.dwt_hip_memcpy_h2d.argtypes = [_P, _P, _S]
+lib.dwt_hip_memcpy_h2d.restype = _I
+lib.dwt_hip_memcpy_d2h.argtypes = [_P, _P, _S]
+lib.dwt_hip_memcpy_d2h.restype = _I
+lib.dwt_hip_is_device_pointer.argtypes = [_P]
+lib.dwt_hip_is_device_pointer.restype = _I
+lib.dwt_hip_prof_enable.argtypes = [_I]
+lib.dwt_hip_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(_I)]
+lib.dwt_hip_prof_read.restype = _I
+lib.dwt_util_get_opt_stride.argtypes = [_I]
+lib.dwt_util_get_opt_stride.restype = _I
+lib.dwt_util_get_stride.argtypes = [_I, _I]
+lib.dwt_util_get_stride.restype = _I
+lib.dwt_util_set_accel.argtypes = [_I]
+lib.dwt_util_get_accel.restype = _I
+for _n in ("dwt_util_test_image_fill_s", "dwt_util_test_image_fill_i"):
+    getattr(lib, _n).argtypes = [_P, _I, _I, _I, _I, _I]
+    getattr(lib, _n).restype = None
+for _n in ("dwt_util_compare_s", "dwt_util_compare_i"):
+    getattr(lib, _n).argtypes = [_P, _P, _I, _I, _I, _I]
+    getattr(lib, _n).restype = _I
+for _n in ("dwt_util_conv_show_s", "dwt_util_conv_show_i", "dwt_util_copy_s", "dwt_util_copy_i"):
+    getattr(lib, _n).argtypes = [_P, _P, _I, _I, _I, _I]
+    getattr(lib, _n).restype = None
+lib.dwt_util_save_to_pgm_s.argtypes = [C.c_char_p, C.c_float, _P, _I, _I, _I, _I]
+lib.dwt_util_save_to_pgm_s.restype = _I
+lib.dwt_util_save_to_pgm_i.argtypes = [C.c_char_p, _I, _P, _I, _I, _I, _I]
+lib.dwt_util_save_to_pgm_i.restype = _I
+lib.dwt_util_version.restype = C.c_char_p
+
+
+def _addr(obj):
+    """Address of a numpy array / torch tensor / ctypes buffer / int."""
+    if obj is None:
+        raise DwtError("null image")
+    if isinstance(obj, int):
+        return obj
+    if hasattr(obj, "data_ptr"):  # torch tensor (host or device)
+        return obj.data_ptr()
+    if hasattr(obj, "ctypes"):  # numpy
+        return obj.ctypes.data
+    return C.cast(obj, C.c_void_p).value
+
+
+def last_error():
+    return lib.dwt_hip_last_error().decode(errors="replace")
+
+
+def _check(rc, what):
+    if rc:
+        raise DwtError(f"{what}: {last_error()}")
+
+
+# ---- lifecycle -----------------------------------------------------------------------
+def dwt_util_init():
+    _check(lib.dwt_hip_init(), "dwt_util_init")
+
+
+def dwt_util_finish():
+    lib.dwt_hip_finish()
+
+
+def dwt_util_set_accel(accel_type):
+    lib.dwt_util_set_accel(accel_type)
+
+
+def dwt_util_get_accel():
+    return lib.dwt_util_get_accel()
+
+
+def device_count():
+    return lib.dwt_hip_device_count()
+
+
+def device_name():
+    return lib.dwt_hip_device_name().decode()
+
+
+def set_stream(stream_handle):
+    """Run subsequent transforms on this hipStream_t (int handle; 0 = default)."""
+    lib.dwt_hip_set_stream(stream_handle)
+
+
+def use_torch_stream():
+    import torch
+
+    lib.dwt_hip_set_stream(torch.cuda.current_stream().cuda_stream)
+
+
+def sync():
+    lib.dwt_hip_sync()
+
+
+def set_option(name, value):
+    _check(lib.dwt_hip_set_option(name.encode(), int(value)), "dwt_hip_set_option")
+
+
+def get_option(name):
+    return lib.dwt_hip_get_option(name.encode())
+
+
+# ---- the reference's 2-D entry points --------------------------------------------------
+def _fwd(wavelet, src, dst, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding, who):
+    j = _I(j_max)
+    rc = lib.dwt_hip_transform2d(wavelet, 0, _addr(src), _addr(dst), stride_x, stride_y, sox, soy, six, siy,
+                                 C.byref(j), decompose_one, zero_padding)
+    _check(rc, who)
+    return j.value
+
+
+def _inv(wavelet, src, dst, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding, who):
+    j = _I(j_max)
+    rc = lib.dwt_hip_transform2d(wavelet, 1, _addr(src), _addr(dst), stride_x, stride_y, sox, soy, six, siy,
+                                 C.byref(j), decompose_one, zero_padding)
+    _check(rc, who)
+
+
+def dwt_cdf97_2f_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:12776.  Returns the level count the C function stores in *j_max_ptr."""
+    return _fwd(CDF97_S, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                j_max, decompose_one, zero_padding, "dwt_cdf97_2f_s")
+
+
+def dwt_cdf97_2i_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:17040"""
+    _inv(CDF97_S, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+         j_max, decompose_one, zero_padding, "dwt_cdf97_2i_s")
+
+
+def dwt_cdf97_2f_s2(src, dst, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                    j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:12619"""
+    return _fwd(CDF97_S, src, dst, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                j_max, decompose_one, zero_padding, "dwt_cdf97_2f_s2")
+
+
+def dwt_cdf97_2i_s2(src, dst, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                    j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:17985"""
+    _inv(CDF97_S, src, dst, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+         j_max, decompose_one, zero_padding, "dwt_cdf97_2i_s2")
+
+
+def dwt_cdf53_2f_i(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:16304"""
+    return _fwd(CDF53_I, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                j_max, decompose_one, zero_padding, "dwt_cdf53_2f_i")
+
+
+def dwt_cdf53_2i_i(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:18142"""
+    _inv(CDF53_I, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+         j_max, decompose_one, zero_padding, "dwt_cdf53_2i_i")
+
+
+def dwt_cdf53_2f_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:16470"""
+    return _fwd(CDF53_S, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                j_max, decompose_one, zero_padding, "dwt_cdf53_2f_s")
+
+
+def dwt_cdf53_2i_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:18296"""
+    _inv(CDF53_S, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+         j_max, decompose_one, zero_padding, "dwt_cdf53_2i_s")
+
+
+FORWARD = {"cdf97_s": dwt_cdf97_2f_s, "cdf53_i": dwt_cdf53_2f_i, "cdf53_s": dwt_cdf53_2f_s}
+INVERSE = {"cdf97_s": dwt_cdf97_2i_s, "cdf53_i": dwt_cdf53_2i_i, "cdf53_s": dwt_cdf53_2i_s}
+WAVELET_ID = {"cdf97_s": CDF97_S, "cdf53_i": CDF53_I, "cdf53_s": CDF53_S}
+
+
+# ---- batches resident in HBM -----------------------------------------------------------
+def transform2d_batch(wavelet, inverse, src, dst, batch_stride, batch, stride_x, size_x, size_y, j_max=-1):
+    j = _I(j_max)
+    rc = lib.dwt_hip_transform2d_batch(WAVELET_ID.get(wavelet, wavelet), int(inverse), _addr(src), _addr(dst),
+                                       batch_stride, batch, stride_x, size_x, size_y, C.byref(j))
+    _check(rc, "dwt_hip_transform2d_batch")
+    return j.value
+
+
+def transform3d(inverse, vol, stride_y, stride_z, size_x, size_y, size_z, levels=1):
+    _check(lib.dwt_hip_transform3d(int(inverse), _addr(vol), stride_y, stride_z, size_x, size_y, size_z, levels),
+           "dwt_hip_transform3d")
+
+
+# ---- device memory without torch -------------------------------------------------------
+class DeviceImage:
+    """A dense device-resident image (hipMalloc) addressed like libdwt images."""
+
+    def __init__(self, height, width, itemsize=4, pitch_bytes=None):
+        self.h, self.w = height, width
+        self.stride_x = pitch_bytes or width * itemsize
+        self.stride_y = itemsize
+        self.nbytes = self.stride_x * height
+        self.ptr = lib.dwt_hip_malloc(max(self.nbytes, 16))
+        if not self.ptr:
+            raise DwtError("dwt_hip_malloc: " + last_error())
+
+    def upload(self, arr):
+        import numpy as np
+
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes == self.nbytes, (a.nbytes, self.nbytes)
+        _check(lib.dwt_hip_memcpy_h2d(self.ptr, a.ctypes.data, self.nbytes), "h2d")
+        return self
+
+    def download(self, dtype):
+        import numpy as np
+
+        out = np.empty((self.h, self.stride_x // 4), dtype=dtype)
+        _check(lib.dwt_hip_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes), "d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib.dwt_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- kernel timing ----------------------------------------------------------------------
+def prof_enable(on=True):
+    lib.dwt_hip_prof_enable(int(bool(on)))
+
+
+def prof_read():
+    """(summed ms of the level-0 sweep kernel launches, number of launches) since last read."""
+    ms, n = C.c_double(0), _I(0)
+    _check(lib.dwt_hip_prof_read(C.byref(ms), C.byref(n)), "dwt_hip_prof_read")
+    return ms.value, n.value

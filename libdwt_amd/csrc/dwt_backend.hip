@@ -1,0 +1,753 @@
+// dwt_backend.hip -- device context, workspace, host<->HBM staging and the multi-level
+// drivers behind the C-ABI of include/libdwt_hip.h.
+//
+// Level scheduling (forward, dense frame).  libdwt transforms in place
+// (src/libdwt.c:12812-12919): level j reads the LL region of the image and writes
+// its four subbands over it.  A fused tile sweep cannot do that (one tile's outputs
+// land on another tile's inputs), so the driver keeps the running LL band in a
+// small ping-pong scratch instead of the image:
+//
+//     level 0 : image            -> HL/LH/HH at their final place, LL -> scratch0
+//     level j : scratch[(j-1)&1] -> HL/LH/HH at their final place, LL -> scratch[j&1]
+//     last    :                     LL -> its final place too
+//
+// Every level therefore reads its input once and writes its output once: the
+// algorithmic traffic 2*sizeof(T)*sum_j(W_j*H_j).  Only when the caller's source
+// and destination are the SAME device buffer does level 0 have to detour its detail
+// subbands through a staging image and copy them back (the `_s2` entries and every
+// host-pointer call avoid that).  The inverse runs the mirror image of this.
+//
+// Frames with size_o != size_i, zero padding, and levels where a direction has a
+// single line follow the reference's exact line-by-line semantics through the
+// generic line-pass kernel, out of place per pass.
+#include "../../include/libdwt_hip.h"
+#include "dwt_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace dwt;
+
+namespace {
+
+struct Ctx {
+	bool inited = false;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	char devname[256] = {0};
+	// workspace
+	void *stage_img = nullptr; // frame-sized staging image (in-place detour, generic passes)
+	size_t stage_bytes = 0;
+	void *ll[2] = {nullptr, nullptr}; // LL ping-pong
+	size_t ll_bytes[2] = {0, 0};
+	void *host_a = nullptr, *host_b = nullptr; // device images for host-pointer calls
+	size_t host_a_bytes = 0, host_b_bytes = 0;
+	// options
+	SweepTuning tune;
+	int force_generic = 0;
+	// profiling
+	int prof_on = 0;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+	size_t prof_used = 0;
+	double prof_ms = 0;
+	int prof_launches = 0;
+};
+
+Ctx g;
+thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                \
+		if (e_ != hipSuccess)                                                                  \
+			return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+inline int ceil_div_pow2(int i, int j) { return (i + (1 << j) - 1) >> j; } // src/inline.h:455-461
+inline int ceil_log2(int x)                                               // src/inline.h:443-448
+{
+	int n = 0;
+	while (n < 31 && (1 << n) < x)
+		n++;
+	return n;
+}
+inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+int grow(void **p, size_t *have, size_t need)
+{
+	if (*have >= need)
+		return 0;
+	if (*p) {
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		HIP_TRY(hipFree(*p));
+		*p = nullptr;
+		*have = 0;
+	}
+	HIP_TRY(hipMalloc(p, need));
+	*have = need;
+	return 0;
+}
+
+// A device image: element (y,x) at p + y*sx + x*4 (element stride is always 4 here).
+struct Img {
+	char *p;
+	long sx; // row pitch in bytes
+};
+
+struct Geom {
+	int sox, soy, six, siy;
+	int Wo(int j) const { return ceil_div_pow2(sox, j); }
+	int Ho(int j) const { return ceil_div_pow2(soy, j); }
+	int Wi(int j) const { return ceil_div_pow2(six, j); }
+	int Hi(int j) const { return ceil_div_pow2(siy, j); }
+	bool dense() const { return sox == six && soy == siy; }
+};
+
+bool skip_single(Wavelet w) { return w == kCdf97S; } // only the 9/7 drivers guard on lines > 1
+
+int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h)
+{
+	if (w <= 0 || h <= 0)
+		return 0;
+	HIP_TRY(hipMemcpy2DAsync(dst.p + dy * dst.sx + dx * 4, dst.sx, src.p + sy_ * src.sx + sx_ * 4, src.sx, w * 4, h,
+		hipMemcpyDeviceToDevice, g.stream));
+	return 0;
+}
+
+int zero_rect(Img img, long x, long y, long w, long h)
+{
+	if (w <= 0 || h <= 0)
+		return 0;
+	HIP_TRY(hipMemset2DAsync(img.p + y * img.sx + x * 4, img.sx, 0, w * 4, h, g.stream));
+	return 0;
+}
+
+// One generic 1-D pass over the frame of a level (rows: lines are image rows).
+// in == out is handled by staging the frame -- pass-through elements included -- in
+// an image with the caller's pitch, so the kernel sees one pair of strides.
+int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_w, int frame_h, int n_lines, int N, int hoff)
+{
+	if (n_lines <= 0 || N <= 0)
+		return 0;
+	if (N == 1 && w == kCdf53I)
+		return 0;
+	const bool alias = in.p == out.p;
+	Img dst = out;
+	if (alias) {
+		// staging image with the SAME pitch as the caller's image
+		if (grow(&g.stage_img, &g.stage_bytes, (size_t)out.sx * frame_h))
+			return 1;
+		dst = Img{(char *)g.stage_img, out.sx};
+		if (copy_rect(dst, 0, 0, out, 0, 0, frame_w, frame_h))
+			return 1;
+	} else if (in.sx != out.sx) {
+		return fail("generic pass: source and destination pitches differ (%ld vs %ld)", in.sx, out.sx);
+	}
+	hipError_t e = launch_line_pass(w, inverse, in.p, dst.p, rows ? in.sx : 4, rows ? 4 : in.sx, n_lines, N, hoff, !rows, g.stream);
+	if (e != hipSuccess)
+		return fail("line pass launch failed: %s", hipGetErrorString(e));
+	if (alias && copy_rect(out, 0, 0, dst, 0, 0, frame_w, frame_h))
+		return 1;
+	return 0;
+}
+
+void prof_before()
+{
+	if (!g.prof_on)
+		return;
+	if (g.prof_used == g.prof_events.size()) {
+		hipEvent_t a, b;
+		hipEventCreate(&a);
+		hipEventCreate(&b);
+		g.prof_events.push_back({a, b});
+	}
+	hipEventRecord(g.prof_events[g.prof_used].first, g.stream);
+}
+
+void prof_after()
+{
+	if (!g.prof_on)
+		return;
+	hipEventRecord(g.prof_events[g.prof_used].second, g.stream);
+	g.prof_used++;
+}
+
+int prof_drain()
+{
+	if (g.prof_used == 0)
+		return 0;
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	for (size_t i = 0; i < g.prof_used; i++) {
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, g.prof_events[i].first, g.prof_events[i].second));
+		g.prof_ms += ms;
+		g.prof_launches++;
+	}
+	g.prof_used = 0;
+	return 0;
+}
+
+long ll_pitch_elems(int w) { return align_up(w, 4); }
+
+int ensure_ll(const Geom &ge, int batch)
+{
+	for (int k = 0; k < 2; k++) {
+		const int w = ge.Wo(k + 1), h = ge.Ho(k + 1);
+		if (grow(&g.ll[k], &g.ll_bytes[k], (size_t)ll_pitch_elems(w) * h * 4 * batch + 64))
+			return 1;
+	}
+	return 0;
+}
+
+bool level_fused_ok(const Geom &ge, int j)
+{
+	return !g.force_generic && ge.Wi(j) == ge.Wo(j) && ge.Hi(j) == ge.Ho(j) && ge.Wo(j) >= 2 && ge.Ho(j) >= 2;
+}
+
+// ---- forward ---------------------------------------------------------------------
+int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompose_one, int zero_padding,
+	int batch, long src_bstride, long dst_bstride)
+{
+	const int so_min = ge.sox < ge.soy ? ge.sox : ge.soy, so_max = ge.sox > ge.soy ? ge.sox : ge.soy;
+	const int j_limit = ceil_log2(decompose_one ? so_max : so_min);
+	if (*jp < 0 || *jp > j_limit)
+		*jp = j_limit; // src/libdwt.c:12807-12810
+	const int J = *jp;
+	if (J == 0)
+		return 0;
+	if (ensure_ll(ge, batch))
+		return 1;
+
+	// where the running LL band lives: -1 = in `cur` image (src before level 0, dst after), else scratch index
+	int ll_in = -1;
+	Img cur = src;
+	for (int j = 0; j < J; j++) {
+		const int Wo = ge.Wo(j), Ho = ge.Ho(j), Wi = ge.Wi(j), Hi = ge.Hi(j);
+		const int Wd = ge.Wo(j + 1), Hd = ge.Ho(j + 1);
+		if (level_fused_ok(ge, j)) {
+			const bool last = (j == J - 1) || !level_fused_ok(ge, j + 1);
+			FwdLevelArgs a;
+			a.W = Wo;
+			a.H = Ho;
+			a.batch = batch;
+			bool detour = false;
+			if (ll_in < 0) {
+				a.in = cur.p;
+				a.in_pitch = cur.sx / 4;
+				a.in_bstride = (cur.p == src.p ? src_bstride : dst_bstride) / 4;
+				detour = (cur.p == dst.p); // reading the image we also write: stage the outputs
+			} else {
+				a.in = g.ll[ll_in];
+				a.in_pitch = ll_pitch_elems(Wo);
+				a.in_bstride = a.in_pitch * Ho;
+			}
+			Img hdst = dst;
+			long h_bstride = dst_bstride;
+			if (detour) {
+				if (batch != 1)
+					return fail("in-place batches are not supported; use distinct src and dst");
+				if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
+					return 1;
+				hdst = Img{(char *)g.stage_img, dst.sx};
+				h_bstride = 0;
+			}
+			a.out_h = hdst.p;
+			a.h_pitch = hdst.sx / 4;
+			a.h_bstride = h_bstride / 4;
+			const int ll_out = last ? -1 : (j & 1);
+			if (last) {
+				a.out_ll = hdst.p;
+				a.ll_pitch = a.h_pitch;
+				a.ll_bstride = a.h_bstride;
+			} else {
+				a.out_ll = g.ll[ll_out];
+				a.ll_pitch = ll_pitch_elems(Wd);
+				a.ll_bstride = a.ll_pitch * Hd;
+			}
+			if (j == 0)
+				prof_before();
+			hipError_t e = launch_fwd_level(w, a, g.tune, g.stream);
+			if (j == 0)
+				prof_after();
+			if (e != hipSuccess)
+				return fail("forward level %d launch failed: %s", j, hipGetErrorString(e));
+			if (detour) {
+				// copy the staged subbands to their place: right half, bottom-left, and
+				// the LL quadrant too when it was written here
+				if (copy_rect(dst, Wd, 0, hdst, Wd, 0, Wo - Wd, Ho) || copy_rect(dst, 0, Hd, hdst, 0, Hd, Wd, Ho - Hd))
+					return 1;
+				if (last && copy_rect(dst, 0, 0, hdst, 0, 0, Wd, Hd))
+					return 1;
+			}
+			ll_in = ll_out;
+			cur = dst;
+			continue;
+		}
+
+		// ---- generic level: exact line semantics, in place on dst ----
+		if (batch != 1)
+			return fail("batched transforms need dense frames with both sides >= 2 at every level");
+		if (ll_in >= 0) {
+			// bring the LL band back into the image
+			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Wo) * 4};
+			if (copy_rect(dst, 0, 0, s, 0, 0, Wo, Ho))
+				return 1;
+			ll_in = -1;
+			cur = dst;
+		}
+		if (!skip_single(w) || Wo > 1) {
+			if (generic_pass(w, false, true, cur, dst, Wo, Ho, Ho, Wi, Wd))
+				return 1;
+			cur = dst; // src/libdwt.c:12709
+		}
+		if (!skip_single(w) || Ho > 1) {
+			if (generic_pass(w, false, false, cur, dst, Wo, Ho, Wo, Hi, Hd))
+				return 1;
+			cur = dst; // src/libdwt.c:12742
+		}
+		if (zero_padding) {
+			// dwt_zero_padding_f_stride_* (src/libdwt.c:12079-12131) over rows then columns
+			const int nl_x = (Wi + 1) >> 1, nh_x = Wi >> 1, nl_y = (Hi + 1) >> 1, nh_y = Hi >> 1;
+			if (zero_rect(dst, nl_x, 0, Wd - nl_x, Ho) || zero_rect(dst, Wd + nh_x, 0, (Wo - Wd) - nh_x, Ho) ||
+				zero_rect(dst, 0, nl_y, Wo, Hd - nl_y) || zero_rect(dst, 0, Hd + nh_y, Wo, (Ho - Hd) - nh_y))
+				return 1;
+		}
+	}
+	return 0;
+}
+
+// ---- inverse ---------------------------------------------------------------------
+int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decompose_one, int zero_padding,
+	int batch, long src_bstride, long dst_bstride)
+{
+	const int so_min = ge.sox < ge.soy ? ge.sox : ge.soy, so_max = ge.sox > ge.soy ? ge.sox : ge.soy;
+	int J = ceil_log2(decompose_one ? so_max : so_min);
+	if (j_max >= 0 && j_max < J)
+		J = j_max; // src/libdwt.c:17069-17072
+	if (J == 0) {
+		// dwt_cdf97_2i_s2 still copies the inner region (src/libdwt.c:18001-18008)
+		if (src.p != dst.p && copy_rect(dst, 0, 0, src, 0, 0, ge.six, ge.siy))
+			return 1;
+		return 0;
+	}
+	if (ensure_ll(ge, batch))
+		return 1;
+	const bool cols_first = (w == kCdf53I);
+
+	// reconstruction level j consumes the subbands of size ceil(.,j) and produces the
+	// band of size ceil(.,j-1); it is fused when that PRODUCED frame is dense and >= 2
+	auto fused_ok = [&](int j) { return level_fused_ok(ge, j - 1); };
+
+	Img cur = src;          // image holding the not-yet-consumed subbands
+	long cur_bstride = src_bstride;
+	int ll_in = -1;         // -1: LL band is in `cur`; else scratch index
+	bool copied = false;
+	for (int j = J; j >= 1; j--) {
+		const int Ws = ge.Wo(j), Hs = ge.Ho(j);       // subband sizes (= Mallat offsets)
+		const int Wo = ge.Wo(j - 1), Ho = ge.Ho(j - 1); // produced frame
+		const int Wi = ge.Wi(j - 1), Hi = ge.Hi(j - 1);
+		if (fused_ok(j)) {
+			InvLevelArgs a;
+			a.W = Wo;
+			a.H = Ho;
+			a.batch = batch;
+			a.in_h = cur.p;
+			a.h_pitch = cur.sx / 4;
+			a.h_bstride = cur_bstride / 4;
+			if (ll_in < 0) {
+				a.in_ll = cur.p;
+				a.ll_pitch = cur.sx / 4;
+				a.ll_bstride = cur_bstride / 4;
+			} else {
+				a.in_ll = g.ll[ll_in];
+				a.ll_pitch = ll_pitch_elems(Ws);
+				a.ll_bstride = a.ll_pitch * Hs;
+			}
+			const bool last = (j == 1);
+			int ll_out = -1;
+			if (last) {
+				a.out = dst.p;
+				a.out_pitch = dst.sx / 4;
+				a.out_bstride = dst_bstride / 4;
+				if (cur.p == dst.p) {
+					// in place: the final level would overwrite subbands it still reads;
+					// move them (right half + bottom-left, and LL if it is still there) aside
+					if (batch != 1)
+						return fail("in-place batches are not supported; use distinct src and dst");
+					if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
+						return 1;
+					Img st{(char *)g.stage_img, dst.sx};
+					if (copy_rect(st, Ws, 0, cur, Ws, 0, Wo - Ws, Ho) || copy_rect(st, 0, Hs, cur, 0, Hs, Ws, Ho - Hs))
+						return 1;
+					if (ll_in < 0 && copy_rect(st, 0, 0, cur, 0, 0, Ws, Hs))
+						return 1;
+					a.in_h = st.p;
+					a.h_bstride = 0;
+					if (ll_in < 0)
+						a.in_ll = st.p;
+				}
+			} else {
+				ll_out = j & 1; // band of level m = j-1 lives in scratch (m-1)&1, as in the forward driver
+				a.out = g.ll[ll_out];
+				a.out_pitch = ll_pitch_elems(Wo);
+				a.out_bstride = a.out_pitch * Ho;
+			}
+			if (last)
+				prof_before();
+			hipError_t e = launch_inv_level(w, a, g.tune, g.stream);
+			if (last)
+				prof_after();
+			if (e != hipSuccess)
+				return fail("inverse level %d launch failed: %s", j, hipGetErrorString(e));
+			ll_in = ll_out;
+			continue;
+		}
+
+		// ---- generic level, in place on dst ----
+		if (batch != 1)
+			return fail("batched transforms need dense frames with both sides >= 2 at every level");
+		if (src.p != dst.p && !copied) {
+			// the `_s2` entry copies the inner region, then works in place (:18001-18008)
+			if (copy_rect(dst, 0, 0, src, 0, 0, ge.six, ge.siy))
+				return 1;
+			copied = true;
+		}
+		cur = dst;
+		cur_bstride = dst_bstride;
+		for (int pass = 0; pass < 2; pass++) {
+			const bool rows = cols_first ? (pass == 1) : (pass == 0);
+			if (rows) {
+				if (!skip_single(w) || Wo > 1)
+					if (generic_pass(w, true, true, dst, dst, Wo, Ho, Ho, Wi, Ws))
+						return 1;
+			} else {
+				if (!skip_single(w) || Ho > 1)
+					if (generic_pass(w, true, false, dst, dst, Wo, Ho, Wo, Hi, Hs))
+						return 1;
+			}
+		}
+		if (zero_padding) {
+			// dwt_zero_padding_i_stride_* (src/libdwt.c:12161-12215)
+			if (zero_rect(dst, Wi, 0, Wo - Wi, Ho) || zero_rect(dst, 0, Hi, Wo, Ho - Hi))
+				return 1;
+		}
+	}
+	return 0;
+}
+
+int check_inited()
+{
+	if (!g.inited && dwt_hip_init())
+		return 1;
+	return 0;
+}
+
+} // namespace
+
+// ---- C ABI ------------------------------------------------------------------------
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char *dwt_hip_last_error(void) { return g_err; }
+
+int dwt_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int dwt_hip_init(void)
+{
+	if (g.inited)
+		return 0;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return fail("no HIP device available (%s); libdwt_amd has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+	int dev = 0;
+	const char *env = getenv("DWT_HIP_DEVICE");
+	if (!env)
+		env = getenv("LOCAL_RANK");
+	if (env)
+		dev = atoi(env) % n;
+	HIP_TRY(hipSetDevice(dev));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, dev));
+	snprintf(g.devname, sizeof(g.devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+	if (!strstr(prop.gcnArchName, "gfx950"))
+		return fail("device %d is %s; this library carries gfx950 code only", dev, prop.gcnArchName);
+	g.device = dev;
+	g.inited = true;
+	return 0;
+}
+
+void dwt_hip_finish(void)
+{
+	if (!g.inited)
+		return;
+	hipStreamSynchronize(g.stream);
+	void **bufs[] = {&g.stage_img, &g.ll[0], &g.ll[1], &g.host_a, &g.host_b};
+	for (void **b : bufs) {
+		if (*b)
+			hipFree(*b);
+		*b = nullptr;
+	}
+	g.stage_bytes = g.ll_bytes[0] = g.ll_bytes[1] = g.host_a_bytes = g.host_b_bytes = 0;
+	for (auto &ev : g.prof_events) {
+		hipEventDestroy(ev.first);
+		hipEventDestroy(ev.second);
+	}
+	g.prof_events.clear();
+	g.prof_used = 0;
+	// the context stays usable: a later call re-allocates its workspace
+}
+
+const char *dwt_hip_device_name(void)
+{
+	if (check_inited())
+		return "";
+	return g.devname;
+}
+
+void dwt_hip_set_stream(void *s) { g.stream = (hipStream_t)s; }
+
+void dwt_hip_sync(void)
+{
+	if (g.inited)
+		hipStreamSynchronize(g.stream);
+}
+
+int dwt_hip_set_option(const char *name, int value)
+{
+	if (!strcmp(name, "generic"))
+		g.force_generic = value;
+	else if (!strcmp(name, "cpt"))
+		g.tune.cpt = value;
+	else if (!strcmp(name, "tile_pairs"))
+		g.tune.tile_pairs = value;
+	else if (!strcmp(name, "waves"))
+		g.tune.waves = value;
+	else if (!strcmp(name, "xcd_swizzle"))
+		g.tune.xcd_swizzle = value;
+	else
+		return fail("unknown option '%s'", name);
+	return 0;
+}
+
+int dwt_hip_get_option(const char *name)
+{
+	if (!strcmp(name, "generic"))
+		return g.force_generic;
+	if (!strcmp(name, "cpt"))
+		return g.tune.cpt;
+	if (!strcmp(name, "tile_pairs"))
+		return g.tune.tile_pairs;
+	if (!strcmp(name, "waves"))
+		return g.tune.waves;
+	if (!strcmp(name, "xcd_swizzle"))
+		return g.tune.xcd_swizzle;
+	return -1;
+}
+
+int dwt_hip_is_device_pointer(const void *p)
+{
+	hipPointerAttribute_t at;
+	hipError_t e = hipPointerGetAttributes(&at, p);
+	if (e != hipSuccess) {
+		(void)hipGetLastError(); // plain host memory reports an error; clear it
+		return 0;
+	}
+	return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+void *dwt_hip_malloc(size_t bytes)
+{
+	if (check_inited())
+		return nullptr;
+	void *p = nullptr;
+	if (hipMalloc(&p, bytes) != hipSuccess) {
+		fail("hipMalloc(%zu) failed", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+void dwt_hip_free(void *p)
+{
+	if (p)
+		hipFree(p);
+}
+
+int dwt_hip_memcpy_h2d(void *d, const void *h, size_t n)
+{
+	if (check_inited())
+		return 1;
+	HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+int dwt_hip_memcpy_d2h(void *h, const void *d, size_t n)
+{
+	if (check_inited())
+		return 1;
+	HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+void dwt_hip_prof_enable(int on)
+{
+	if (g.inited)
+		prof_drain();
+	g.prof_on = on;
+	g.prof_ms = 0;
+	g.prof_launches = 0;
+}
+
+int dwt_hip_prof_read(double *ms, int *launches)
+{
+	if (prof_drain())
+		return 1;
+	if (ms)
+		*ms = g.prof_ms;
+	if (launches)
+		*launches = g.prof_launches;
+	g.prof_ms = 0;
+	g.prof_launches = 0;
+	return 0;
+}
+
+int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, int stride_x, int stride_y,
+	int sox, int soy, int six, int siy, int *j, int decompose_one, int zero_padding)
+{
+	if (check_inited())
+		return 1;
+	if (wavelet < 0 || wavelet > 2)
+		return fail("unknown wavelet %d", wavelet);
+	if (!src || !dst || !j)
+		return fail("null pointer argument");
+	if (sox <= 0 || soy <= 0 || six < 0 || siy < 0 || six > sox || siy > soy)
+		return fail("bad sizes: outer %dx%d inner %dx%d", sox, soy, six, siy);
+	const Wavelet w = (Wavelet)wavelet;
+	const Geom ge{sox, soy, six, siy};
+	const bool dev_src = dwt_hip_is_device_pointer(src), dev_dst = dwt_hip_is_device_pointer(dst);
+	if (dev_src != dev_dst)
+		return fail("src and dst must both be host or both be device pointers");
+
+	if (dev_dst) {
+		if (stride_y != 4 || (stride_x & 3) || stride_x < sox * 4)
+			return fail("device images need stride_y == 4 and stride_x a multiple of 4 >= width*4 (got %d, %d)", stride_x, stride_y);
+		Img s{(char *)src, stride_x}, d{(char *)dst, stride_x};
+		return inverse ? inverse2d(w, s, d, ge, *j, decompose_one, zero_padding, 1, 0, 0)
+		               : forward2d(w, s, d, ge, j, decompose_one, zero_padding, 1, 0, 0);
+	}
+
+	// ---- host pointers: stage the whole outer frame through HBM ----
+	const long pitch = align_up((long)sox * 4, 256);
+	const size_t bytes = (size_t)pitch * soy;
+	if (grow(&g.host_a, &g.host_a_bytes, bytes) || grow(&g.host_b, &g.host_b_bytes, bytes))
+		return 1;
+	const bool s2 = (src != dst);
+	// dense element stride: one 2-D copy; otherwise gather on the host first
+	std::vector<char> packed;
+	auto upload = [&](const void *hp, void *dp) -> int {
+		if (stride_y == 4) {
+			HIP_TRY(hipMemcpy2DAsync(dp, pitch, hp, stride_x, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+		} else {
+			packed.resize((size_t)sox * soy * 4);
+			for (int y = 0; y < soy; y++)
+				for (int x = 0; x < sox; x++)
+					memcpy(&packed[((size_t)y * sox + x) * 4], (const char *)hp + (long)y * stride_x + (long)x * stride_y, 4);
+			HIP_TRY(hipMemcpy2DAsync(dp, pitch, packed.data(), (size_t)sox * 4, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+		}
+		return 0;
+	};
+	auto download = [&](void *hp, const void *dp) -> int {
+		if (stride_y == 4) {
+			HIP_TRY(hipMemcpy2DAsync(hp, stride_x, dp, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+		} else {
+			packed.resize((size_t)sox * soy * 4);
+			HIP_TRY(hipMemcpy2DAsync(packed.data(), (size_t)sox * 4, dp, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			for (int y = 0; y < soy; y++)
+				for (int x = 0; x < sox; x++)
+					memcpy((char *)hp + (long)y * stride_x + (long)x * stride_y, &packed[((size_t)y * sox + x) * 4], 4);
+		}
+		return 0;
+	};
+	Img A{(char *)g.host_a, pitch}, B{(char *)g.host_b, pitch};
+	if (upload(src, A.p))
+		return 1;
+	// B receives the result.  It starts as a copy of what the destination holds so
+	// that every element the reference leaves untouched keeps its value.
+	if (s2) {
+		if (upload(dst, B.p))
+			return 1;
+	} else {
+		if (copy_rect(B, 0, 0, A, 0, 0, sox, soy))
+			return 1;
+	}
+	int rc;
+	if (s2 || ge.dense()) {
+		// out of place on the device: no in-place detour even for the in-place entry
+		rc = inverse ? inverse2d(w, A, B, ge, *j, decompose_one, zero_padding, 1, 0, 0)
+		             : forward2d(w, A, B, ge, j, decompose_one, zero_padding, 1, 0, 0);
+	} else {
+		rc = inverse ? inverse2d(w, B, B, ge, *j, decompose_one, zero_padding, 1, 0, 0)
+		             : forward2d(w, B, B, ge, j, decompose_one, zero_padding, 1, 0, 0);
+	}
+	if (rc)
+		return rc;
+	return download(dst, B.p);
+}
+
+int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *dst, size_t batch_stride, int batch,
+	int stride_x, int size_x, int size_y, int *j)
+{
+	if (check_inited())
+		return 1;
+	if (wavelet < 0 || wavelet > 2)
+		return fail("unknown wavelet %d", wavelet);
+	if (!src || !dst || !j || batch < 1)
+		return fail("bad argument");
+	if (!dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
+		return fail("batched transforms take device pointers");
+	if ((stride_x & 3) || stride_x < size_x * 4 || (batch_stride & 3) || batch_stride < (size_t)stride_x * size_y)
+		return fail("bad strides");
+	if (batch > 1 && src == dst)
+		return fail("in-place batches are not supported; use distinct src and dst");
+	const Geom ge{size_x, size_y, size_x, size_y};
+	Img s{(char *)src, stride_x}, d{(char *)dst, stride_x};
+	return inverse ? inverse2d((Wavelet)wavelet, s, d, ge, *j, 0, 0, batch, (long)batch_stride, (long)batch_stride)
+	               : forward2d((Wavelet)wavelet, s, d, ge, j, 0, 0, batch, (long)batch_stride, (long)batch_stride);
+}
+
+int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
+{
+	(void)inverse; (void)vol; (void)stride_y; (void)stride_z; (void)nx; (void)ny; (void)nz; (void)levels;
+	if (check_inited())
+		return 1;
+	return fail("dwt_hip_transform3d: not built yet");
+}
+
+} // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,139 @@
+/*
+ * dwt_entry.c -- libdwt's 2-D entry points and lifecycle hooks as thin C wrappers
+ * over the device backend (include/libdwt_hip.h).  Host code in C; all compute is in
+ * the HIP kernels.  There is no CPU path here: a call that cannot run on the device
+ * logs the reason and aborts, as dwt_util_error does in the reference
+ * (src/libdwt.c:20410-20421).
+ */
+#include "../../include/libdwt.h"
+#include "../../include/libdwt_hip.h"
+
+#include <stdlib.h>
+
+static int g_accel = 0;
+static int g_threads = 1;
+static int g_workers = 1;
+
+static void run(int wavelet, int inverse, const void *src, void *dst, int stride_x, int stride_y,
+	int sox, int soy, int six, int siy, int *j, int decompose_one, int zero_padding, const char *who)
+{
+	if (dwt_hip_transform2d(wavelet, inverse, src, dst, stride_x, stride_y, sox, soy, six, siy, j, decompose_one, zero_padding))
+		dwt_util_error("%s: %s\n", who, dwt_hip_last_error());
+}
+
+/* src/libdwt.c:12776 */
+void dwt_cdf97_2f_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF97_S, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:17040 */
+void dwt_cdf97_2i_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF97_S, 1, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:12619 */
+void dwt_cdf97_2f_s2(const void *src, void *dst, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF97_S, 0, src, dst, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:17985 */
+void dwt_cdf97_2i_s2(const void *src, void *dst, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF97_S, 1, src, dst, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:16304 */
+void dwt_cdf53_2f_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF53_I, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:18142 */
+void dwt_cdf53_2i_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF53_I, 1, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:16470 */
+void dwt_cdf53_2f_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF53_S, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:18296 */
+void dwt_cdf53_2i_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF53_S, 1, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, zero_padding, __func__);
+}
+
+/* src/libdwt.c:19158: platform bring-up.  The reference loads accelerator firmware
+ * on ASVP and does nothing on x86; here the device context is created. */
+void dwt_util_init(void)
+{
+	if (dwt_hip_init())
+		dwt_util_error("dwt_util_init: %s\n", dwt_hip_last_error());
+}
+
+/* src/libdwt.c:19186 */
+void dwt_util_finish(void)
+{
+	dwt_hip_finish();
+}
+
+/* src/libdwt.c:19200 */
+void dwt_util_abort(void)
+{
+	abort();
+}
+
+/* src/libdwt.c:19946 / libdwt.h:1703-1720 */
+void dwt_util_set_accel(int accel_type)
+{
+	g_accel = accel_type;
+	dwt_hip_set_option("generic", accel_type == 1);
+}
+
+int dwt_util_get_accel(void)
+{
+	return g_accel;
+}
+
+/* src/libdwt.c:19116-19156: OpenMP threads / SIMD-BCE workers of the CPU schedules.
+ * Stored and reported back so that callers' bookkeeping keeps working. */
+void dwt_util_set_num_threads(int num_threads)
+{
+	if (num_threads > 0)
+		g_threads = num_threads;
+}
+
+int dwt_util_get_num_threads(void)
+{
+	return g_threads;
+}
+
+int dwt_util_get_max_threads(void)
+{
+	return 1;
+}
+
+void dwt_util_set_num_workers(int num_workers)
+{
+	if (num_workers > 0)
+		g_workers = num_workers;
+}
+
+int dwt_util_get_num_workers(void)
+{
+	return g_workers;
+}

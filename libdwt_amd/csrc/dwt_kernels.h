@@ -1,0 +1,65 @@
+// dwt_kernels.h -- launch interface between the backend (dwt_backend.hip) and the
+// HIP kernels (dwt_kernels.hip).  Internal to the shared library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace dwt {
+
+enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2 };
+
+// Tuning knobs of the fused sweep kernels (set through dwt_hip_set_option).
+struct SweepTuning {
+	int cpt = 0;        // columns per lane: 4 or 8; 0 = choose from the level width
+	int tile_pairs = 0; // output row pairs per wave tile; 0 = choose from the level height
+	int waves = 4;      // waves per workgroup (each wave owns one tile)
+	int xcd_swizzle = 1; // remap workgroups so neighbouring tiles share an XCD's L2
+};
+
+// One decomposition level, forward, dense frame (size_o == size_i, W,H >= 2).
+// Reads the W x H region at `in`; writes LL (ceil(W/2) x ceil(H/2)) to `out_ll` and
+// the three detail subbands at their Mallat offsets relative to `out_h`:
+// HL at (0, Wd), LH at (Hd, 0), HH at (Hd, Wd), Wd = ceil(W/2), Hd = ceil(H/2).
+// Pitches are in ELEMENTS.  `batch` images lie `*_bstride` elements apart.
+struct FwdLevelArgs {
+	const void *in;
+	long in_pitch, in_bstride;
+	void *out_ll;
+	long ll_pitch, ll_bstride;
+	void *out_h;
+	long h_pitch, h_bstride;
+	int W, H, batch;
+};
+
+// One reconstruction level, inverse, dense frame.  Reads LL from `in_ll` and the
+// detail subbands at their Mallat offsets relative to `in_h`; writes the W x H
+// interleaved result to `out`.
+struct InvLevelArgs {
+	const void *in_ll;
+	long ll_pitch, ll_bstride;
+	const void *in_h;
+	long h_pitch, h_bstride;
+	void *out;
+	long out_pitch, out_bstride;
+	int W, H, batch;
+};
+
+hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
+hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s);
+// true when launch_inv_level has a fused kernel for this wavelet
+bool have_fused_inverse(Wavelet w);
+
+// Generic out-of-place 1-D pass over `n_lines` strided lines of length N (exact
+// reference semantics for any N; used for sparse frames, single-line directions and
+// as the cross-check variant).  Strides in BYTES.  Forward writes L to dst[0..) and
+// H to dst[hoff..); inverse reads L from src[0..), H from src[hoff..).
+// `lanes_along_lines`: adjacent lanes take adjacent lines (column passes).
+hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
+	int n_lines, int N, int hoff, bool lanes_along_lines, hipStream_t s);
+
+// 3-D single level in place over the interleaved layout: one axis at a time.
+// axis 0 = x (elements), 1 = y (rows), 2 = z (slices); strides in ELEMENTS.
+hipError_t launch_vol_axis(bool inverse, int axis, void *vol, long sy, long sz, int nx, int ny, int nz,
+	void *scratch, hipStream_t s);
+
+} // namespace dwt

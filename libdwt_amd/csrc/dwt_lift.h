@@ -1,0 +1,140 @@
+// dwt_lift.h -- lifting arithmetic shared by every HIP kernel of the path.
+//
+// One policy struct per wavelet/type.  A policy states the lifting steps exactly as
+// the reference evaluates them, so that results are bit-identical to libdwt's CPU
+// path (built without FMA: arch.mk:15,38-39 -- this file must be compiled with
+// -ffp-contract=off):
+//
+//   CDF 9/7 float  src/libdwt.c:2264-2355 (accel_lift_op4s_main_s), constants
+//                  src/inline.h:309-315; forward call :10780, inverse call :11561
+//   CDF 5/3 int32  src/libdwt.c:10950-10984 / 11749-11783
+//   CDF 5/3 float  src/libdwt.c:10986-11030 / 11785-11829, constants inline.h:331-335
+//
+// Conventions.  A line is an interleaved signal a[0..N): even samples become L
+// (s), odd samples become H (d).  Ends use whole-sample symmetric reflection, which
+// reproduces the reference's explicit end formulas (`2*c*x` == `c*(x+x)` in fp32;
+// `(2d+2)>>2 == (d+1)>>1` for |d| < 2^30).  A forward transform runs K lifting
+// steps, step s acting on samples of parity (s+1)&1, then scales; an inverse
+// transform descales, then runs K steps, step s acting on parity s&1.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dwt {
+
+struct Cdf97S {
+	using T = float;
+	static constexpr int K = 4;          // lifting steps; also the halo in samples
+	static constexpr bool kScaleSingle = true;   // N==1 lines are scaled (:10757, :11546)
+	static constexpr bool kSkipSingleLine = true; // 2-D drivers skip a direction with one line (:12837)
+	static constexpr bool kInvColsFirst = false;  // inverse: rows then columns (:17098-17154)
+	// -p1, u1, -p2, u2 as the forward call passes them (:10780)
+	static __device__ __forceinline__ T fc(int s)
+	{
+		return s == 0 ? -1.58613434342059f : s == 1 ? -0.0529801185729f : s == 2 ? 0.8829110755309f : 0.4435068520439f;
+	}
+	// -u2, p2, -u1, p1 as the inverse call passes them (:11561)
+	static __device__ __forceinline__ T ic(int s)
+	{
+		return s == 0 ? -0.4435068520439f : s == 1 ? -0.8829110755309f : s == 2 ? 0.0529801185729f : 1.58613434342059f;
+	}
+	static __device__ __forceinline__ T zeta() { return 1.1496043988602f; }
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r) { return c + fc(s) * (l + r); }
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r) { return c + ic(s) * (l + r); }
+	// forward: even *= zeta, odd *= 1/zeta with 1/zeta a float division (:2327, :2344-2353)
+	static __device__ __forceinline__ T fwd_scale(int parity, T v) { return parity ? v * (1.0f / zeta()) : v * zeta(); }
+	// inverse: even *= 1/zeta, odd *= zeta (:2292-2300)
+	static __device__ __forceinline__ T inv_scale(int parity, T v) { return parity ? v * zeta() : v * (1.0f / zeta()); }
+	// N==1: forward *s1 (:10759); inverse *s2 where s2 = (float)(1/1.1496043988602) (inline.h:315)
+	static __device__ __forceinline__ T fwd_single(T v) { return v * zeta(); }
+	static __device__ __forceinline__ T inv_single(T v) { return v * (float)(1 / 1.1496043988602); }
+};
+
+struct Cdf53I {
+	using T = int;
+	static constexpr int K = 2;
+	static constexpr bool kScaleSingle = false;   // N<2 untouched (:10961)
+	static constexpr bool kSkipSingleLine = false;
+	static constexpr bool kInvColsFirst = true;   // inverse: columns then rows (:18178-18195)
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - ((l + r) >> 1) : c + ((l + r + 2) >> 2);
+	}
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - ((l + r + 2) >> 2) : c + ((l + r) >> 1);
+	}
+	static __device__ __forceinline__ T fwd_scale(int, T v) { return v; }
+	static __device__ __forceinline__ T inv_scale(int, T v) { return v; }
+	static __device__ __forceinline__ T fwd_single(T v) { return v; }
+	static __device__ __forceinline__ T inv_single(T v) { return v; }
+};
+
+struct Cdf53S {
+	using T = float;
+	static constexpr int K = 2;
+	static constexpr bool kScaleSingle = true;    // :10998-11003, :11797-11802
+	static constexpr bool kSkipSingleLine = false; // :16507-16523 run unconditionally
+	static constexpr bool kInvColsFirst = false;  // :18333-18349
+	static __device__ __forceinline__ T s1() { return 1.41421356237309504880f; }
+	static __device__ __forceinline__ T s2() { return 0.70710678118654752440f; }
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - 0.5f * (l + r) : c + 0.25f * (l + r);
+	}
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - 0.25f * (l + r) : c + 0.5f * (l + r);
+	}
+	static __device__ __forceinline__ T fwd_scale(int parity, T v) { return parity ? v * s2() : v * s1(); }
+	static __device__ __forceinline__ T inv_scale(int parity, T v) { return parity ? v * s1() : v * s2(); }
+	static __device__ __forceinline__ T fwd_single(T v) { return v * s1(); }
+	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
+};
+
+// Whole-sample symmetric reflection of i into [0, N), N >= 2, any i.
+static __device__ __forceinline__ int reflect(int i, int N)
+{
+	const int period = 2 * (N - 1);
+	i %= period;
+	if (i < 0)
+		i += period;
+	return i < N ? i : period - i;
+}
+
+// Single-bounce reflection, valid for -N < i < 2N-1 (the only range a halo of K
+// samples needs when N > K).
+static __device__ __forceinline__ int reflect1(int i, int N)
+{
+	i = i < 0 ? -i : i;
+	return i >= N ? 2 * (N - 1) - i : i;
+}
+
+// Run the K lifting steps of a forward transform over a register array a[0..n)
+// whose element 0 is an EVEN sample.  After step s, entries j in [s+1, n-2-s] of
+// parity (s+1)&1 are valid; the caller takes the centre it needs.  Fully unrolled:
+// all indices are compile-time constants.
+template <class W, int n>
+static __device__ __forceinline__ void lift_fwd_regs(typename W::T (&a)[n])
+{
+#pragma unroll
+	for (int s = 0; s < W::K; s++) {
+#pragma unroll
+		for (int j = s + 1; j <= n - 2 - s; j += 2)
+			a[j] = W::fwd_step(s, a[j], a[j - 1], a[j + 1]);
+	}
+}
+
+// Inverse steps over a[0..n) whose element 0 is an ODD sample (so step 0, which
+// acts on even samples, again starts at j = 1).  Entries must be descaled first.
+template <class W, int n>
+static __device__ __forceinline__ void lift_inv_regs(typename W::T (&a)[n])
+{
+#pragma unroll
+	for (int s = 0; s < W::K; s++) {
+#pragma unroll
+		for (int j = s + 1; j <= n - 2 - s; j += 2)
+			a[j] = W::inv_step(s, a[j], a[j - 1], a[j + 1]);
+	}
+}
+
+} // namespace dwt

@@ -1,0 +1,298 @@
+"""GPU parity tests: every call goes through the C-ABI of libdwt_hip.so and is compared
+with the committed golden vectors and with the oracle on the same seeded inputs.
+Bar: bit-exact (int 5/3 exact; float kernels keep the reference's unfused mul/add
+order, so float coefficients are bit-identical too -- far inside the 1e-5 relative
+tolerance the north star allows, which is also asserted explicitly)."""
+import numpy as np
+import pytest
+
+from conftest import bits, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+NAMES = {"cdf97_s": ("cdf97_2f_s", "cdf97_2i_s", np.float32),
+         "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i", np.int32),
+         "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32)}
+
+
+@pytest.fixture(scope="module")
+def dwt():
+    import libdwt_amd as d
+
+    d.dwt_util_init()
+    yield d
+    for k, v in (("generic", 0), ("cpt", 0), ("tile_pairs", 0), ("waves", 4), ("xcd_swizzle", 1)):
+        d.set_option(k, v)
+    d.dwt_util_finish()
+
+
+def rand_img(rng, h, w, dt):
+    if dt == np.float32:
+        return rng.random((h, w), dtype=np.float32) * 2 - 1
+    return rng.integers(-32768, 32768, size=(h, w), dtype=np.int32)
+
+
+def rel_err(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(1e-30, np.abs(b).max()))
+
+
+# ---- golden vectors through the host-pointer (drop-in) entry -------------------------
+def _golden_params():
+    for w in NAMES:
+        for case in golden_cases(w):
+            yield pytest.param(w, case, id=f"{w}-{case[0]['name']}")
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+@pytest.mark.parametrize("wname,case", list(_golden_params()))
+def test_golden_host_entry(dwt, wname, case, accel):
+    meta, src, fwd, inv = case
+    dwt.dwt_util_set_accel(accel)
+    try:
+        if meta.get("s2"):
+            h, w = src.shape
+            dst = np.full_like(src, meta["dst_fill"])
+            j = dwt.dwt_cdf97_2f_s2(src.copy(), dst, dst.strides[0], 4, w, h, w, h, meta["j_in"])
+            assert j == meta["j_out"]
+            assert np.array_equal(bits(dst), bits(fwd))
+            rec = np.full_like(src, meta["rec_fill"])
+            dwt.dwt_cdf97_2i_s2(dst, rec, rec.strides[0], 4, w, h, w, h, j)
+            assert np.array_equal(bits(rec), bits(inv))
+            return
+        buf = src.copy()
+        (sox, soy), (six, siy) = meta["size_o"], meta["size_i"]
+        j = dwt.FORWARD[wname](buf, buf.strides[0], 4, sox, soy, six, siy, meta["j_in"],
+                               meta["decompose_one"], meta["zero_padding"])
+        assert j == meta["j_out"]
+        assert np.array_equal(bits(buf), bits(fwd)), "forward differs from the reference's coefficients"
+        dwt.INVERSE[wname](buf, buf.strides[0], 4, sox, soy, six, siy, j, meta["decompose_one"], meta["zero_padding"])
+        assert np.array_equal(bits(buf), bits(inv)), "inverse differs from the reference's output"
+    finally:
+        dwt.dwt_util_set_accel(0)
+
+
+# ---- device-resident images vs the oracle ---------------------------------------------
+SHAPES = [(512, 512), (1000, 1000), (300, 513), (64, 2048), (2050, 130), (768, 1024), (5, 7), (2, 2), (1536, 2048)]
+
+
+@pytest.mark.parametrize("wname", list(NAMES))
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("inplace", [True, False], ids=["inplace", "s2"])
+def test_device_resident_vs_oracle(dwt, oracle, wname, shape, inplace):
+    ff, fi, dt = NAMES[wname]
+    h, w = shape
+    rng = np.random.default_rng(h * 7919 + w)
+    img = rand_img(rng, h, w, dt)
+    want = img.copy()
+    jw = oracle.fwd(ff, want, -1)
+    wid = dwt.WAVELET_ID[wname]
+    a = dwt.DeviceImage(h, w).upload(img)
+    b = a if inplace else dwt.DeviceImage(h, w).upload(np.zeros_like(img))
+    j = dwt._fwd(wid, a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, -1, 0, 0, "fwd")
+    got = b.download(dt)
+    assert j == jw
+    assert np.array_equal(bits(got), bits(want))
+    if dt == np.float32:
+        assert rel_err(got, want) <= 1e-5  # the north star's stated tolerance
+    if not inplace:
+        assert np.array_equal(a.download(dt), img), "_s2 must leave the source untouched"
+    # inverse (b -> a for s2, in place otherwise)
+    dwt._inv(wid, b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, j, 0, 0, "inv")
+    rec = a.download(dt)
+    oracle.inv(fi, want, jw)
+    assert np.array_equal(bits(rec), bits(want))
+    if dt == np.int32:
+        assert np.array_equal(rec, img), "int 5/3 must reconstruct exactly"
+    else:
+        assert np.abs(rec - img).max() < 1e-4
+    a.free()
+    if b is not a:
+        b.free()
+
+
+def test_padded_device_pitch(dwt, oracle):
+    """Device image whose row pitch is wider than the image (and not 16-byte aligned)."""
+    h, w, pe = 200, 333, 341
+    rng = np.random.default_rng(3)
+    buf = rng.random((h, pe), dtype=np.float32)
+    want = buf.copy()
+    jw = oracle.fwd("cdf97_2f_s", want[:, :w], 4)
+    d = dwt.DeviceImage(h, w, pitch_bytes=pe * 4).upload(buf)
+    j = dwt.dwt_cdf97_2f_s(d.ptr, pe * 4, 4, w, h, w, h, 4)
+    got = d.download(np.float32)
+    assert j == jw and np.array_equal(bits(got), bits(want))
+    d.free()
+
+
+# ---- every tile geometry gives the same bits --------------------------------------------
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
+def test_tile_variants_agree(dwt, oracle, wname):
+    ff, fi, dt = NAMES[wname]
+    h, w = 1100, 1300
+    rng = np.random.default_rng(17)
+    img = rand_img(rng, h, w, dt)
+    want = img.copy()
+    jw = oracle.fwd(ff, want, 4)
+    rec_want = want.copy()
+    oracle.inv(fi, rec_want, jw)
+    wid = dwt.WAVELET_ID[wname]
+    try:
+        for cpt in (4, 8):
+            for tp in (8, 24, 128):
+                for waves in (1, 4):
+                    for swz in (0, 1):
+                        dwt.set_option("cpt", cpt)
+                        dwt.set_option("tile_pairs", tp)
+                        dwt.set_option("waves", waves)
+                        dwt.set_option("xcd_swizzle", swz)
+                        a = dwt.DeviceImage(h, w).upload(img)
+                        b = dwt.DeviceImage(h, w).upload(np.zeros_like(img))
+                        j = dwt._fwd(wid, a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, 4, 0, 0, "fwd")
+                        got = b.download(dt)
+                        assert j == jw and np.array_equal(bits(got), bits(want)), (cpt, tp, waves, swz)
+                        dwt._inv(wid, b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, j, 0, 0, "inv")
+                        assert np.array_equal(bits(a.download(dt)), bits(rec_want)), (cpt, tp, waves, swz)
+                        a.free()
+                        b.free()
+    finally:
+        for k, v in (("cpt", 0), ("tile_pairs", 0), ("waves", 4), ("xcd_swizzle", 1)):
+            dwt.set_option(k, v)
+
+
+# ---- BASELINE.json configs ------------------------------------------------------------
+def test_config1_simple_example_flow(dwt, oracle):
+    """configs[0]: 512x512 float, libdwt pattern, prime pitch 2053 B, as examples/simple."""
+    x = y = 512
+    stride_y = 4
+    stride_x = dwt.lib.dwt_util_get_opt_stride(stride_y * x)
+    assert stride_x == 2053
+    raw1 = np.zeros(stride_x * y + 16, np.uint8)
+    dwt.lib.dwt_util_test_image_fill_s(raw1.ctypes.data, stride_x, stride_y, x, y, 0)
+    raw2 = raw1.copy()
+    ref = raw1.copy()
+    for jreq in (1, -1):
+        raw1[:] = raw2
+        ref[:] = raw2
+        j = dwt.dwt_cdf97_2f_s(raw1.ctypes.data, stride_x, stride_y, x, y, x, y, jreq)
+        import ctypes as C
+        jr = C.c_int(jreq)
+        oracle.lib.oracle_cdf97_2f_s(ref.ctypes.data, stride_x, stride_y, x, y, x, y, C.byref(jr), 0, 0)
+        assert j == jr.value == (1 if jreq == 1 else 9)
+        assert np.array_equal(raw1, ref)
+        dwt.dwt_cdf97_2i_s(raw1.ctypes.data, stride_x, stride_y, x, y, x, y, j)
+        assert dwt.lib.dwt_util_compare_s(raw1.ctypes.data, raw2.ctypes.data, stride_x, stride_y, x, y) == 0
+        # round-trip PSNR (peak 1.0)
+        a = np.array([np.frombuffer(raw1[r * stride_x:r * stride_x + 4 * x].tobytes(), np.float32) for r in range(y)])
+        b = np.array([np.frombuffer(raw2[r * stride_x:r * stride_x + 4 * x].tobytes(), np.float32) for r in range(y)])
+        mse = float(np.mean((a.astype(np.float64) - b) ** 2))
+        psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+        assert psnr > 100.0, psnr
+
+
+def test_config2_8192_full_size(dwt, oracle):
+    """configs[1]: 8192x8192 float, 5 levels, device resident, full compare with the oracle."""
+    n = 8192
+    rng = np.random.default_rng(1234)
+    img = rng.random((n, n), dtype=np.float32)
+    a = dwt.DeviceImage(n, n).upload(img)
+    b = dwt.DeviceImage(n, n)
+    j = dwt.dwt_cdf97_2f_s2(a.ptr, b.ptr, n * 4, 4, n, n, n, n, 5)
+    got = b.download(np.float32)
+    want = img.copy()
+    assert oracle.fwd("cdf97_2f_s", want, 5) == j == 5
+    assert np.array_equal(bits(got), bits(want))
+    # in-place entry on the same data
+    j = dwt.dwt_cdf97_2f_s(a.ptr, n * 4, 4, n, n, n, n, 5)
+    assert np.array_equal(bits(a.download(np.float32)), bits(want))
+    # size-independent properties: round trip and energy of the LL band (DC gain 2^J)
+    dwt.dwt_cdf97_2i_s(a.ptr, n * 4, 4, n, n, n, n, 5)
+    rec = a.download(np.float32)
+    assert np.abs(rec - img).max() < 1e-4
+    ll = got[: n >> 5, : n >> 5]
+    assert abs(ll.mean() / (img.mean() * 32) - 1) < 1e-3
+    a.free()
+    b.free()
+
+
+def test_config3_int53_4096(dwt, oracle):
+    """configs[2]: 4096x4096 int32, 3 levels: bit-exact forward, exact reconstruction."""
+    n = 4096
+    rng = np.random.default_rng(7)
+    img = rng.integers(-32768, 32768, size=(n, n), dtype=np.int32)
+    a = dwt.DeviceImage(n, n).upload(img)
+    j = dwt.dwt_cdf53_2f_i(a.ptr, n * 4, 4, n, n, n, n, 3)
+    want = img.copy()
+    assert oracle.fwd("cdf53_2f_i", want, 3) == j == 3
+    assert np.array_equal(a.download(np.int32), want)
+    dwt.dwt_cdf53_2i_i(a.ptr, n * 4, 4, n, n, n, n, 3)
+    assert np.array_equal(a.download(np.int32), img)
+    # libdwt's own int pattern through the host entry (examples/simple-int)
+    pat = np.zeros((512, 512), np.int32)
+    dwt.lib.dwt_util_test_image_fill_i(pat.ctypes.data, 2048, 4, 512, 512, 0)
+    keep = pat.copy()
+    want = pat.copy()
+    j = dwt.dwt_cdf53_2f_i(pat, 2048, 4, 512, 512, 512, 512, -1)
+    assert oracle.fwd("cdf53_2f_i", want, -1) == j
+    assert np.array_equal(pat, want)
+    dwt.dwt_cdf53_2i_i(pat, 2048, 4, 512, 512, 512, 512, j)
+    assert dwt.lib.dwt_util_compare_i(pat.ctypes.data, keep.ctypes.data, 2048, 4, 512, 512) == 0
+    a.free()
+
+
+def test_config4_batch(dwt, oracle):
+    """configs[3] at reduced count: a batch of independent images in one launch per level."""
+    n, nb = 1024, 6
+    rng = np.random.default_rng(99)
+    imgs = rng.random((nb, n, n), dtype=np.float32)
+    src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    assert src and dst
+    assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+    j = dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, 5)
+    out = np.empty_like(imgs)
+    assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
+    assert j == 5
+    for k in range(nb):
+        want = imgs[k].copy()
+        oracle.fwd("cdf97_2f_s", want, 5)
+        assert np.array_equal(bits(out[k]), bits(want)), k
+    # inverse of the batch back into src
+    dwt.transform2d_batch("cdf97_s", 1, dst, src, n * n * 4, nb, n * 4, n, n, 5)
+    assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, src, imgs.nbytes) == 0
+    assert np.abs(out - imgs).max() < 1e-4
+    dwt.lib.dwt_hip_free(src)
+    dwt.lib.dwt_hip_free(dst)
+
+
+def test_linearity_and_constant(dwt):
+    n = 2048
+    rng = np.random.default_rng(5)
+    x = rng.random((n, n), dtype=np.float32)
+    y = rng.random((n, n), dtype=np.float32)
+    outs = []
+    for img in (x, y, (x + y).astype(np.float32)):
+        d = dwt.DeviceImage(n, n).upload(img)
+        dwt.dwt_cdf97_2f_s(d.ptr, n * 4, 4, n, n, n, n, 5)
+        outs.append(d.download(np.float32))
+        d.free()
+    assert np.abs(outs[0] + outs[1] - outs[2]).max() < 2e-3
+    c = np.full((n, n), 3.0, np.float32)
+    d = dwt.DeviceImage(n, n).upload(c)
+    dwt.dwt_cdf97_2f_s(d.ptr, n * 4, 4, n, n, n, n, 5)
+    t = d.download(np.float32)
+    d.free()
+    ll = n >> 5
+    assert np.allclose(t[:ll, :ll], 3.0 * 32, rtol=1e-5)
+    mask = np.ones_like(t, bool)
+    mask[:ll, :ll] = False
+    assert np.abs(t[mask]).max() < 1e-4
+
+
+def test_errors_are_reported(dwt):
+    img = np.zeros((8, 8), np.float32)
+    with pytest.raises(dwt.DwtError):
+        dwt._fwd(7, img, img, 32, 4, 8, 8, 8, 8, -1, 0, 0, "bad wavelet")
+    d = dwt.DeviceImage(8, 8)
+    with pytest.raises(dwt.DwtError):  # mixing host and device pointers
+        dwt._fwd(0, img, d.ptr, 32, 4, 8, 8, 8, 8, -1, 0, 0, "mixed")
+    d.free()

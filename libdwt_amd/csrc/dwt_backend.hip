@@ -427,6 +427,13 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 		}
 		cur = dst;
 		cur_bstride = dst_bstride;
+		if (ll_in >= 0) {
+			// a deeper fused level left its result in scratch: bring it back into the image
+			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Ws) * 4};
+			if (copy_rect(dst, 0, 0, s, 0, 0, Ws, Hs))
+				return 1;
+			ll_in = -1;
+		}
 		for (int pass = 0; pass < 2; pass++) {
 			const bool rows = cols_first ? (pass == 1) : (pass == 0);
 			if (rows) {

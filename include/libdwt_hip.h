@@ -48,6 +48,7 @@ void dwt_hip_sync(void);
 
 /* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).
  * Names: "generic" (1 = force the exact line-pass kernels), "cpt" (0/4/8),
+ * "wave_horiz" (0/1), "ring" (8/16), "nt" and "nt_inv" (bit 0 nt stores, bit 1 nt loads),
  * "tile_pairs" (0 = auto), "waves" (1..4), "xcd_swizzle" (0/1). */
 int dwt_hip_set_option(const char *name, int value);
 int dwt_hip_get_option(const char *name);

@@ -551,6 +551,14 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.waves = value;
 	else if (!strcmp(name, "xcd_swizzle"))
 		g.tune.xcd_swizzle = value;
+	else if (!strcmp(name, "wave_horiz"))
+		g.tune.wave_horiz = value;
+	else if (!strcmp(name, "ring"))
+		g.tune.ring = value;
+	else if (!strcmp(name, "nt"))
+		g.tune.nt = value;
+	else if (!strcmp(name, "nt_inv"))
+		g.tune.nt_inv = value;
 	else
 		return fail("unknown option '%s'", name);
 	return 0;
@@ -568,6 +576,14 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.waves;
 	if (!strcmp(name, "xcd_swizzle"))
 		return g.tune.xcd_swizzle;
+	if (!strcmp(name, "wave_horiz"))
+		return g.tune.wave_horiz;
+	if (!strcmp(name, "ring"))
+		return g.tune.ring;
+	if (!strcmp(name, "nt"))
+		return g.tune.nt;
+	if (!strcmp(name, "nt_inv"))
+		return g.tune.nt_inv;
 	return -1;
 }
 

@@ -127,16 +127,29 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 // ---------------------------------------------------------------------------------
 #define DWT_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// AUX selects the cache policy of the LDS-DMA: 0 = default, 2 = non-temporal (the
+// image is read once per level; nt keeps it from displacing reusable lines).
+template <int AUX = 0>
 static __device__ __forceinline__ void dma16(const void *g, void *l)
 {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-		(__attribute__((address_space(3))) void *)l, 16, 0, 0);
+		(__attribute__((address_space(3))) void *)l, 16, 0, AUX);
 }
 
+template <int AUX = 0>
 static __device__ __forceinline__ void dma4(const void *g, void *l)
 {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-		(__attribute__((address_space(3))) void *)l, 4, 0, 0);
+		(__attribute__((address_space(3))) void *)l, 4, 0, AUX);
+}
+
+template <bool NT, class V>
+static __device__ __forceinline__ void store_vec(V *p, V v)
+{
+	if constexpr (NT)
+		__builtin_nontemporal_store(v, p);
+	else
+		*p = v;
 }
 
 // LDS reads go through inline asm: hipcc (ROCm 7.2) otherwise drains every
@@ -172,7 +185,7 @@ static __device__ __forceinline__ unsigned lds_offset(const void *p)
 	return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const void *)p);
 }
 
-constexpr int kRing = 8;            // ring rows per wave (power of two)
+constexpr int kRing = 8;            // inverse sweep: ring rows per wave (power of two)
 constexpr int kAhead = kRing / 2 - 1; // sweep iterations of DMA lookahead (2 rows each)
 
 // Workgroup -> tile mapping shared by both sweeps.  Each XCD has its own L2 and
@@ -189,14 +202,19 @@ static __device__ __forceinline__ int tile_block_id(int swz)
 
 struct SweepGeom {
 	int tile_pairs, ntx, swz, in_vec_ok, out_vec_ok;
+	int wave_horiz; // 1: the waves of a workgroup take horizontally adjacent tiles
 };
 
 // ---- forward -------------------------------------------------------------------
-template <class W, int CPT>
+template <class W, int CPT, int RING, int NT>
 __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 {
 	using T = typename W::T;
 	constexpr int K = W::K;
+	constexpr int kRing = RING;           // ring rows per wave (power of two)
+	constexpr int kAhead = kRing / 2 - 1; // sweep iterations of DMA lookahead (2 rows each)
+	constexpr int kLdAux = (NT & 2) ? 2 : 0;
+	constexpr bool kNtStore = (NT & 1) != 0;
 	constexpr int TW = 64 * CPT;
 	constexpr int RS = TW + 8; // LDS row slot: [main TW | left halo 4 | right halo 4]
 	constexpr int NARR = CPT + 2 * K;
@@ -205,12 +223,19 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
 	const int bid = tile_block_id(g.swz);
-	const int tx = bid % g.ntx;
-	const int ty = (bid / g.ntx) * nwv + wv;
+	int tx, ty;
+	if (g.wave_horiz) {
+		const int ntxb = (g.ntx + nwv - 1) / nwv;
+		tx = (bid % ntxb) * nwv + wv;
+		ty = bid / ntxb;
+	} else {
+		tx = bid % g.ntx;
+		ty = (bid / g.ntx) * nwv + wv;
+	}
 	const int img = blockIdx.y;
 	const int Wd = (a.W + 1) >> 1, Hd = (a.H + 1) >> 1;
 	const int A = ty * g.tile_pairs;
-	if (A >= Hd)
+	if (A >= Hd || tx >= g.ntx)
 		return; // whole wave leaves; no barriers are used anywhere
 	const int B = min(A + g.tile_pairs, Hd);
 	const int c0 = tx * TW;
@@ -242,14 +267,14 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			if (main16) {
 #pragma unroll
 				for (int i = 0; i < CPT / 4; i++)
-					dma16(grow + c0 + i * 256 + lane * 4, lrow + i * 1024);
+					dma16<kLdAux>(grow + c0 + i * 256 + lane * 4, lrow + i * 1024);
 			} else {
 #pragma unroll
 				for (int i = 0; i < CPT; i++)
-					dma4(grow + colmap[i], lrow + i * 256);
+					dma4<kLdAux>(grow + colmap[i], lrow + i * 256);
 			}
 			if (lane < 8)
-				dma4(grow + halo_col, lrow + TW * 4);
+				dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
 		}
 	};
 
@@ -340,18 +365,18 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			const bool hrow = k < (a.H >> 1);
 			if (full && g.out_vec_ok) {
 				if constexpr (CPT == 8) {
-					*(u4 *)ll = u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])};
-					*(u4 *)hl = u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])};
+					store_vec<kNtStore>((u4 *)ll, u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
+					store_vec<kNtStore>((u4 *)hl, u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])});
 					if (hrow) {
-						*(u4 *)lh = u4{to_bits(hi[0]), to_bits(hi[2]), to_bits(hi[4]), to_bits(hi[6])};
-						*(u4 *)hh = u4{to_bits(hi[1]), to_bits(hi[3]), to_bits(hi[5]), to_bits(hi[7])};
+						store_vec<kNtStore>((u4 *)lh, u4{to_bits(hi[0]), to_bits(hi[2]), to_bits(hi[4]), to_bits(hi[6])});
+						store_vec<kNtStore>((u4 *)hh, u4{to_bits(hi[1]), to_bits(hi[3]), to_bits(hi[5]), to_bits(hi[7])});
 					}
 				} else {
-					*(u2 *)ll = u2{to_bits(lo[0]), to_bits(lo[2])};
-					*(u2 *)hl = u2{to_bits(lo[1]), to_bits(lo[3])};
+					store_vec<kNtStore>((u2 *)ll, u2{to_bits(lo[0]), to_bits(lo[2])});
+					store_vec<kNtStore>((u2 *)hl, u2{to_bits(lo[1]), to_bits(lo[3])});
 					if (hrow) {
-						*(u2 *)lh = u2{to_bits(hi[0]), to_bits(hi[2])};
-						*(u2 *)hh = u2{to_bits(hi[1]), to_bits(hi[3])};
+						store_vec<kNtStore>((u2 *)lh, u2{to_bits(hi[0]), to_bits(hi[2])});
+						store_vec<kNtStore>((u2 *)hh, u2{to_bits(hi[1]), to_bits(hi[3])});
 					}
 				}
 			} else {
@@ -379,11 +404,13 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 // Source rows are Mallat rows: "L row p" = [LL | HL] and "H row p" = [LH | HH].
 // LDS row slot (floats): [L main M | H main M | L halo 8 | H halo 8], M = TW/2;
 // a halo block is [4 columns left of the tile | 4 columns right of the tile].
-template <class W, int CPT>
+template <class W, int CPT, int NT>
 __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 {
 	using T = typename W::T;
 	constexpr int K = W::K;
+	constexpr int kLdAux = (NT & 2) ? 2 : 0;
+	constexpr bool kNtStore = (NT & 1) != 0;
 	constexpr int TW = 64 * CPT;
 	constexpr int M = TW / 2;
 	constexpr int HC = CPT / 2;          // subband columns per lane
@@ -451,23 +478,23 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 			char *lrow = ring + (size_t)((2 * it + rr) & (kRing - 1)) * RS * 4;
 			if (main16) {
 				if constexpr (CPT == 8) {
-					dma16(gl + cl0 + lane * 4, lrow);
-					dma16(gh + cl0 + lane * 4, lrow + M * 4);
+					dma16<kLdAux>(gl + cl0 + lane * 4, lrow);
+					dma16<kLdAux>(gh + cl0 + lane * 4, lrow + M * 4);
 				} else {
 					// lanes 0..31 fetch the L segment, 32..63 the H segment
 					const T *gsel = lane < 32 ? gl : gh;
-					dma16(gsel + cl0 + (lane & 31) * 4, lrow);
+					dma16<kLdAux>(gsel + cl0 + (lane & 31) * 4, lrow);
 				}
 			} else {
 #pragma unroll
 				for (int i = 0; i < CPT / 2; i++)
-					dma4(gl + colmapL[i], lrow + i * 256);
+					dma4<kLdAux>(gl + colmapL[i], lrow + i * 256);
 #pragma unroll
 				for (int i = 0; i < CPT / 2; i++)
-					dma4(gh + colmapH[i], lrow + M * 4 + i * 256);
+					dma4<kLdAux>(gh + colmapH[i], lrow + M * 4 + i * 256);
 			}
 			if (lane < 16)
-				dma4((halo_is_h ? gh : gl) + halo_col, lrow + 2 * M * 4);
+				dma4<kLdAux>((halo_is_h ? gh : gl) + halo_col, lrow + 2 * M * 4);
 		}
 	};
 
@@ -618,13 +645,13 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 				T *o = out + (long)(2 * po + 1) * a.out_pitch + c;
 #pragma unroll
 				for (int e = 0; e < CPT; e += 4)
-					*(u4 *)(o + e) = u4{to_bits(orow[e]), to_bits(orow[e + 1]), to_bits(orow[e + 2]), to_bits(orow[e + 3])};
+					store_vec<kNtStore>((u4 *)(o + e), u4{to_bits(orow[e]), to_bits(orow[e + 1]), to_bits(orow[e + 2]), to_bits(orow[e + 3])});
 			}
 			if (ve) {
 				T *o = out + (long)(2 * pe) * a.out_pitch + c;
 #pragma unroll
 				for (int e = 0; e < CPT; e += 4)
-					*(u4 *)(o + e) = u4{to_bits(erow[e]), to_bits(erow[e + 1]), to_bits(erow[e + 2]), to_bits(erow[e + 3])};
+					store_vec<kNtStore>((u4 *)(o + e), u4{to_bits(erow[e]), to_bits(erow[e + 1]), to_bits(erow[e + 2]), to_bits(erow[e + 3])});
 			}
 		} else {
 			if (vo) {
@@ -655,19 +682,23 @@ static int pick_cpt(const SweepTuning &t, int W, bool inverse)
 	// take the narrower tile so that more waves share the work.
 	if (inverse)
 		return 4;
-	return W >= 2048 ? 8 : 4;
+	return W >= 1024 ? 8 : 4;
 }
 
 static int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batch)
 {
 	if (t.tile_pairs > 0)
 		return t.tile_pairs;
-	// enough tiles to give every one of the 256 CUs several waves, but tall enough
-	// that the K-row warm-up (re-read of the tile above) stays a few percent
+	// Measured on MI355X (scripts/sweep_levels.sh): big levels are bandwidth bound and
+	// want tall tiles (the K-row warm-up re-reads the tile above: 6 % at 64 pairs);
+	// levels of a few million samples are latency bound -- a wave's sweep is a serial
+	// chain -- and want the shortest tiles so that all CUs work at once.
 	const int Hd = (H + 1) / 2;
+	if ((long)W * H * batch <= (4L << 20))
+		return 4;
 	const long ntx = (W + 64 * cpt - 1) / (64 * cpt);
 	int tp = 64;
-	while (tp > 8 && ntx * ((Hd + tp - 1) / tp) * batch < 2048)
+	while (tp > 8 && ntx * ((Hd + tp - 1) / tp) * batch < 1024)
 		tp >>= 1;
 	return tp;
 }
@@ -683,6 +714,36 @@ static hipError_t allow_lds(const void *kernel, size_t bytes)
 	return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+template <class W, int CPT, int RING, int NT>
+static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, hipStream_t s)
+{
+	const size_t lds = (size_t)waves * RING * (64 * CPT + 8) * 4;
+	if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, CPT, RING, NT>, lds))
+		return e;
+	k_fwd_sweep<W, CPT, RING, NT><<<grid, 64 * waves, lds, s>>>(a, g);
+	return hipGetLastError();
+}
+
+template <class W, int CPT>
+static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, const SweepTuning &t, hipStream_t s)
+{
+	const int nt = t.nt & 3;
+	if (t.ring == 16) {
+		switch (nt) {
+		case 0: return fwd_launch<W, CPT, 16, 0>(a, g, grid, waves, s);
+		case 1: return fwd_launch<W, CPT, 16, 1>(a, g, grid, waves, s);
+		case 2: return fwd_launch<W, CPT, 16, 2>(a, g, grid, waves, s);
+		default: return fwd_launch<W, CPT, 16, 3>(a, g, grid, waves, s);
+		}
+	}
+	switch (nt) {
+	case 0: return fwd_launch<W, CPT, 8, 0>(a, g, grid, waves, s);
+	case 1: return fwd_launch<W, CPT, 8, 1>(a, g, grid, waves, s);
+	case 2: return fwd_launch<W, CPT, 8, 2>(a, g, grid, waves, s);
+	default: return fwd_launch<W, CPT, 8, 3>(a, g, grid, waves, s);
+	}
+}
+
 template <class W>
 static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s)
 {
@@ -694,6 +755,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
+	g.wave_horiz = t.wave_horiz;
 	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
 	g.in_vec_ok = aligned16(a.in) && (a.in_pitch % 4 == 0) && (a.in_bstride % 4 == 0);
 	const int ov = cpt / 2; // elements per vector store
@@ -702,18 +764,12 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 		(Wd % ov == 0);
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
-	dim3 grid(g.ntx * ((nty + waves - 1) / waves), a.batch);
-	const size_t lds = (size_t)waves * kRing * (TW + 8) * 4;
-	if (cpt == 8) {
-		if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, 8>, lds))
-			return e;
-		k_fwd_sweep<W, 8><<<grid, 64 * waves, lds, s>>>(a, g);
-	} else {
-		if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, 4>, lds))
-			return e;
-		k_fwd_sweep<W, 4><<<grid, 64 * waves, lds, s>>>(a, g);
-	}
-	return hipGetLastError();
+	dim3 grid;
+	if (g.wave_horiz)
+		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
+	else
+		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
+	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, t, s) : fwd_pick<W, 4>(a, g, grid, waves, t, s);
 }
 
 template <class W>
@@ -727,6 +783,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
+	g.wave_horiz = 0;
 	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
 	g.in_vec_ok = aligned16(a.in_ll) && aligned16(a.in_h) && (a.ll_pitch % 4 == 0) && (a.h_pitch % 4 == 0) &&
 		(a.ll_bstride % 4 == 0) && (a.h_bstride % 4 == 0) && (Wd % 4 == 0);
@@ -735,15 +792,29 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
 	dim3 grid(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	const size_t lds = (size_t)waves * kRing * (TW + 16) * 4;
+	const int nt = t.nt_inv & 3;
+#define DWT_INV_LAUNCH(C, N)                                                             \
+	do {                                                                                 \
+		if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, C, N>, lds))           \
+			return e;                                                                    \
+		k_inv_sweep<W, C, N><<<grid, 64 * waves, lds, s>>>(a, g);                        \
+	} while (0)
 	if (cpt == 8) {
-		if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, 8>, lds))
-			return e;
-		k_inv_sweep<W, 8><<<grid, 64 * waves, lds, s>>>(a, g);
+		switch (nt) {
+		case 0: DWT_INV_LAUNCH(8, 0); break;
+		case 1: DWT_INV_LAUNCH(8, 1); break;
+		case 2: DWT_INV_LAUNCH(8, 2); break;
+		default: DWT_INV_LAUNCH(8, 3); break;
+		}
 	} else {
-		if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, 4>, lds))
-			return e;
-		k_inv_sweep<W, 4><<<grid, 64 * waves, lds, s>>>(a, g);
+		switch (nt) {
+		case 0: DWT_INV_LAUNCH(4, 0); break;
+		case 1: DWT_INV_LAUNCH(4, 1); break;
+		case 2: DWT_INV_LAUNCH(4, 2); break;
+		default: DWT_INV_LAUNCH(4, 3); break;
+		}
 	}
+#undef DWT_INV_LAUNCH
 	return hipGetLastError();
 }
 

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profile the headline bench on the GPU box.  Run through gpurun:
+#   gpurun --timeout 900 -- 'bash scripts/profile_gpu.sh r01'
+# Writes raw output under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/.
+# Counters are collected in their own passes (never together with trace domains
+# other than --kernel-trace), as MI355X_MICROARCH.md prescribes.
+set -u
+TAG=${1:-run}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu ${BENCH_ARGS:-}"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
+echo "trace rc=$?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
+echo "fetch rc=$?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
+echo "write rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
+echo "sq rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/pmc_sq2.log 2>&1
+echo "sq2 rc=$?"
+rocprofv3 -L > $OUT/counters_list.txt 2>&1
+find $OUT -name "*.csv" | head -40

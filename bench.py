@@ -45,10 +45,12 @@ def cpu_baseline(size, levels):
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        avail = os.cpu_count() or 1
+    # one GPU's share of the host (16 cores on the MI355X boxes); BENCH_CPU_THREADS overrides
+    cores = int(os.environ.get("BENCH_CPU_THREADS", min(avail, 16)))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import oraclelib
@@ -60,9 +62,11 @@ def cpu_baseline(size, levels):
         lib = oraclelib.Reference()
         lib.lib.dwt_util_set_accel(0)
         lib.lib.dwt_util_set_num_workers(1)
+        lib.lib.dwt_util_set_num_threads(cores)
     except Exception:
         kind = "port"
         lib = oraclelib.Oracle()
+        lib.set_threads(cores)
     rng = np.random.default_rng(1234)
     # pitch as dwt_util_get_stride(.,2) would pick it (power-of-two pitches alias in cache)
     pitch_elems = size + 144 if size % 1024 == 0 else size
@@ -151,10 +155,9 @@ def main():
     k_ms, k_launches = dwt.prof_read()
     dwt.prof_enable(False)
 
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from libdwt_amd.batch import max_over_ranks
+
+    elapsed = max_over_ranks(elapsed, device=dev)
 
     samples = world * nb * n * n * args.steps
     value = samples / elapsed / 1e9
@@ -165,6 +168,21 @@ def main():
     l0_bytes = 2 * 4 * n * n * images_per_launch
     l0_ms = k_ms / max(k_launches, 1)
     achieved = l0_bytes / (l0_ms * 1e-3) / 1e9 if k_launches else None
+
+    # HBM traffic of the dominant kernel from the PMC passes of the committed profile
+    # (profiles/<tag>_pmc_level0.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE per
+    # launch of 4 images); scaled to this run's images per launch.  None if absent.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_level0.json")))[-1]
+        pj = json.load(open(prof))
+        if n == 8192 and "hbm_traffic_bytes_per_launch" in pj:
+            traffic = pj["hbm_traffic_bytes_per_launch"] * l0_bytes / pj["algorithmic_bytes_per_launch"]
+            traffic_src = os.path.relpath(prof, ROOT)
+    except Exception:
+        pass
 
     if rank == 0:
         out = {
@@ -188,7 +206,8 @@ def main():
             "hbm_frac_algorithmic": round(value * 1e9 * alg / (n * n) / (HBM_PEAK_GBS * 1e9) / world, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": None, "kernel": "k_fwd_sweep<Cdf97S> level 0",
+                         "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src,
+                         "kernel": "k_fwd_sweep<Cdf97S> level 0",
                          "bytes_per_launch": l0_bytes, "avg_launch_ms": round(l0_ms, 5), "launches": k_launches},
         }
         if world == 1 and not args.no_cpu:

@@ -1,0 +1,108 @@
+"""Batch sharding of independent images across the GPUs of one node.
+
+libdwt has no multi-process anything; images of a batch are independent units, so the
+path shards embarrassingly: image b of B goes to rank b*G//B
+(contiguous blocks), every rank runs the single-GPU multi-level pipeline on its block,
+and there is NO collective inside the transform.  torch.distributed (backend "nccl" =
+RCCL over xGMI on the GPU node, "gloo" in the CPU tests) is used only
+
+  * to split a batch that starts on one rank (scatter) and to collect it (gather), and
+  * for the barrier / max-over-ranks of the benchmark's timing.
+
+One process per GPU; the caller initialises the process group.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """[lo, hi) of the contiguous block of `n_items` owned by `rank` (block sizes differ
+    by at most one; rank r owns items with b*world//n_items == r for even splits)."""
+    lo = (n_items * rank) // world
+    hi = (n_items * (rank + 1)) // world
+    return lo, hi
+
+
+def _world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def scatter_images(batch_on_root, n_items, item_shape, dtype, device, root=0):
+    """Split a (B, H, W) batch held by `root` into per-rank blocks.  Every rank passes
+    the same n_items/item_shape/dtype; only root passes the tensor.  Returns this
+    rank's block (a view of the input on a single rank)."""
+    rank, world = _world()
+    lo, hi = shard_range(n_items, rank, world)
+    if world == 1:
+        return batch_on_root[lo:hi]
+    local = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=device)
+    # point-to-point sends from the root: on xGMI each destination has its own link, so
+    # the root's 7 egress links work in parallel (root-egress bound)
+    if rank == root:
+        reqs = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_items, r, world)
+            if r == root:
+                local.copy_(batch_on_root[rlo:rhi])
+            elif rhi > rlo:
+                reqs.append(dist.isend(batch_on_root[rlo:rhi].contiguous(), dst=r))
+        for q in reqs:
+            q.wait()
+    elif hi > lo:
+        dist.recv(local, src=root)
+    return local
+
+
+def gather_images(local, n_items, root=0):
+    """Inverse of scatter_images: root gets the (B, ...) batch back, others get None."""
+    rank, world = _world()
+    if world == 1:
+        return local
+    if rank == root:
+        out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        for r in range(world):
+            rlo, rhi = shard_range(n_items, r, world)
+            if r == root:
+                out[rlo:rhi].copy_(local)
+            elif rhi > rlo:
+                dist.recv(out[rlo:rhi], src=r)
+        return out
+    if local.shape[0] > 0:
+        dist.send(local.contiguous(), dst=root)
+    return None
+
+
+def max_over_ranks(seconds, device="cpu"):
+    """Slowest rank's time: what a whole-job throughput has to be divided by."""
+    rank, world = _world()
+    if world == 1:
+        return float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def transform_sharded(batch_on_root, n_items, item_shape, wavelet="cdf97_s", levels=-1, inverse=False,
+                      device=None, root=0, transform=None):
+    """scatter -> per-rank multi-level transform of the local block -> gather.
+
+    `transform(block, levels)` defaults to the HIP batch entry (device tensors); the CPU
+    tests inject the oracle here, the product never does."""
+    rank, world = _world()
+    dtype = torch.int32 if wavelet == "cdf53_i" else torch.float32
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    local = scatter_images(batch_on_root, n_items, item_shape, dtype, device, root)
+    if transform is None:
+        import libdwt_amd as dwt
+
+        def transform(block, lv):
+            if block.shape[0] == 0:
+                return block
+            h, w = block.shape[1:]
+            out = torch.empty_like(block)
+            dwt.use_torch_stream()
+            dwt.transform2d_batch(wavelet, int(inverse), block, out, h * w * 4, block.shape[0], w * 4, w, h, lv)
+            return out
+    local_out = transform(local, levels)
+    return gather_images(local_out, n_items, root)

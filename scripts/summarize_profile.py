@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of scripts/profile_gpu.sh into profiles/<tag>_*.
+    python scripts/summarize_profile.py gpurun_out/prof_r01 r01
+Writes profiles/<tag>_kernel_stats.csv (the --stats table, torch's own kernels dropped),
+profiles/<tag>_pmc_level0.json (per-launch counters of the dominant kernel with the
+gfx950 FETCH_SIZE correction applied) and a short profiles/<tag>_summary.md."""
+import csv, glob, json, os, sys, collections
+
+src, tag = sys.argv[1], sys.argv[2]
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(out, exist_ok=True)
+
+stats = list(csv.DictReader(open(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0])))
+keep = [r for r in stats if "dwt::" in r["Name"]]
+with open(f"{out}/{tag}_kernel_stats.csv", "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
+    w.writeheader()
+    w.writerows(keep)
+
+trace = list(csv.DictReader(open(glob.glob(f"{src}/trace/*/*_kernel_trace.csv")[0])))
+sweeps = [r for r in trace if "k_fwd_sweep" in r["Kernel_Name"]]
+gmax = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in sweeps)
+l0 = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sweeps if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == gmax]
+l0 = l0[2:] if len(l0) > 4 else l0  # drop the warm-up launches
+per_level = collections.OrderedDict()
+for r in sweeps:
+    key = (int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]), r["Kernel_Name"].split("(")[0])
+    per_level.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+pmc = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    if not fs:
+        continue
+    rows = [r for r in csv.DictReader(open(fs[0])) if "k_fwd_sweep" in r["Kernel_Name"]]
+    if not rows:
+        continue
+    g = max(int(r["Grid_Size"]) for r in rows)
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if int(r["Grid_Size"]) == g:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        pmc[k] = sum(v) / len(v)
+
+summary = {
+    "tag": tag,
+    "kernel": "dwt::k_fwd_sweep<dwt::Cdf97S, 8, 8, 3> (level 0: 4 images of 8192x8192 float per launch)",
+    "level0_avg_ns": sum(l0) / len(l0), "level0_launches": len(l0),
+    "algorithmic_bytes_per_launch": 2 * 4 * 8192 * 8192 * 4,
+    "pmc_per_launch": pmc,
+}
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE is in KiB and on gfx950 reports exactly half
+    # of a wide (16 B/lane) streaming read -> double it; WRITE_SIZE (KiB) is exact.
+    fetch = pmc["FETCH_SIZE"] * 1024 * 2
+    write = pmc["WRITE_SIZE"] * 1024
+    summary["hbm_traffic_bytes_per_launch"] = fetch + write
+    summary["hbm_fetch_bytes_corrected"] = fetch
+    summary["hbm_write_bytes"] = write
+    summary["traffic_over_algorithmic"] = (fetch + write) / summary["algorithmic_bytes_per_launch"]
+if "TCC_HIT_sum" in pmc:
+    summary["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+json.dump(summary, open(f"{out}/{tag}_pmc_level0.json", "w"), indent=1)
+
+with open(f"{out}/{tag}_summary.md", "w") as f:
+    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu` "
+            f"(+ separate `--pmc` passes), MI355X, see scripts/profile_gpu.sh.\n\n## per-kernel (kernel-trace --stats)\n\n")
+    f.write("| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
+    for r in keep:
+        f.write(f"| `{r['Name'].split('(')[0]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
+    f.write("\n## per level (grid size, kernel) -> avg duration us\n\n")
+    for (g, name), v in per_level.items():
+        f.write(f"- grid {g} `{name}`: {sum(v)/len(v)/1e3:.1f} us over {len(v)} launches\n")
+    f.write(f"\n## dominant kernel (level 0, {summary['level0_launches']} timed launches)\n\n")
+    f.write(f"- average duration {summary['level0_avg_ns']/1e3:.1f} us -> algorithmic {summary['algorithmic_bytes_per_launch']/summary['level0_avg_ns']:.0f} GB/s\n")
+    if "hbm_traffic_bytes_per_launch" in summary:
+        f.write(f"- HBM traffic per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): {summary['hbm_traffic_bytes_per_launch']/1e6:.1f} MB "
+                f"= {summary['traffic_over_algorithmic']:.3f} x algorithmic bytes\n")
+    if "l2_hit_rate" in summary:
+        f.write(f"- L2 hit rate {summary['l2_hit_rate']:.3f}\n")
+    for k in sorted(pmc):
+        f.write(f"- {k}: {pmc[k]:.0f}\n")
+print(json.dumps(summary, indent=1))

@@ -1,0 +1,90 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo process groups exercise the batch
+sharding, the scatter/gather used for the batch split, and the max-over-ranks timing.
+The per-rank transform is injected (the oracle -- allowed in tests only); the product
+path uses the HIP batch entry and no collective inside the transform."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_items, h, w, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oraclelib import Oracle
+
+        from libdwt_amd import batch as B
+
+        orc = Oracle()
+        orc.set_threads(1)
+        rng = np.random.default_rng(2024)
+        full = torch.from_numpy(rng.random((n_items, h, w), dtype=np.float32))  # same on every rank; only root's is used
+
+        def cpu_transform(block, levels):
+            out = block.clone().numpy()
+            for k in range(out.shape[0]):
+                orc.fwd("cdf97_2f_s", out[k], levels)
+            return torch.from_numpy(out)
+
+        lo, hi = B.shard_range(n_items, rank, world)
+        got = B.transform_sharded(full if rank == 0 else None, n_items, (h, w), "cdf97_s", 3,
+                                  device=torch.device("cpu"), transform=cpu_transform)
+        t = B.max_over_ranks(0.5 + rank)
+        assert t == 0.5 + (world - 1), t
+        if rank == 0:
+            want = full.clone().numpy()
+            for k in range(n_items):
+                orc.fwd("cdf97_2f_s", want[k], 3)
+            ok = np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+            with open(out_path, "w") as f:
+                f.write("ok" if ok else "mismatch")
+        else:
+            assert got is None
+        # every rank's block is what the partition says
+        assert 0 <= lo <= hi <= n_items
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 5), (3, 4), (2, 1)])
+def test_sharded_batch_roundtrip_gloo(tmp_path, world, n_items):
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(world, _free_port(), n_items, 48, 64, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
+def test_shard_range_partitions():
+    from libdwt_amd.batch import shard_range
+
+    for n in (0, 1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            for (a, b), (c, d) in zip(blocks, blocks[1:]):
+                assert b == c and a <= b and c <= d
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    # config 4: 256 images over 8 GPUs -> 32 contiguous images each
+    assert shard_range(256, 3, 8) == (96, 128)

@@ -766,10 +766,85 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
 {
-	(void)inverse; (void)vol; (void)stride_y; (void)stride_z; (void)nx; (void)ny; (void)nz; (void)levels;
 	if (check_inited())
 		return 1;
-	return fail("dwt_hip_transform3d: not built yet");
+	if (!vol || !dwt_hip_is_device_pointer(vol))
+		return fail("dwt_hip_transform3d takes a device pointer");
+	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
+		return fail("bad volume strides");
+	if (levels < 1)
+		return 0;
+	// every level needs at least 2 samples per axis (the reference asserts >= 5, dwt-simple.c:2172)
+	if (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2)
+		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
+	float *v = (float *)vol;
+	const long vsy = (long)stride_y / 4, vsz = (long)stride_z / 4;
+
+	// scratch: S (pass-to-pass buffer) and, for levels >= 1, the packed lattice P
+	const long s_sy = align_up(nx, 4), s_sz = s_sy * ny;
+	if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
+		return 1;
+	float *S = (float *)g.stage_img;
+	float *P = nullptr;
+	long p_sy = 0, p_sz = 0;
+	if (levels > 1) {
+		const int px = ceil_div_pow2(nx, 1), py = ceil_div_pow2(ny, 1), pz = ceil_div_pow2(nz, 1);
+		p_sy = align_up(px, 4);
+		p_sz = p_sy * py;
+		if (grow(&g.host_a, &g.host_a_bytes, (size_t)p_sz * pz * 4))
+			return 1;
+		P = (float *)g.host_a;
+	}
+
+	auto one_level = [&](float *buf, long bsy, long bsz, int lx, int ly, int lz) -> int {
+		// x then y fused per slice, then z (src/volume-dwt.c:677-725; inverse :1115-1163)
+		hipError_t e;
+		if (!inverse) {
+			FwdLevelArgs a;
+			a.in = buf; a.in_pitch = bsy; a.in_bstride = bsz;
+			a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
+			a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
+			a.W = lx; a.H = ly; a.batch = lz; a.interleaved = 1;
+			e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
+		} else {
+			InvLevelArgs a;
+			a.in_ll = buf; a.ll_pitch = bsy; a.ll_bstride = bsz;
+			a.in_h = buf; a.h_pitch = bsy; a.h_bstride = bsz;
+			a.out = S; a.out_pitch = s_sy; a.out_bstride = s_sz;
+			a.W = lx; a.H = ly; a.batch = lz; a.interleaved = 1;
+			e = launch_inv_level(kCdf97S, a, g.tune, g.stream);
+		}
+		if (e != hipSuccess)
+			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
+		e = launch_vol_z(inverse != 0, S, s_sy, s_sz, buf, bsy, bsz, lx, ly, lz, g.stream);
+		if (e != hipSuccess)
+			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
+		return 0;
+	};
+
+	for (int step = 0; step < levels; step++) {
+		const int j = inverse ? levels - 1 - step : step;
+		const int lx = ceil_div_pow2(nx, j), ly = ceil_div_pow2(ny, j), lz = ceil_div_pow2(nz, j);
+		if (lz > 65535 || ly > 65535)
+			return fail("volume too large for the launch grid");
+		if (j == 0) {
+			if (one_level(v, vsy, vsz, lx, ly, lz))
+				return 1;
+		} else {
+			// level j lives on the lattice of stride 2^j (even-even-even samples): pack it,
+			// transform the dense copy, put it back
+			const long st = 1L << j;
+			hipError_t e = launch_lattice_copy(v, st, vsy * st, vsz * st, P, 1, p_sy, p_sz, lx, ly, lz, g.stream);
+			if (e != hipSuccess)
+				return fail("lattice pack failed: %s", hipGetErrorString(e));
+			if (one_level(P, p_sy, p_sz, lx, ly, lz))
+				return 1;
+			e = launch_lattice_copy(P, 1, p_sy, p_sz, v, st, vsy * st, vsz * st, lx, ly, lz, g.stream);
+			if (e != hipSuccess)
+				return fail("lattice unpack failed: %s", hipGetErrorString(e));
+		}
+	}
+	return 0;
 }
 
 } // extern "C"

@@ -33,6 +33,7 @@ struct FwdLevelArgs {
 	void *out_h;
 	long h_pitch, h_bstride;
 	int W, H, batch;
+	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path layout)
 };
 
 // One reconstruction level, inverse, dense frame.  Reads LL from `in_ll` and the
@@ -46,6 +47,7 @@ struct InvLevelArgs {
 	void *out;
 	long out_pitch, out_bstride;
 	int W, H, batch;
+	int interleaved = 0; // 1: read an interleaved image from in_h (3-D path layout)
 };
 
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
@@ -61,9 +63,14 @@ bool have_fused_inverse(Wavelet w);
 hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
 	int n_lines, int N, int hoff, bool lanes_along_lines, hipStream_t s);
 
-// 3-D single level in place over the interleaved layout: one axis at a time.
-// axis 0 = x (elements), 1 = y (rows), 2 = z (slices); strides in ELEMENTS.
-hipError_t launch_vol_axis(bool inverse, int axis, void *vol, long sy, long sz, int nx, int ny, int nz,
-	void *scratch, hipStream_t s);
+// z pass of the 3-D path: CDF 9/7 float along the slice axis of an interleaved volume,
+// out of place (in != out), x dense; strides in ELEMENTS.
+hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
+	int nx, int ny, int nz, hipStream_t s);
+
+// Strided 3-D copy (lattice pack/unpack for the levels >= 1 of the 3-D path);
+// strides in ELEMENTS, including the x strides.
+hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
+	int nx, int ny, int nz, hipStream_t s);
 
 } // namespace dwt

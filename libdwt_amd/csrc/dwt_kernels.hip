@@ -32,6 +32,7 @@
 #include "dwt_lift.h"
 
 #include <stdint.h>
+#include <type_traits>
 
 namespace dwt {
 
@@ -206,7 +207,10 @@ struct SweepGeom {
 };
 
 // ---- forward -------------------------------------------------------------------
-template <class W, int CPT, int RING, int NT>
+// IL: write the result INTERLEAVED in place of the Mallat de-interleave (row 2k = L
+// row, row 2k+1 = H row, columns interleaved alike) to `out_h`: the layout of the
+// 3-D path (src/volume-dwt.c:677-725), where a batch is the slices of a volume.
+template <class W, int CPT, int RING, int NT, bool IL = false>
 __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 {
 	using T = typename W::T;
@@ -355,6 +359,31 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			}
 		}
 
+		if constexpr (IL) {
+			if (it >= K) {
+				const int k = A + it - K;
+				const int c = c0 + lane * CPT;
+				T *r0 = out_h + (long)(2 * k) * a.h_pitch + c;
+				T *r1 = r0 + a.h_pitch;
+				const bool hrow = 2 * k + 1 < a.H;
+				if (full && g.out_vec_ok) {
+#pragma unroll
+					for (int e = 0; e < CPT; e += 4) {
+						store_vec<kNtStore>((u4 *)(r0 + e), u4{to_bits(lo[e]), to_bits(lo[e + 1]), to_bits(lo[e + 2]), to_bits(lo[e + 3])});
+						if (hrow)
+							store_vec<kNtStore>((u4 *)(r1 + e), u4{to_bits(hi[e]), to_bits(hi[e + 1]), to_bits(hi[e + 2]), to_bits(hi[e + 3])});
+					}
+				} else {
+#pragma unroll
+					for (int e = 0; e < CPT; e++)
+						if (c + e < a.W) {
+							r0[e] = lo[e];
+							if (hrow)
+								r1[e] = hi[e];
+						}
+				}
+			}
+		} else
 		if (it >= K) {
 			const int k = A + it - K;
 			const int cl = (c0 + lane * CPT) >> 1;
@@ -404,7 +433,8 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 // Source rows are Mallat rows: "L row p" = [LL | HL] and "H row p" = [LH | HH].
 // LDS row slot (floats): [L main M | H main M | L halo 8 | H halo 8], M = TW/2;
 // a halo block is [4 columns left of the tile | 4 columns right of the tile].
-template <class W, int CPT, int NT>
+// IL: the input is INTERLEAVED (3-D path layout) at `in_h` instead of Mallat subbands.
+template <class W, int CPT, int NT, bool IL = false>
 __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 {
 	using T = typename W::T;
@@ -416,7 +446,7 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	constexpr int HC = CPT / 2;          // subband columns per lane
 	constexpr int RS = 2 * M + 16;
 	constexpr int NARR = CPT + 2 * K - 1; // interleaved samples c-K+1 .. c+CPT+K-1
-	constexpr int kDmaMain = CPT == 8 ? 2 : 1;
+	constexpr int kDmaMain = IL ? CPT / 4 : (CPT == 8 ? 2 : 1);
 	constexpr int kDmaPerIter = 2 * (kDmaMain + 1);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -459,8 +489,37 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	const bool halo_is_h = (lane >> 3) & 1;
 
 	// pointers to the four subbands' row starts are formed per source row
+	// interleaved input: source columns of the element-wise loader and of the halo
+	int colmapI[IL ? CPT : 1];
+	int halo_colI = 0;
+	if constexpr (IL) {
+#pragma unroll
+		for (int i = 0; i < CPT; i++)
+			colmapI[i] = reflect(c0 + i * 64 + lane, a.W);
+		halo_colI = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
+	}
 	auto issue = [&](int it) {
 		const int p = p0 + it;
+		if constexpr (IL) {
+#pragma unroll
+			for (int rr = 0; rr < 2; rr++) {
+				const int r = reflect(2 * p + rr, a.H);
+				char *lrow = ring + (size_t)((2 * it + rr) & (kRing - 1)) * RS * 4;
+				const T *grow = in_h + (long)r * a.h_pitch;
+				if (main16) {
+#pragma unroll
+					for (int i = 0; i < CPT / 4; i++)
+						dma16<kLdAux>(grow + c0 + i * 256 + lane * 4, lrow + i * 1024);
+				} else {
+#pragma unroll
+					for (int i = 0; i < CPT; i++)
+						dma4<kLdAux>(grow + colmapI[i], lrow + i * 256);
+				}
+				if (lane < 8)
+					dma4<kLdAux>(grow + halo_colI, lrow + TW * 4);
+			}
+			return;
+		}
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
 			// rr = 0: L row p (interleaved row 2p); rr = 1: H row p (row 2p+1)
@@ -525,6 +584,32 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
 			const unsigned base = ring_off + (unsigned)((2 * it + rr) & (kRing - 1)) * RS * 4;
+			if constexpr (IL) {
+				// LDS row: [main TW | left halo 4 | right halo 4] of interleaved samples
+				const unsigned own = base + lane * CPT * 4;
+				const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
+				const unsigned ra = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
+				u4 L4, R4, O0, O1;
+				T ownv[CPT];
+				if constexpr (CPT == 8) {
+					lds_read4(la, own, ra, L4, O0, O1, R4);
+#pragma unroll
+					for (int e = 0; e < 4; e++)
+						ownv[4 + e] = from_bits<T>(O1[e]);
+				} else {
+					lds_read3(la, own, ra, L4, O0, R4);
+				}
+#pragma unroll
+				for (int e = 0; e < 4; e++)
+					ownv[e] = from_bits<T>(O0[e]);
+#pragma unroll
+				for (int j = 0; j < NARR; j++) {
+					const int rel = j - K + 1;
+					const T v = rel < 0 ? from_bits<T>(L4[(4 + rel) & 3]) : rel < CPT ? ownv[rel < CPT ? (rel < 0 ? 0 : rel) : 0] : from_bits<T>(R4[(rel - CPT) & 3]);
+					x[rr][j] = W::inv_scale(rel & 1, v);
+				}
+				continue;
+			}
 			const unsigned hbase = base + 2 * M * 4;
 			// subband values L[cl-2 .. cl+HC+2), H[cl-2 .. cl+HC+2) as l[], h[]
 			T l[HC + 4], h[HC + 4];
@@ -769,6 +854,25 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
+	if (a.interleaved) {
+		// 3-D path: float 9/7 only, the measured-best policy (8-row ring, nt)
+		if constexpr (std::is_same<W, Cdf97S>::value) {
+			g.out_vec_ok = aligned16(a.out_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
+			const size_t lds = (size_t)waves * 8 * (TW + 8) * 4;
+			if (cpt == 8) {
+				if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, 8, 8, 3, true>, lds))
+					return e;
+				k_fwd_sweep<W, 8, 8, 3, true><<<grid, 64 * waves, lds, s>>>(a, g);
+			} else {
+				if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, 4, 8, 3, true>, lds))
+					return e;
+				k_fwd_sweep<W, 4, 8, 3, true><<<grid, 64 * waves, lds, s>>>(a, g);
+			}
+			return hipGetLastError();
+		} else {
+			return hipErrorInvalidValue;
+		}
+	}
 	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, t, s) : fwd_pick<W, 4>(a, g, grid, waves, t, s);
 }
 
@@ -792,6 +896,23 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
 	dim3 grid(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	const size_t lds = (size_t)waves * kRing * (TW + 16) * 4;
+	if (a.interleaved) {
+		if constexpr (std::is_same<W, Cdf97S>::value) {
+			g.in_vec_ok = aligned16(a.in_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
+			if (cpt == 8) {
+				if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, 8, 0, true>, lds))
+					return e;
+				k_inv_sweep<W, 8, 0, true><<<grid, 64 * waves, lds, s>>>(a, g);
+			} else {
+				if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, 4, 0, true>, lds))
+					return e;
+				k_inv_sweep<W, 4, 0, true><<<grid, 64 * waves, lds, s>>>(a, g);
+			}
+			return hipGetLastError();
+		} else {
+			return hipErrorInvalidValue;
+		}
+	}
 	const int nt = t.nt_inv & 3;
 #define DWT_INV_LAUNCH(C, N)                                                             \
 	do {                                                                                 \
@@ -836,6 +957,169 @@ hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning 
 	case kCdf53S: return inv_level_t<Cdf53S>(a, t, s);
 	}
 	return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------
+// 3. z pass of the 3-D path and the lattice copy
+// ---------------------------------------------------------------------------------
+// One wave owns 256 contiguous x columns of one row y and marches along z with the
+// lifting state in registers (the z neighbours of a sample are whole slices apart, but
+// each access is a contiguous 1 KiB row segment).  Same streaming recurrences as the
+// vertical pass of the 2-D sweeps; out of place, because the symmetric extension at
+// the far end re-reads slices the sweep has already produced.
+template <bool INV>
+__global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, long in_sy, long in_sz,
+	float *__restrict__ out, long out_sy, long out_sz, int nx, int ny, int nz, int tile_pairs, int vec_ok)
+{
+	using W = Cdf97S;
+	constexpr int K = 4, CPT = 4;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+	const int c = ((blockIdx.x * nwv + wv) * 64 + lane) * CPT;
+	const int y = blockIdx.y;
+	const int Zd = (nz + 1) >> 1;
+	const int A = blockIdx.z * tile_pairs;
+	if (A >= Zd || (blockIdx.x * nwv + wv) * 64 * CPT >= nx)
+		return;
+	const int B = min(A + tile_pairs, Zd);
+	const int n_iter = (B - A) + K;
+	const int q0 = A - K / 2;
+	const bool vec = vec_ok && (c + CPT <= nx);
+	const float *src = in + (long)y * in_sy + c;
+	float *dst = out + (long)y * out_sy + c;
+
+	auto load = [&](int slice, float (&v)[CPT]) {
+		const float *p = src + (long)reflect(slice, nz) * in_sz;
+		if (vec) {
+			const u4 t = *(const u4 *)p;
+#pragma unroll
+			for (int e = 0; e < CPT; e++)
+				v[e] = from_bits<float>(t[e]);
+		} else {
+#pragma unroll
+			for (int e = 0; e < CPT; e++)
+				v[e] = (c + e < nx) ? p[e] : 0.f;
+		}
+	};
+	auto store = [&](int slice, const float (&v)[CPT]) {
+		float *p = dst + (long)slice * out_sz;
+		if (vec) {
+			*(u4 *)p = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
+		} else {
+#pragma unroll
+			for (int e = 0; e < CPT; e++)
+				if (c + e < nx)
+					p[e] = v[e];
+		}
+	};
+
+	float st[K][CPT];
+#pragma unroll
+	for (int s = 0; s < K; s++)
+#pragma unroll
+		for (int e = 0; e < CPT; e++)
+			st[s][e] = 0.f;
+
+	float na[CPT], nb[CPT];
+	load(2 * q0 - (INV ? 0 : 1), na);
+	load(2 * q0 + (INV ? 1 : 0), nb);
+	for (int it = 0; it < n_iter; it++) {
+		const int q = q0 + it;
+		float ra[CPT], rb[CPT];
+#pragma unroll
+		for (int e = 0; e < CPT; e++) {
+			ra[e] = na[e];
+			rb[e] = nb[e];
+		}
+		if (it + 1 < n_iter) { // software prefetch of the next pair of slices
+			load(2 * (q + 1) - (INV ? 0 : 1), na);
+			load(2 * (q + 1) + (INV ? 1 : 0), nb);
+		}
+		float o0[CPT], o1[CPT];
+#pragma unroll
+		for (int e = 0; e < CPT; e++) {
+			if constexpr (!INV) {
+				// ra = slice 2q-1 (odd), rb = slice 2q (even)
+				const float d1n = W::fwd_step(0, ra[e], st[0][e], rb[e]);
+				const float s1n = W::fwd_step(1, st[0][e], st[1][e], d1n);
+				const float d2n = W::fwd_step(2, st[1][e], st[2][e], s1n);
+				const float s2n = W::fwd_step(3, st[2][e], st[3][e], d2n);
+				o0[e] = W::fwd_scale(0, s2n);
+				o1[e] = W::fwd_scale(1, d2n);
+				st[0][e] = rb[e];
+				st[1][e] = d1n;
+				st[2][e] = s1n;
+				st[3][e] = d2n;
+			} else {
+				// ra = slice 2q (even, s2'), rb = slice 2q+1 (odd, d2')
+				const float s2 = W::inv_scale(0, ra[e]), d2 = W::inv_scale(1, rb[e]);
+				const float s1n = W::inv_step(0, s2, st[0][e], d2);
+				const float d1n = W::inv_step(1, st[0][e], st[1][e], s1n);
+				const float en = W::inv_step(2, st[1][e], st[2][e], d1n);
+				const float on = W::inv_step(3, st[2][e], st[3][e], en);
+				o0[e] = on; // slice 2q-3
+				o1[e] = en; // slice 2q-2
+				st[0][e] = d2;
+				st[1][e] = s1n;
+				st[2][e] = d1n;
+				st[3][e] = en;
+			}
+		}
+		if constexpr (!INV) {
+			if (it >= K) {
+				const int k = A + it - K;
+				store(2 * k, o0);
+				if (2 * k + 1 < nz)
+					store(2 * k + 1, o1);
+			}
+		} else {
+			const int pe = q - 1, po = q - 2;
+			if (po >= A && po < B && 2 * po + 1 < nz)
+				store(2 * po + 1, o0);
+			if (pe >= A && pe < B)
+				store(2 * pe, o1);
+		}
+	}
+}
+
+hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
+	int nx, int ny, int nz, hipStream_t s)
+{
+	if (nx < 1 || ny < 1 || nz < 2 || ny > 65535)
+		return hipErrorInvalidValue;
+	const int Zd = (nz + 1) / 2;
+	const int ntx = (nx + 255) / 256;
+	// long z lines: split them so that at least ~2048 waves exist
+	int tp = 64;
+	while (tp > 8 && (long)ntx * ny * ((Zd + tp - 1) / tp) < 2048)
+		tp >>= 1;
+	const int nzt = (Zd + tp - 1) / tp;
+	const int waves = ntx >= 4 ? 4 : ntx;
+	dim3 grid((ntx + waves - 1) / waves, ny, nzt);
+	const int vec_ok = aligned16(in) && aligned16(out) && in_sy % 4 == 0 && in_sz % 4 == 0 && out_sy % 4 == 0 && out_sz % 4 == 0;
+	if (inverse)
+		k_vol_z<true><<<grid, 64 * waves, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok);
+	else
+		k_vol_z<false><<<grid, 64 * waves, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok);
+	return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ src, long s_sx, long s_sy, long s_sz,
+	float *__restrict__ dst, long d_sx, long d_sy, long d_sz, int nx, int ny)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y, z = blockIdx.z;
+	if (x < nx && y < ny)
+		dst[(long)z * d_sz + (long)y * d_sy + (long)x * d_sx] = src[(long)z * s_sz + (long)y * s_sy + (long)x * s_sx];
+}
+
+hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
+	int nx, int ny, int nz, hipStream_t s)
+{
+	if (nx < 1 || ny < 1 || nz < 1 || ny > 65535 || nz > 65535)
+		return hipErrorInvalidValue;
+	dim3 grid((nx + 255) / 256, ny, nz);
+	k_lattice_copy<<<grid, 256, 0, s>>>(src, s_sx, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny);
+	return hipGetLastError();
 }
 
 bool have_fused_inverse(Wavelet) { return true; }

@@ -296,3 +296,19 @@ def test_errors_are_reported(dwt):
     with pytest.raises(dwt.DwtError):  # mixing host and device pointers
         dwt._fwd(0, img, d.ptr, 32, 4, 8, 8, 8, 8, -1, 0, 0, "mixed")
     d.free()
+
+
+def test_c_example_program(dwt, tmp_path):
+    """examples/roundtrip.c: a C program against include/libdwt.h, host and device images."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "roundtrip"
+    libdir = os.path.join(root, "libdwt_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "roundtrip.c"), "-o", str(exe),
+                           "-L", libdir, "-l:libdwt_hip.so", "-Wl,-rpath," + libdir, "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "host round trip: success" in out.stderr and "device round trip: success" in out.stderr

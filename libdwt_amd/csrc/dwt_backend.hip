@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 #include <vector>
 
 using namespace dwt;
@@ -46,6 +47,20 @@ struct Ctx {
 	size_t ll_bytes[2] = {0, 0};
 	void *host_a = nullptr, *host_b = nullptr; // device images for host-pointer calls
 	size_t host_a_bytes = 0, host_b_bytes = 0;
+	// pipeline lanes for batches: image k runs all its levels on lane k % lanes, so the
+	// small tail levels of one image overlap the big levels of the next
+	struct Lane {
+		hipStream_t stream = nullptr;
+		void *ll[2] = {nullptr, nullptr};
+		size_t ll_bytes[2] = {0, 0};
+		void *stage_img = nullptr;
+		size_t stage_bytes = 0;
+		hipEvent_t done = nullptr;
+	};
+	static constexpr int kMaxLanes = 4;
+	Lane lanes[kMaxLanes];
+	hipEvent_t fork = nullptr;
+	int pipeline = 0; // 0: one launch per level for the whole batch; n>=2: n lanes
 	// options
 	SweepTuning tune;
 	int force_generic = 0;
@@ -198,6 +213,18 @@ int prof_drain()
 	}
 	g.prof_used = 0;
 	return 0;
+}
+
+// make a lane's stream and scratch the active ones (and back)
+void swap_lane(Ctx::Lane &l)
+{
+	std::swap(g.stream, l.stream);
+	std::swap(g.ll[0], l.ll[0]);
+	std::swap(g.ll[1], l.ll[1]);
+	std::swap(g.ll_bytes[0], l.ll_bytes[0]);
+	std::swap(g.ll_bytes[1], l.ll_bytes[1]);
+	std::swap(g.stage_img, l.stage_img);
+	std::swap(g.stage_bytes, l.stage_bytes);
 }
 
 long ll_pitch_elems(int w) { return align_up(w, 4); }
@@ -515,6 +542,15 @@ void dwt_hip_finish(void)
 		*b = nullptr;
 	}
 	g.stage_bytes = g.ll_bytes[0] = g.ll_bytes[1] = g.host_a_bytes = g.host_b_bytes = 0;
+	for (auto &l : g.lanes) {
+		void **lb[] = {&l.ll[0], &l.ll[1], &l.stage_img};
+		for (void **p : lb) {
+			if (*p)
+				hipFree(*p);
+			*p = nullptr;
+		}
+		l.ll_bytes[0] = l.ll_bytes[1] = l.stage_bytes = 0;
+	}
 	for (auto &ev : g.prof_events) {
 		hipEventDestroy(ev.first);
 		hipEventDestroy(ev.second);
@@ -559,6 +595,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.nt = value;
 	else if (!strcmp(name, "nt_inv"))
 		g.tune.nt_inv = value;
+	else if (!strcmp(name, "pipeline"))
+		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else
 		return fail("unknown option '%s'", name);
 	return 0;
@@ -584,6 +622,8 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.nt;
 	if (!strcmp(name, "nt_inv"))
 		return g.tune.nt_inv;
+	if (!strcmp(name, "pipeline"))
+		return g.pipeline;
 	return -1;
 }
 
@@ -760,6 +800,39 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 		return fail("in-place batches are not supported; use distinct src and dst");
 	const Geom ge{size_x, size_y, size_x, size_y};
 	Img s{(char *)src, stride_x}, d{(char *)dst, stride_x};
+	if (g.pipeline >= 2 && batch >= 2) {
+		// per-image pipelines on internal streams, forked from and joined to the caller's stream
+		const int nl = g.pipeline < batch ? g.pipeline : batch;
+		if (!g.fork)
+			HIP_TRY(hipEventCreateWithFlags(&g.fork, hipEventDisableTiming));
+		for (int l = 0; l < nl; l++) {
+			if (!g.lanes[l].stream) {
+				HIP_TRY(hipStreamCreateWithFlags(&g.lanes[l].stream, hipStreamNonBlocking));
+				HIP_TRY(hipEventCreateWithFlags(&g.lanes[l].done, hipEventDisableTiming));
+			}
+		}
+		HIP_TRY(hipEventRecord(g.fork, g.stream));
+		for (int l = 0; l < nl; l++)
+			HIP_TRY(hipStreamWaitEvent(g.lanes[l].stream, g.fork, 0));
+		int rc = 0;
+		const int j_in = *j;
+		for (int k = 0; k < batch && !rc; k++) {
+			Ctx::Lane &lane = g.lanes[k % nl];
+			Img sk{s.p + (size_t)k * batch_stride, s.sx}, dk{d.p + (size_t)k * batch_stride, d.sx};
+			int jk = j_in;
+			swap_lane(lane);
+			rc = inverse ? inverse2d((Wavelet)wavelet, sk, dk, ge, jk, 0, 0, 1, 0, 0)
+			             : forward2d((Wavelet)wavelet, sk, dk, ge, &jk, 0, 0, 1, 0, 0);
+			swap_lane(lane);
+			if (!inverse)
+				*j = jk;
+		}
+		for (int l = 0; l < nl; l++) {
+			HIP_TRY(hipEventRecord(g.lanes[l].done, g.lanes[l].stream));
+			HIP_TRY(hipStreamWaitEvent(g.stream, g.lanes[l].done, 0));
+		}
+		return rc;
+	}
 	return inverse ? inverse2d((Wavelet)wavelet, s, d, ge, *j, 0, 0, batch, (long)batch_stride, (long)batch_stride)
 	               : forward2d((Wavelet)wavelet, s, d, ge, j, 0, 0, batch, (long)batch_stride, (long)batch_stride);
 }

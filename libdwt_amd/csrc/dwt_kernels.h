@@ -14,10 +14,11 @@ struct SweepTuning {
 	int tile_pairs = 0; // output row pairs per wave tile; 0 = choose from the level height
 	int waves = 4;      // waves per workgroup (each wave owns one tile)
 	int xcd_swizzle = 1; // remap workgroups so neighbouring tiles share an XCD's L2
-	int wave_horiz = 0;  // waves of a workgroup side by side (1) or stacked (0)
-	int ring = 8;        // LDS ring rows per wave (8 or 16)
-	int nt = 3;          // forward: bit 0 non-temporal stores, bit 1 non-temporal LDS-DMA loads
-	int nt_inv = 0;      // same bits for the inverse sweep (measured: plain policy is faster there)
+	int wave_horiz = -1; // waves of a workgroup side by side (1) or stacked (0); -1 = auto
+	int ring = 0;        // LDS ring rows per wave (8 or 16); 0 = auto
+	int nt = 7;          // forward: bit 0 non-temporal stores, bit 1 non-temporal LDS-DMA loads,
+	                     // bit 2 keep the LL band's stores temporal (the next level reads it)
+	int nt_inv = 1;      // inverse sweep: non-temporal stores only (measured best)
 };
 
 // One decomposition level, forward, dense frame (size_o == size_i, W,H >= 2).

@@ -219,6 +219,9 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	constexpr int kAhead = kRing / 2 - 1; // sweep iterations of DMA lookahead (2 rows each)
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
 	constexpr bool kNtStore = (NT & 1) != 0;
+	// the LL band is read again by the next level: bit 2 keeps its stores temporal so it
+	// can stay in L2 / Infinity Cache
+	[[maybe_unused]] constexpr bool kNtStoreLL = kNtStore && !(NT & 4);
 	constexpr int TW = 64 * CPT;
 	constexpr int RS = TW + 8; // LDS row slot: [main TW | left halo 4 | right halo 4]
 	constexpr int NARR = CPT + 2 * K;
@@ -394,14 +397,14 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			const bool hrow = k < (a.H >> 1);
 			if (full && g.out_vec_ok) {
 				if constexpr (CPT == 8) {
-					store_vec<kNtStore>((u4 *)ll, u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
+					store_vec<kNtStoreLL>((u4 *)ll, u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
 					store_vec<kNtStore>((u4 *)hl, u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])});
 					if (hrow) {
 						store_vec<kNtStore>((u4 *)lh, u4{to_bits(hi[0]), to_bits(hi[2]), to_bits(hi[4]), to_bits(hi[6])});
 						store_vec<kNtStore>((u4 *)hh, u4{to_bits(hi[1]), to_bits(hi[3]), to_bits(hi[5]), to_bits(hi[7])});
 					}
 				} else {
-					store_vec<kNtStore>((u2 *)ll, u2{to_bits(lo[0]), to_bits(lo[2])});
+					store_vec<kNtStoreLL>((u2 *)ll, u2{to_bits(lo[0]), to_bits(lo[2])});
 					store_vec<kNtStore>((u2 *)hl, u2{to_bits(lo[1]), to_bits(lo[3])});
 					if (hrow) {
 						store_vec<kNtStore>((u2 *)lh, u2{to_bits(hi[0]), to_bits(hi[2])});
@@ -441,6 +444,9 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	constexpr int K = W::K;
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
 	constexpr bool kNtStore = (NT & 1) != 0;
+	// the LL band is read again by the next level: bit 2 keeps its stores temporal so it
+	// can stay in L2 / Infinity Cache
+	[[maybe_unused]] constexpr bool kNtStoreLL = kNtStore && !(NT & 4);
 	constexpr int TW = 64 * CPT;
 	constexpr int M = TW / 2;
 	constexpr int HC = CPT / 2;          // subband columns per lane
@@ -812,21 +818,20 @@ static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 gri
 template <class W, int CPT>
 static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, const SweepTuning &t, hipStream_t s)
 {
-	const int nt = t.nt & 3;
+	const int nt = t.nt & 7;
+#define DWT_FWD_CASE(R, N) case N: return fwd_launch<W, CPT, R, N>(a, g, grid, waves, s)
 	if (t.ring == 16) {
 		switch (nt) {
-		case 0: return fwd_launch<W, CPT, 16, 0>(a, g, grid, waves, s);
-		case 1: return fwd_launch<W, CPT, 16, 1>(a, g, grid, waves, s);
-		case 2: return fwd_launch<W, CPT, 16, 2>(a, g, grid, waves, s);
-		default: return fwd_launch<W, CPT, 16, 3>(a, g, grid, waves, s);
+			DWT_FWD_CASE(16, 0); DWT_FWD_CASE(16, 1); DWT_FWD_CASE(16, 2); DWT_FWD_CASE(16, 3);
+			DWT_FWD_CASE(16, 4); DWT_FWD_CASE(16, 5); DWT_FWD_CASE(16, 6); DWT_FWD_CASE(16, 7);
 		}
 	}
 	switch (nt) {
-	case 0: return fwd_launch<W, CPT, 8, 0>(a, g, grid, waves, s);
-	case 1: return fwd_launch<W, CPT, 8, 1>(a, g, grid, waves, s);
-	case 2: return fwd_launch<W, CPT, 8, 2>(a, g, grid, waves, s);
-	default: return fwd_launch<W, CPT, 8, 3>(a, g, grid, waves, s);
+		DWT_FWD_CASE(8, 0); DWT_FWD_CASE(8, 1); DWT_FWD_CASE(8, 2); DWT_FWD_CASE(8, 3);
+		DWT_FWD_CASE(8, 4); DWT_FWD_CASE(8, 5); DWT_FWD_CASE(8, 6); DWT_FWD_CASE(8, 7);
 	}
+#undef DWT_FWD_CASE
+	return hipErrorInvalidValue;
 }
 
 template <class W>
@@ -840,7 +845,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
-	g.wave_horiz = t.wave_horiz;
+	g.wave_horiz = 0;
 	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
 	g.in_vec_ok = aligned16(a.in) && (a.in_pitch % 4 == 0) && (a.in_bstride % 4 == 0);
 	const int ov = cpt / 2; // elements per vector store
@@ -849,6 +854,16 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 		(Wd % ov == 0);
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
+	// Ring depth (measured, scripts/sweep.py): when a launch has several rounds of tiles
+	// per CU, 4 waves/CU with a 16-row ring (7 iterations of DMA in flight per wave) and
+	// side-by-side waves beat 8 waves/CU with an 8-row ring (5.5 -> 6.0 TB/s at level 0);
+	// smaller launches prefer more resident waves.
+	SweepTuning tt = t;
+	if (tt.ring != 8 && tt.ring != 16)
+		tt.ring = (cpt == 8 && !a.interleaved && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
+	if (tt.wave_horiz < 0)
+		tt.wave_horiz = tt.ring == 16;
+	g.wave_horiz = tt.wave_horiz;
 	dim3 grid;
 	if (g.wave_horiz)
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
@@ -873,7 +888,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 			return hipErrorInvalidValue;
 		}
 	}
-	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, t, s) : fwd_pick<W, 4>(a, g, grid, waves, t, s);
+	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, tt, s) : fwd_pick<W, 4>(a, g, grid, waves, tt, s);
 }
 
 template <class W>

@@ -21,7 +21,8 @@ def dwt():
 
     d.dwt_util_init()
     yield d
-    for k, v in (("generic", 0), ("cpt", 0), ("tile_pairs", 0), ("waves", 4), ("xcd_swizzle", 1)):
+    for k, v in (("generic", 0), ("cpt", 0), ("tile_pairs", 0), ("waves", 4), ("xcd_swizzle", 1), ("ring", 0),
+                 ("wave_horiz", -1), ("nt", 7), ("nt_inv", 1), ("pipeline", 0)):
         d.set_option(k, v)
     d.dwt_util_finish()
 
@@ -157,6 +158,61 @@ def test_tile_variants_agree(dwt, oracle, wname):
     finally:
         for k, v in (("cpt", 0), ("tile_pairs", 0), ("waves", 4), ("xcd_swizzle", 1)):
             dwt.set_option(k, v)
+
+
+def test_ring_layout_and_cache_policy_variants_agree(dwt, oracle):
+    """ring depth, wave layout and nt policy change scheduling only, never the bits."""
+    h, w = 700, 2100
+    rng = np.random.default_rng(23)
+    img = rand_img(rng, h, w, np.float32)
+    want = img.copy()
+    jw = oracle.fwd("cdf97_2f_s", want, 3)
+    rec_want = want.copy()
+    oracle.inv("cdf97_2i_s", rec_want, jw)
+    try:
+        for ring in (8, 16):
+            for horiz in (0, 1):
+                for nt in (0, 3, 7):
+                    for cpt in (4, 8):
+                        for k, v in (("ring", ring), ("wave_horiz", horiz), ("nt", nt), ("nt_inv", nt & 3), ("cpt", cpt), ("tile_pairs", 16)):
+                            dwt.set_option(k, v)
+                        a = dwt.DeviceImage(h, w).upload(img)
+                        b = dwt.DeviceImage(h, w).upload(np.zeros_like(img))
+                        j = dwt.dwt_cdf97_2f_s2(a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, 3)
+                        assert j == jw and np.array_equal(bits(b.download(np.float32)), bits(want)), (ring, horiz, nt, cpt)
+                        dwt.dwt_cdf97_2i_s2(b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, j)
+                        assert np.array_equal(bits(a.download(np.float32)), bits(rec_want)), (ring, horiz, nt, cpt)
+                        a.free()
+                        b.free()
+    finally:
+        for k, v in (("ring", 0), ("wave_horiz", -1), ("nt", 7), ("nt_inv", 1), ("cpt", 0), ("tile_pairs", 0)):
+            dwt.set_option(k, v)
+
+
+def test_pipelined_batch_matches_batched_launch(dwt, oracle):
+    n, nb = 512, 5
+    rng = np.random.default_rng(31)
+    imgs = rng.random((nb, n, n), dtype=np.float32)
+    src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+    outs = []
+    try:
+        for lanes in (0, 2, 3):
+            dwt.set_option("pipeline", lanes)
+            dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, 4)
+            dwt.sync()
+            out = np.empty_like(imgs)
+            assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
+            outs.append(out)
+    finally:
+        dwt.set_option("pipeline", 0)
+    want = imgs[2].copy()
+    oracle.fwd("cdf97_2f_s", want, 4)
+    assert np.array_equal(bits(outs[0][2]), bits(want))
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+    dwt.lib.dwt_hip_free(src)
+    dwt.lib.dwt_hip_free(dst)
 
 
 # ---- BASELINE.json configs ------------------------------------------------------------

@@ -23,6 +23,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -113,6 +114,46 @@ int dwt_util_save_to_pgm_s(const char *filename, float max_value, const void *pt
 int dwt_util_save_to_pgm_i(const char *filename, int max_value, const void *ptr, int stride_x, int stride_y,
 	int size_i_big_x, int size_i_big_y);
 
+/* ---- subband addressing (src/libdwt.h:2276-2330, src/libdwt.c:20731-20950) -------- */
+enum dwt_subbands { DWT_LL, DWT_HL, DWT_LH, DWT_HH };
+/* Address and size of a subband after j_max levels.  Pure address arithmetic: valid
+ * for host and for device images. */
+void dwt_util_subband(void *ptr, int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, enum dwt_subbands band,
+	void **dst_ptr, int *dst_size_x, int *dst_size_y);
+void dwt_util_subband_s(void *ptr, int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, enum dwt_subbands band,
+	void **dst_ptr, int *dst_size_x, int *dst_size_y);
+void dwt_util_subband_i(void *ptr, int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, enum dwt_subbands band,
+	void **dst_ptr, int *dst_size_x, int *dst_size_y);
+float *dwt_util_addr_coeff_s(void *ptr, int y, int x, int stride_x, int stride_y); /* src/libdwt.c:1064 */
+int *dwt_util_addr_coeff_i(void *ptr, int y, int x, int stride_x, int stride_y);
+
+/* ---- measurement and self-test helpers (src/libdwt.h:2618-2760; src/libdwt.c:21262,
+ * 21391, 22296, 22559, 23788, 23877, 24163, 24203) ---------------------------------- */
+enum dwt_array { DWT_ARR_SIMPLE, DWT_ARR_SPARSE, DWT_ARR_PACKED };
+int dwt_util_pow2_ceil_log2(int x);
+void dwt_util_get_sizes_s(enum dwt_array array_type, int size_x, int size_y, int opt_stride,
+	int *stride_x, int *stride_y, int *size_o_big_x, int *size_o_big_y, int *size_i_big_x, int *size_i_big_y);
+void dwt_util_get_sizes_i(enum dwt_array array_type, int size_x, int size_y, int opt_stride,
+	int *stride_x, int *stride_y, int *size_o_big_x, int *size_o_big_y, int *size_i_big_x, int *size_i_big_y);
+/* M transforms per loop, minimum over N loops, seconds per transform; host images (the
+ * call is timed as a drop-in user sees it, staging included) */
+void dwt_util_perf_cdf97_2_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding,
+	int M, int N, int clock_type, float *fwd_secs, float *inv_secs);
+void dwt_util_perf_cdf53_2_i(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding,
+	int M, int N, int clock_type, float *fwd_secs, float *inv_secs);
+/* round-trip self-tests: 0 = success */
+int dwt_util_test_cdf97_2_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding);
+int dwt_util_test_cdf97_2_s2(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding);
+int dwt_util_test2_cdf97_2_s(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one);
+int dwt_util_test2_cdf97_2_s2(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one);
+
 /* ---- timers (src/libdwt.h:1589-1658) --------------------------------------------- */
 enum dwt_timer_types {
 	DWT_TIME_CLOCK_GETTIME,
@@ -145,6 +186,11 @@ const char *dwt_util_version(void);
 const char *dwt_util_arch(void);
 const char *dwt_util_node(void);
 const char *dwt_util_appname(void);
+
+/* size sweep writing "pixels<TAB>seconds per pixel" rows (src/libdwt.c:22559) */
+void dwt_util_measure_perf_cdf97_2_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
+	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
+	FILE *fwd_plot_data, FILE *inv_plot_data);
 
 #ifdef __cplusplus
 }

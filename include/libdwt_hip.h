@@ -80,12 +80,20 @@ int dwt_hip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int dwt_hip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
 int dwt_hip_is_device_pointer(const void *p);
 
+/* dwt_util_perf_cdf97_2_s's protocol (src/libdwt.c:21444-21476) with the M images
+ * resident in HBM: seconds per transform, minimum over N loops. */
+void dwt_hip_perf_cdf97_2_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding,
+	int M, int N, int clock_type, float *fwd_secs, float *inv_secs);
+
 /* Kernel timing with HIP events on the stream the kernels run on.  While enabled,
  * every launch of the level-0 sweep kernel (the dominant kernel) is bracketed by
  * an event pair; dwt_hip_prof_read synchronises and returns the summed duration
  * and the number of launches since the last reset. */
-void dwt_hip_prof_enable(int on);
+void dwt_hip_prof_enable(int on); /* 1: level-0 kernel only; 2: every level's kernel */
 int dwt_hip_prof_read(double *level0_ms_sum, int *launches);
+/* mode 2: per-level sums (index = level whose input/output is the larger frame) */
+int dwt_hip_prof_read_levels(double *ms_sum, int *launches, int n);
 
 #ifdef __cplusplus
 }

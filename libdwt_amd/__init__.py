@@ -79,6 +79,8 @@ lib.dwt_hip_is_device_pointer.restype = _I
 lib.dwt_hip_prof_enable.argtypes = [_I]
 lib.dwt_hip_prof_read.argtypes = [C.POINTER(C.c_double), C.POINTER(_I)]
 lib.dwt_hip_prof_read.restype = _I
+lib.dwt_hip_prof_read_levels.argtypes = [C.POINTER(C.c_double), C.POINTER(_I), _I]
+lib.dwt_hip_prof_read_levels.restype = _I
 lib.dwt_util_get_opt_stride.argtypes = [_I]
 lib.dwt_util_get_opt_stride.restype = _I
 lib.dwt_util_get_stride.argtypes = [_I, _I]
@@ -304,7 +306,15 @@ class DeviceImage:
 
 # ---- kernel timing ----------------------------------------------------------------------
 def prof_enable(on=True):
-    lib.dwt_hip_prof_enable(int(bool(on)))
+    """True/1: time the level-0 kernel; 2: time every level's kernel."""
+    lib.dwt_hip_prof_enable(int(on))
+
+
+def prof_read_levels(n=8):
+    ms = (C.c_double * n)()
+    cnt = (_I * n)()
+    _check(lib.dwt_hip_prof_read_levels(ms, cnt, n), "dwt_hip_prof_read_levels")
+    return [(ms[i] / cnt[i] if cnt[i] else 0.0) for i in range(n)], list(cnt)
 
 
 def prof_read():

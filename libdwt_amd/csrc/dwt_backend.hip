@@ -67,9 +67,12 @@ struct Ctx {
 	// profiling
 	int prof_on = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+	std::vector<int> prof_tag; // level index of each recorded pair
 	size_t prof_used = 0;
 	double prof_ms = 0;
 	int prof_launches = 0;
+	double prof_level_ms[16] = {0};
+	int prof_level_n[16] = {0};
 };
 
 Ctx g;
@@ -179,10 +182,13 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 	return 0;
 }
 
-void prof_before()
+void prof_before(int level = 0)
 {
-	if (!g.prof_on)
+	if (!g.prof_on || (g.prof_on == 1 && level != 0))
 		return;
+	if (g.prof_tag.size() <= g.prof_used)
+		g.prof_tag.resize(g.prof_used + 1);
+	g.prof_tag[g.prof_used] = level;
 	if (g.prof_used == g.prof_events.size()) {
 		hipEvent_t a, b;
 		hipEventCreate(&a);
@@ -192,9 +198,9 @@ void prof_before()
 	hipEventRecord(g.prof_events[g.prof_used].first, g.stream);
 }
 
-void prof_after()
+void prof_after(int level = 0)
 {
-	if (!g.prof_on)
+	if (!g.prof_on || (g.prof_on == 1 && level != 0))
 		return;
 	hipEventRecord(g.prof_events[g.prof_used].second, g.stream);
 	g.prof_used++;
@@ -208,8 +214,13 @@ int prof_drain()
 	for (size_t i = 0; i < g.prof_used; i++) {
 		float ms = 0;
 		HIP_TRY(hipEventElapsedTime(&ms, g.prof_events[i].first, g.prof_events[i].second));
-		g.prof_ms += ms;
-		g.prof_launches++;
+		const int lv = g.prof_tag[i] & 15;
+		g.prof_level_ms[lv] += ms;
+		g.prof_level_n[lv]++;
+		if (lv == 0) {
+			g.prof_ms += ms;
+			g.prof_launches++;
+		}
 	}
 	g.prof_used = 0;
 	return 0;
@@ -304,11 +315,9 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				a.ll_pitch = ll_pitch_elems(Wd);
 				a.ll_bstride = a.ll_pitch * Hd;
 			}
-			if (j == 0)
-				prof_before();
+			prof_before(j);
 			hipError_t e = launch_fwd_level(w, a, g.tune, g.stream);
-			if (j == 0)
-				prof_after();
+			prof_after(j);
 			if (e != hipSuccess)
 				return fail("forward level %d launch failed: %s", j, hipGetErrorString(e));
 			if (detour) {
@@ -432,11 +441,9 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				a.out_pitch = ll_pitch_elems(Wo);
 				a.out_bstride = a.out_pitch * Ho;
 			}
-			if (last)
-				prof_before();
+			prof_before(j - 1);
 			hipError_t e = launch_inv_level(w, a, g.tune, g.stream);
-			if (last)
-				prof_after();
+			prof_after(j - 1);
 			if (e != hipSuccess)
 				return fail("inverse level %d launch failed: %s", j, hipGetErrorString(e));
 			ll_in = ll_out;
@@ -595,6 +602,10 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.nt = value;
 	else if (!strcmp(name, "nt_inv"))
 		g.tune.nt_inv = value;
+	else if (!strcmp(name, "ring_inv"))
+		g.tune.ring_inv = value;
+	else if (!strcmp(name, "wave_horiz_inv"))
+		g.tune.wave_horiz_inv = value;
 	else if (!strcmp(name, "pipeline"))
 		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else
@@ -683,6 +694,21 @@ void dwt_hip_prof_enable(int on)
 	g.prof_launches = 0;
 }
 
+int dwt_hip_prof_read_levels(double *ms_sum, int *launches, int n)
+{
+	if (prof_drain())
+		return 1;
+	for (int i = 0; i < n && i < 16; i++) {
+		ms_sum[i] = g.prof_level_ms[i];
+		launches[i] = g.prof_level_n[i];
+		g.prof_level_ms[i] = 0;
+		g.prof_level_n[i] = 0;
+	}
+	g.prof_ms = 0;
+	g.prof_launches = 0;
+	return 0;
+}
+
 int dwt_hip_prof_read(double *ms, int *launches)
 {
 	if (prof_drain())
@@ -693,6 +719,10 @@ int dwt_hip_prof_read(double *ms, int *launches)
 		*launches = g.prof_launches;
 	g.prof_ms = 0;
 	g.prof_launches = 0;
+	for (int i = 0; i < 16; i++) {
+		g.prof_level_ms[i] = 0;
+		g.prof_level_n[i] = 0;
+	}
 	return 0;
 }
 

@@ -19,6 +19,8 @@ struct SweepTuning {
 	int nt = 7;          // forward: bit 0 non-temporal stores, bit 1 non-temporal LDS-DMA loads,
 	                     // bit 2 keep the LL band's stores temporal (the next level reads it)
 	int nt_inv = 1;      // inverse sweep: non-temporal stores only (measured best)
+	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
+	int wave_horiz_inv = 0;
 };
 
 // One decomposition level, forward, dense frame (size_o == size_i, W,H >= 2).

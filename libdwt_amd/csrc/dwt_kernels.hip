@@ -186,8 +186,6 @@ static __device__ __forceinline__ unsigned lds_offset(const void *p)
 	return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const void *)p);
 }
 
-constexpr int kRing = 8;            // inverse sweep: ring rows per wave (power of two)
-constexpr int kAhead = kRing / 2 - 1; // sweep iterations of DMA lookahead (2 rows each)
 
 // Workgroup -> tile mapping shared by both sweeps.  Each XCD has its own L2 and
 // workgroups are dealt round-robin over the 8 XCDs, so with `swz` consecutive
@@ -437,11 +435,13 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 // LDS row slot (floats): [L main M | H main M | L halo 8 | H halo 8], M = TW/2;
 // a halo block is [4 columns left of the tile | 4 columns right of the tile].
 // IL: the input is INTERLEAVED (3-D path layout) at `in_h` instead of Mallat subbands.
-template <class W, int CPT, int NT, bool IL = false>
+template <class W, int CPT, int RING, int NT, bool IL = false>
 __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 {
 	using T = typename W::T;
 	constexpr int K = W::K;
+	constexpr int kRing = RING;
+	constexpr int kAhead = kRing / 2 - 1;
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
 	constexpr bool kNtStore = (NT & 1) != 0;
 	// the LL band is read again by the next level: bit 2 keeps its stores temporal so it
@@ -458,12 +458,19 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
 	const int bid = tile_block_id(g.swz);
-	const int tx = bid % g.ntx;
-	const int ty = (bid / g.ntx) * nwv + wv;
+	int tx, ty;
+	if (g.wave_horiz) {
+		const int ntxb = (g.ntx + nwv - 1) / nwv;
+		tx = (bid % ntxb) * nwv + wv;
+		ty = bid / ntxb;
+	} else {
+		tx = bid % g.ntx;
+		ty = (bid / g.ntx) * nwv + wv;
+	}
 	const int img = blockIdx.y;
 	const int Wd = (a.W + 1) >> 1, Hd = (a.H + 1) >> 1;
 	const int A = ty * g.tile_pairs;
-	if (A >= Hd)
+	if (A >= Hd || tx >= g.ntx)
 		return;
 	const int B = min(A + g.tile_pairs, Hd);
 	const int c0 = tx * TW;
@@ -891,6 +898,28 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, tt, s) : fwd_pick<W, 4>(a, g, grid, waves, tt, s);
 }
 
+template <class W, int CPT, int RING, int NT, bool IL>
+static hipError_t inv_launch(const InvLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, hipStream_t s)
+{
+	const size_t lds = (size_t)waves * RING * (64 * CPT + 16) * 4;
+	if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, CPT, RING, NT, IL>, lds))
+		return e;
+	k_inv_sweep<W, CPT, RING, NT, IL><<<grid, 64 * waves, lds, s>>>(a, g);
+	return hipGetLastError();
+}
+
+template <class W, int CPT>
+static hipError_t inv_pick(const InvLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, int ring, int nt, hipStream_t s)
+{
+#define DWT_INV_CASE(R, N) case N: return inv_launch<W, CPT, R, N, false>(a, g, grid, waves, s)
+	if (ring == 16) {
+		switch (nt & 3) { DWT_INV_CASE(16, 0); DWT_INV_CASE(16, 1); DWT_INV_CASE(16, 2); DWT_INV_CASE(16, 3); }
+	}
+	switch (nt & 3) { DWT_INV_CASE(8, 0); DWT_INV_CASE(8, 1); DWT_INV_CASE(8, 2); DWT_INV_CASE(8, 3); }
+#undef DWT_INV_CASE
+	return hipErrorInvalidValue;
+}
+
 template <class W>
 static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipStream_t s)
 {
@@ -902,56 +931,28 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
-	g.wave_horiz = 0;
 	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
 	g.in_vec_ok = aligned16(a.in_ll) && aligned16(a.in_h) && (a.ll_pitch % 4 == 0) && (a.h_pitch % 4 == 0) &&
 		(a.ll_bstride % 4 == 0) && (a.h_bstride % 4 == 0) && (Wd % 4 == 0);
 	g.out_vec_ok = aligned16(a.out) && (a.out_pitch % 4 == 0) && (a.out_bstride % 4 == 0);
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
-	dim3 grid(g.ntx * ((nty + waves - 1) / waves), a.batch);
-	const size_t lds = (size_t)waves * kRing * (TW + 16) * 4;
+	int ring = t.ring_inv == 16 ? 16 : 8;
+	g.wave_horiz = t.wave_horiz_inv > 0;
+	dim3 grid;
+	if (g.wave_horiz)
+		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
+	else
+		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
 		if constexpr (std::is_same<W, Cdf97S>::value) {
 			g.in_vec_ok = aligned16(a.in_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
-			if (cpt == 8) {
-				if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, 8, 0, true>, lds))
-					return e;
-				k_inv_sweep<W, 8, 0, true><<<grid, 64 * waves, lds, s>>>(a, g);
-			} else {
-				if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, 4, 0, true>, lds))
-					return e;
-				k_inv_sweep<W, 4, 0, true><<<grid, 64 * waves, lds, s>>>(a, g);
-			}
-			return hipGetLastError();
+			return cpt == 8 ? inv_launch<W, 8, 8, 0, true>(a, g, grid, waves, s) : inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
 		} else {
 			return hipErrorInvalidValue;
 		}
 	}
-	const int nt = t.nt_inv & 3;
-#define DWT_INV_LAUNCH(C, N)                                                             \
-	do {                                                                                 \
-		if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, C, N>, lds))           \
-			return e;                                                                    \
-		k_inv_sweep<W, C, N><<<grid, 64 * waves, lds, s>>>(a, g);                        \
-	} while (0)
-	if (cpt == 8) {
-		switch (nt) {
-		case 0: DWT_INV_LAUNCH(8, 0); break;
-		case 1: DWT_INV_LAUNCH(8, 1); break;
-		case 2: DWT_INV_LAUNCH(8, 2); break;
-		default: DWT_INV_LAUNCH(8, 3); break;
-		}
-	} else {
-		switch (nt) {
-		case 0: DWT_INV_LAUNCH(4, 0); break;
-		case 1: DWT_INV_LAUNCH(4, 1); break;
-		case 2: DWT_INV_LAUNCH(4, 2); break;
-		default: DWT_INV_LAUNCH(4, 3); break;
-		}
-	}
-#undef DWT_INV_LAUNCH
-	return hipGetLastError();
+	return cpt == 8 ? inv_pick<W, 8>(a, g, grid, waves, ring, t.nt_inv, s) : inv_pick<W, 4>(a, g, grid, waves, ring, t.nt_inv, s);
 }
 
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s)

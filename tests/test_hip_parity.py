@@ -368,3 +368,37 @@ def test_c_example_program(dwt, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "host round trip: success" in out.stderr and "device round trip: success" in out.stderr
+
+
+def test_harness_helpers(dwt):
+    """libdwt's own self-test and perf helpers (src/libdwt.c:24163, 24203, 21391) over the backend."""
+    import ctypes as C
+
+    L = dwt.lib
+    L.dwt_util_test2_cdf97_2_s.restype = C.c_int
+    L.dwt_util_test2_cdf97_2_s2.restype = C.c_int
+    # the loop of examples/test/test.c: 256x256, DWT_ARR_SIMPLE (0), opt stride 1, full depth, decompose_one
+    for arr in (0, 1, 2):
+        assert L.dwt_util_test2_cdf97_2_s(arr, 256, 256, 1, -1, 1) == 0
+        assert L.dwt_util_test2_cdf97_2_s2(arr, 200, 120, 1, -1, 1) == 0
+    f, i = C.c_float(0), C.c_float(0)
+    L.dwt_util_perf_cdf97_2_s.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_float)] * 2
+    L.dwt_util_perf_cdf97_2_s(2048 * 4, 4, 2048, 2048, 2048, 2048, 3, 0, 0, 2, 3, 0, C.byref(f), C.byref(i))
+    assert 0 < f.value < 1 and 0 < i.value < 1
+    L.dwt_hip_perf_cdf97_2_s.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_float)] * 2
+    L.dwt_hip_perf_cdf97_2_s(2048 * 4, 4, 2048, 2048, 2048, 2048, 3, 0, 0, 2, 3, 0, C.byref(f), C.byref(i))
+    assert 0 < f.value < 0.01 and 0 < i.value < 0.01
+    # subband addressing on a device image: read HH of level 2 back through the address it returns
+    n = 64
+    img = np.random.default_rng(1).random((n, n), dtype=np.float32)
+    d = dwt.DeviceImage(n, n).upload(img)
+    dwt.dwt_cdf97_2f_s(d.ptr, n * 4, 4, n, n, n, n, 2)
+    full = d.download(np.float32)
+    p, sx, sy = C.c_void_p(), C.c_int(), C.c_int()
+    L.dwt_util_subband_s.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dwt_util_subband_s(d.ptr, n * 4, 4, n, n, n, n, 2, 3, C.byref(p), C.byref(sx), C.byref(sy))
+    assert (sx.value, sy.value) == (16, 16) and p.value == d.ptr + 16 * n * 4 + 16 * 4
+    row = np.empty(16, np.float32)
+    assert L.dwt_hip_memcpy_d2h(row.ctypes.data, p.value, 64) == 0
+    assert np.array_equal(row, full[16, 16:32])
+    d.free()

@@ -125,14 +125,18 @@ def test_conv_show_copy_pgm(dwt, tmp_path):
 
 
 def test_reference_examples_link_unchanged(dwt, tmp_path):
-    """examples/simple/simple.c and examples/simple-int/simple.c compile against
-    include/libdwt.h and link against libdwt_hip.so without modification."""
+    """The reference's own programs around the path -- examples/simple, simple-int,
+    simple-perf, subbands, perf-plot -- compile against include/libdwt.h and link against
+    libdwt_hip.so without modification."""
     ref = "/root/reference/examples"
     if not os.path.isdir(ref):
         pytest.skip("reference sources not present on this machine")
     libdir = os.path.join(ROOT, "libdwt_amd")
-    for ex in ("simple", "simple-int"):
+    import glob
+
+    for ex in ("simple", "simple-int", "simple-perf", "subbands", "perf-plot"):
         exe = tmp_path / (ex + ".bin")
-        subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", INCLUDE, os.path.join(ref, ex, "simple.c"),
+        src = sorted(glob.glob(os.path.join(ref, ex, "*.c")))[0]
+        subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", INCLUDE, src,
                                "-o", str(exe), "-L", libdir, "-l:libdwt_hip.so", "-Wl,-rpath," + libdir, "-lm"])
         assert exe.exists()

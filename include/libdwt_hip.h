@@ -11,7 +11,9 @@
  * Pointer rule for every transform entry: `src`/`dst`/`ptr` may be ordinary host
  * memory (any byte strides; staged through HBM, result copied back) or device
  * memory (hipMalloc / dwt_hip_malloc / a torch tensor's data_ptr; requires
- * stride_y == 4 and stride_x % 4 == 0; transformed in HBM, nothing crosses PCIe).
+ * stride_y == element size and stride_x a multiple of it; transformed in HBM, nothing
+ * crosses PCIe).  The double-precision wavelets run on the exact line-pass kernels
+ * (two passes per level); the fused sweeps exist for the 32-bit types.
  *
  * Error rule: every int function returns 0 on success and non-zero on failure with
  * a message retrievable by dwt_hip_last_error().  There is NO CPU fallback: without
@@ -30,7 +32,9 @@ extern "C" {
 enum dwt_hip_wavelet {
 	DWT_HIP_CDF97_S = 0, /* float CDF 9/7: dwt_cdf97_2f_s / dwt_cdf97_2i_s (src/libdwt.c:12776, 17040) */
 	DWT_HIP_CDF53_I = 1, /* int32 CDF 5/3: dwt_cdf53_2f_i / dwt_cdf53_2i_i (src/libdwt.c:16304, 18142) */
-	DWT_HIP_CDF53_S = 2  /* float CDF 5/3: dwt_cdf53_2f_s / dwt_cdf53_2i_s (src/libdwt.c:16470, 18296) */
+	DWT_HIP_CDF53_S = 2, /* float CDF 5/3: dwt_cdf53_2f_s / dwt_cdf53_2i_s (src/libdwt.c:16470, 18296) */
+	DWT_HIP_CDF97_D = 3, /* double CDF 9/7: dwt_cdf97_2f_d / dwt_cdf97_2i_d (src/libdwt.c:12451, 16884) */
+	DWT_HIP_CDF53_D = 4  /* double CDF 5/3: dwt_cdf53_2f_d / dwt_cdf53_2i_d (src/libdwt.c:12535, 16962) */
 };
 
 /* Lifecycle.  dwt_hip_init picks the device from DWT_HIP_DEVICE, else LOCAL_RANK,

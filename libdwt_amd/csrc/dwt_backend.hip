@@ -119,10 +119,11 @@ int grow(void **p, size_t *have, size_t need)
 	return 0;
 }
 
-// A device image: element (y,x) at p + y*sx + x*4 (element stride is always 4 here).
+// A device image: element (y,x) at p + y*sx + x*es (dense elements of es = 4 or 8 bytes).
 struct Img {
 	char *p;
-	long sx; // row pitch in bytes
+	long sx;    // row pitch in bytes
+	int es = 4; // element size in bytes
 };
 
 struct Geom {
@@ -140,7 +141,7 @@ int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, lo
 {
 	if (w <= 0 || h <= 0)
 		return 0;
-	HIP_TRY(hipMemcpy2DAsync(dst.p + dy * dst.sx + dx * 4, dst.sx, src.p + sy_ * src.sx + sx_ * 4, src.sx, w * 4, h,
+	HIP_TRY(hipMemcpy2DAsync(dst.p + dy * dst.sx + dx * dst.es, dst.sx, src.p + sy_ * src.sx + sx_ * src.es, src.sx, w * dst.es, h,
 		hipMemcpyDeviceToDevice, g.stream));
 	return 0;
 }
@@ -149,7 +150,7 @@ int zero_rect(Img img, long x, long y, long w, long h)
 {
 	if (w <= 0 || h <= 0)
 		return 0;
-	HIP_TRY(hipMemset2DAsync(img.p + y * img.sx + x * 4, img.sx, 0, w * 4, h, g.stream));
+	HIP_TRY(hipMemset2DAsync(img.p + y * img.sx + x * img.es, img.sx, 0, w * img.es, h, g.stream));
 	return 0;
 }
 
@@ -168,13 +169,13 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 		// staging image with the SAME pitch as the caller's image
 		if (grow(&g.stage_img, &g.stage_bytes, (size_t)out.sx * frame_h))
 			return 1;
-		dst = Img{(char *)g.stage_img, out.sx};
+		dst = Img{(char *)g.stage_img, out.sx, out.es};
 		if (copy_rect(dst, 0, 0, out, 0, 0, frame_w, frame_h))
 			return 1;
 	} else if (in.sx != out.sx) {
 		return fail("generic pass: source and destination pitches differ (%ld vs %ld)", in.sx, out.sx);
 	}
-	hipError_t e = launch_line_pass(w, inverse, in.p, dst.p, rows ? in.sx : 4, rows ? 4 : in.sx, n_lines, N, hoff, !rows, g.stream);
+	hipError_t e = launch_line_pass(w, inverse, in.p, dst.p, rows ? in.sx : in.es, rows ? in.es : in.sx, n_lines, N, hoff, !rows, g.stream);
 	if (e != hipSuccess)
 		return fail("line pass launch failed: %s", hipGetErrorString(e));
 	if (alias && copy_rect(out, 0, 0, dst, 0, 0, frame_w, frame_h))
@@ -250,9 +251,11 @@ int ensure_ll(const Geom &ge, int batch)
 	return 0;
 }
 
+bool g_elems_are_32bit = true; // set per call: the fused sweeps exist for 4-byte elements only
+
 bool level_fused_ok(const Geom &ge, int j)
 {
-	return !g.force_generic && ge.Wi(j) == ge.Wo(j) && ge.Hi(j) == ge.Ho(j) && ge.Wo(j) >= 2 && ge.Ho(j) >= 2;
+	return !g.force_generic && g_elems_are_32bit && ge.Wi(j) == ge.Wo(j) && ge.Hi(j) == ge.Ho(j) && ge.Wo(j) >= 2 && ge.Ho(j) >= 2;
 }
 
 // ---- forward ---------------------------------------------------------------------
@@ -731,10 +734,12 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 {
 	if (check_inited())
 		return 1;
-	if (wavelet < 0 || wavelet > 2)
+	if (wavelet < 0 || wavelet > 4)
 		return fail("unknown wavelet %d", wavelet);
 	if (!src || !dst || !j)
 		return fail("null pointer argument");
+	const int es = elem_size((Wavelet)wavelet);
+	g_elems_are_32bit = (es == 4);
 	if (sox <= 0 || soy <= 0 || six < 0 || siy < 0 || six > sox || siy > soy)
 		return fail("bad sizes: outer %dx%d inner %dx%d", sox, soy, six, siy);
 	const Wavelet w = (Wavelet)wavelet;
@@ -744,15 +749,15 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 		return fail("src and dst must both be host or both be device pointers");
 
 	if (dev_dst) {
-		if (stride_y != 4 || (stride_x & 3) || stride_x < sox * 4)
-			return fail("device images need stride_y == 4 and stride_x a multiple of 4 >= width*4 (got %d, %d)", stride_x, stride_y);
-		Img s{(char *)src, stride_x}, d{(char *)dst, stride_x};
+		if (stride_y != es || (stride_x % es) || stride_x < sox * es)
+			return fail("device images need stride_y == %d and stride_x a multiple of it >= width*%d (got %d, %d)", es, es, stride_x, stride_y);
+		Img s{(char *)src, stride_x, es}, d{(char *)dst, stride_x, es};
 		return inverse ? inverse2d(w, s, d, ge, *j, decompose_one, zero_padding, 1, 0, 0)
 		               : forward2d(w, s, d, ge, j, decompose_one, zero_padding, 1, 0, 0);
 	}
 
 	// ---- host pointers: stage the whole outer frame through HBM ----
-	const long pitch = align_up((long)sox * 4, 256);
+	const long pitch = align_up((long)sox * es, 256);
 	const size_t bytes = (size_t)pitch * soy;
 	if (grow(&g.host_a, &g.host_a_bytes, bytes) || grow(&g.host_b, &g.host_b_bytes, bytes))
 		return 1;
@@ -760,34 +765,34 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	// dense element stride: one 2-D copy; otherwise gather on the host first
 	std::vector<char> packed;
 	auto upload = [&](const void *hp, void *dp) -> int {
-		if (stride_y == 4) {
-			HIP_TRY(hipMemcpy2DAsync(dp, pitch, hp, stride_x, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
+		if (stride_y == es) {
+			HIP_TRY(hipMemcpy2DAsync(dp, pitch, hp, stride_x, (size_t)sox * es, soy, hipMemcpyHostToDevice, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
 		} else {
-			packed.resize((size_t)sox * soy * 4);
+			packed.resize((size_t)sox * soy * es);
 			for (int y = 0; y < soy; y++)
 				for (int x = 0; x < sox; x++)
-					memcpy(&packed[((size_t)y * sox + x) * 4], (const char *)hp + (long)y * stride_x + (long)x * stride_y, 4);
-			HIP_TRY(hipMemcpy2DAsync(dp, pitch, packed.data(), (size_t)sox * 4, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
+					memcpy(&packed[((size_t)y * sox + x) * es], (const char *)hp + (long)y * stride_x + (long)x * stride_y, es);
+			HIP_TRY(hipMemcpy2DAsync(dp, pitch, packed.data(), (size_t)sox * es, (size_t)sox * es, soy, hipMemcpyHostToDevice, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
 		}
 		return 0;
 	};
 	auto download = [&](void *hp, const void *dp) -> int {
-		if (stride_y == 4) {
-			HIP_TRY(hipMemcpy2DAsync(hp, stride_x, dp, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
+		if (stride_y == es) {
+			HIP_TRY(hipMemcpy2DAsync(hp, stride_x, dp, pitch, (size_t)sox * es, soy, hipMemcpyDeviceToHost, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
 		} else {
-			packed.resize((size_t)sox * soy * 4);
-			HIP_TRY(hipMemcpy2DAsync(packed.data(), (size_t)sox * 4, dp, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
+			packed.resize((size_t)sox * soy * es);
+			HIP_TRY(hipMemcpy2DAsync(packed.data(), (size_t)sox * es, dp, pitch, (size_t)sox * es, soy, hipMemcpyDeviceToHost, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
 			for (int y = 0; y < soy; y++)
 				for (int x = 0; x < sox; x++)
-					memcpy((char *)hp + (long)y * stride_x + (long)x * stride_y, &packed[((size_t)y * sox + x) * 4], 4);
+					memcpy((char *)hp + (long)y * stride_x + (long)x * stride_y, &packed[((size_t)y * sox + x) * es], es);
 		}
 		return 0;
 	};
-	Img A{(char *)g.host_a, pitch}, B{(char *)g.host_b, pitch};
+	Img A{(char *)g.host_a, pitch, es}, B{(char *)g.host_b, pitch, es};
 	if (upload(src, A.p))
 		return 1;
 	// B receives the result.  It starts as a copy of what the destination holds so
@@ -819,7 +824,8 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 	if (check_inited())
 		return 1;
 	if (wavelet < 0 || wavelet > 2)
-		return fail("unknown wavelet %d", wavelet);
+		return fail("unknown wavelet %d (batches take the 32-bit wavelets)", wavelet);
+	g_elems_are_32bit = true;
 	if (!src || !dst || !j || batch < 1)
 		return fail("bad argument");
 	if (!dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))

@@ -119,6 +119,8 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 	case kCdf97S: return line_pass_t<Cdf97S>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf53I: return line_pass_t<Cdf53I>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf53S: return line_pass_t<Cdf53S>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
+	case kCdf97D: return line_pass_t<Cdf97D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
+	case kCdf53D: return line_pass_t<Cdf53D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	}
 	return hipErrorInvalidValue;
 }
@@ -812,13 +814,13 @@ static hipError_t allow_lds(const void *kernel, size_t bytes)
 	return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <class W, int CPT, int RING, int NT>
+template <class W, int CPT, int RING, int NT, bool IL = false>
 static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, hipStream_t s)
 {
 	const size_t lds = (size_t)waves * RING * (64 * CPT + 8) * 4;
-	if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, CPT, RING, NT>, lds))
+	if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, CPT, RING, NT, IL>, lds))
 		return e;
-	k_fwd_sweep<W, CPT, RING, NT><<<grid, 64 * waves, lds, s>>>(a, g);
+	k_fwd_sweep<W, CPT, RING, NT, IL><<<grid, 64 * waves, lds, s>>>(a, g);
 	return hipGetLastError();
 }
 
@@ -846,7 +848,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 {
 	if (a.W < 2 || a.H < 2 || a.batch < 1)
 		return hipErrorInvalidValue;
-	const int cpt = pick_cpt(t, a.W, false);
+	const int cpt = a.interleaved ? 4 : pick_cpt(t, a.W, false);
 	const int TW = 64 * cpt;
 	SweepGeom g;
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
@@ -867,7 +869,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	// smaller launches prefer more resident waves.
 	SweepTuning tt = t;
 	if (tt.ring != 8 && tt.ring != 16)
-		tt.ring = (cpt == 8 && !a.interleaved && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
+		tt.ring = (cpt == 8 && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
 	if (tt.wave_horiz < 0)
 		tt.wave_horiz = tt.ring == 16;
 	g.wave_horiz = tt.wave_horiz;
@@ -877,20 +879,13 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
-		// 3-D path: float 9/7 only, the measured-best policy (8-row ring, nt)
+		// 3-D path: float 9/7 only; always 4 columns per lane so that each row leaves the
+		// wave as ONE contiguous 16 B/lane store (two strided stores per row cost 40 %)
 		if constexpr (std::is_same<W, Cdf97S>::value) {
 			g.out_vec_ok = aligned16(a.out_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
-			const size_t lds = (size_t)waves * 8 * (TW + 8) * 4;
-			if (cpt == 8) {
-				if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, 8, 8, 3, true>, lds))
-					return e;
-				k_fwd_sweep<W, 8, 8, 3, true><<<grid, 64 * waves, lds, s>>>(a, g);
-			} else {
-				if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, 4, 8, 3, true>, lds))
-					return e;
-				k_fwd_sweep<W, 4, 8, 3, true><<<grid, 64 * waves, lds, s>>>(a, g);
-			}
-			return hipGetLastError();
+			if (tt.ring == 16)
+				return fwd_launch<W, 4, 16, 3, true>(a, g, grid, waves, s);
+			return fwd_launch<W, 4, 8, 3, true>(a, g, grid, waves, s);
 		} else {
 			return hipErrorInvalidValue;
 		}
@@ -925,7 +920,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 {
 	if (a.W < 2 || a.H < 2 || a.batch < 1)
 		return hipErrorInvalidValue;
-	const int cpt = pick_cpt(t, a.W, true);
+	const int cpt = a.interleaved ? 4 : pick_cpt(t, a.W, true);
 	const int TW = 64 * cpt;
 	SweepGeom g;
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
@@ -961,6 +956,7 @@ hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning 
 	case kCdf97S: return fwd_level_t<Cdf97S>(a, t, s);
 	case kCdf53I: return fwd_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return fwd_level_t<Cdf53S>(a, t, s);
+	default: break; // the double-precision drivers run on the line-pass kernels
 	}
 	return hipErrorInvalidValue;
 }
@@ -971,6 +967,7 @@ hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning 
 	case kCdf97S: return inv_level_t<Cdf97S>(a, t, s);
 	case kCdf53I: return inv_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return inv_level_t<Cdf53S>(a, t, s);
+	default: break;
 	}
 	return hipErrorInvalidValue;
 }

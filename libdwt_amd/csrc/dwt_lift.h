@@ -91,6 +91,52 @@ struct Cdf53S {
 	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
 };
 
+// Double precision (src/libdwt.c:2024-2083, 11423-11482; constants src/inline.h:317-323).
+// The reference writes the steps as `a -= p*(l+r)` / `a += u*(l+r)` and scales by the
+// two stored constants s1, s2 = 1/1.1496043988602.
+struct Cdf97D {
+	using T = double;
+	static constexpr int K = 4;
+	static constexpr bool kScaleSingle = true;
+	static constexpr bool kSkipSingleLine = false; // :12490-12506 run unconditionally
+	static constexpr bool kInvColsFirst = false;
+	static __device__ __forceinline__ T p1() { return 1.58613434342059; }
+	static __device__ __forceinline__ T u1() { return -0.0529801185729; }
+	static __device__ __forceinline__ T p2() { return -0.8829110755309; }
+	static __device__ __forceinline__ T u2() { return 0.4435068520439; }
+	static __device__ __forceinline__ T s1() { return 1.1496043988602; }
+	static __device__ __forceinline__ T s2() { return 1 / 1.1496043988602; }
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - p1() * (l + r) : s == 1 ? c + u1() * (l + r) : s == 2 ? c - p2() * (l + r) : c + u2() * (l + r);
+	}
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - u2() * (l + r) : s == 1 ? c + p2() * (l + r) : s == 2 ? c - u1() * (l + r) : c + p1() * (l + r);
+	}
+	static __device__ __forceinline__ T fwd_scale(int parity, T v) { return parity ? v * s2() : v * s1(); }
+	static __device__ __forceinline__ T inv_scale(int parity, T v) { return parity ? v * s1() : v * s2(); }
+	static __device__ __forceinline__ T fwd_single(T v) { return v * s1(); }
+	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
+};
+
+// src/libdwt.c:2085-2130, 11484-11530; constants src/inline.h:337-341
+struct Cdf53D {
+	using T = double;
+	static constexpr int K = 2;
+	static constexpr bool kScaleSingle = true;
+	static constexpr bool kSkipSingleLine = false;
+	static constexpr bool kInvColsFirst = false;
+	static __device__ __forceinline__ T s1() { return 1.41421356237309504880; }
+	static __device__ __forceinline__ T s2() { return 0.70710678118654752440; }
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r) { return s == 0 ? c - 0.5 * (l + r) : c + 0.25 * (l + r); }
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r) { return s == 0 ? c - 0.25 * (l + r) : c + 0.5 * (l + r); }
+	static __device__ __forceinline__ T fwd_scale(int parity, T v) { return parity ? v * s2() : v * s1(); }
+	static __device__ __forceinline__ T inv_scale(int parity, T v) { return parity ? v * s1() : v * s2(); }
+	static __device__ __forceinline__ T fwd_single(T v) { return v * s1(); }
+	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
+};
+
 // Whole-sample symmetric reflection of i into [0, N), N >= 2, any i.
 static __device__ __forceinline__ int reflect(int i, int N)
 {

@@ -34,6 +34,17 @@ static const float C53_P1 = 0.5;
 static const float C53_U1 = 0.25;
 static const float C53_S1 = 1.41421356237309504880;
 static const float C53_S2 = 0.70710678118654752440;
+/* double constants: src/inline.h:317-323, 337-341 */
+static const double D97_P1 = 1.58613434342059;
+static const double D97_U1 = -0.0529801185729;
+static const double D97_P2 = -0.8829110755309;
+static const double D97_U2 = 0.4435068520439;
+static const double D97_S1 = 1.1496043988602;
+static const double D97_S2 = 1 / 1.1496043988602;
+static const double D53_P1 = 0.5;
+static const double D53_U1 = 0.25;
+static const double D53_S1 = 1.41421356237309504880;
+static const double D53_S2 = 0.70710678118654752440;
 
 /* ---- integer helpers: src/inline.h:443-461 ---- */
 int oracle_ceil_div_pow2(int i, int j)
@@ -211,11 +222,100 @@ void oracle_line_cdf53_i_s(float *a, int N)
 		a[i] += C53_P1 * (a[i - 1] + a[i + 1]);
 }
 
+/* ---- double precision line kernels, statement order of the reference kept ----
+ * generic in the four constants: CDF 9/7 runs (p1,u1) then (p2,u2); CDF 5/3 only (p1,u1)
+ * src/libdwt.c:2024-2083 (9/7 fwd), :11423-11482 (9/7 inv), :2085-2130, :11484-11530 (5/3) */
+static void pu_fwd_d(double *a, int N, double p, double u)
+{
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] -= p * (a[i - 1] + a[i + 1]);
+	if (N & 1)
+		a[N - 1] += 2 * u * a[N - 2];
+	else
+		a[N - 1] -= 2 * p * a[N - 2];
+	a[0] += 2 * u * a[1];
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] += u * (a[i - 1] + a[i + 1]);
+}
+
+static void pu_inv_d(double *a, int N, double p, double u)
+{
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] -= u * (a[i - 1] + a[i + 1]);
+	a[0] -= 2 * u * a[1];
+	if (N & 1)
+		a[N - 1] -= 2 * u * a[N - 2];
+	else
+		a[N - 1] += 2 * p * a[N - 2];
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] += p * (a[i - 1] + a[i + 1]);
+}
+
+void oracle_line_cdf97_f_d(double *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * D97_S1;
+		return;
+	}
+	pu_fwd_d(a, N, D97_P1, D97_U1);
+	pu_fwd_d(a, N, D97_P2, D97_U2);
+	for (int i = 0; i < N; i += 2)
+		a[i] = a[i] * D97_S1;
+	for (int i = 1; i < N; i += 2)
+		a[i] = a[i] * D97_S2;
+}
+
+void oracle_line_cdf97_i_d(double *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * D97_S2;
+		return;
+	}
+	for (int i = 0; i < N; i += 2)
+		a[i] = a[i] * D97_S2;
+	for (int i = 1; i < N; i += 2)
+		a[i] = a[i] * D97_S1;
+	pu_inv_d(a, N, D97_P2, D97_U2);
+	pu_inv_d(a, N, D97_P1, D97_U1);
+}
+
+void oracle_line_cdf53_f_d(double *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * D53_S1;
+		return;
+	}
+	pu_fwd_d(a, N, D53_P1, D53_U1);
+	for (int i = 0; i < N; i += 2)
+		a[i] = a[i] * D53_S1;
+	for (int i = 1; i < N; i += 2)
+		a[i] = a[i] * D53_S2;
+}
+
+void oracle_line_cdf53_i_d(double *a, int N)
+{
+	if (N < 2) {
+		if (N == 1)
+			a[0] = a[0] * D53_S2;
+		return;
+	}
+	for (int i = 0; i < N; i += 2)
+		a[i] = a[i] * D53_S2;
+	for (int i = 1; i < N; i += 2)
+		a[i] = a[i] * D53_S1;
+	pu_inv_d(a, N, D53_P1, D53_U1);
+}
+
 /* ---- strided line drivers (gather -> lift -> Mallat scatter) ----
  * The gather/scatter is dwt_util_memcpy_stride_{s,i} (src/system.c:102-164). */
 typedef void (*line_fn)(void *a, int N);
 
-enum wavelet { W97S, W53I, W53S };
+enum wavelet { W97S, W53I, W53S, W97D, W53D };
+
+static int elem_size(enum wavelet w) { return (w == W97D || w == W53D) ? 8 : 4; }
 
 static void lift_fwd(enum wavelet w, void *tmp, int N)
 {
@@ -223,6 +323,8 @@ static void lift_fwd(enum wavelet w, void *tmp, int N)
 	case W97S: oracle_line_cdf97_f_s((float *)tmp, N); break;
 	case W53I: oracle_line_cdf53_f_i((int *)tmp, N); break;
 	case W53S: oracle_line_cdf53_f_s((float *)tmp, N); break;
+	case W97D: oracle_line_cdf97_f_d((double *)tmp, N); break;
+	case W53D: oracle_line_cdf53_f_d((double *)tmp, N); break;
 	}
 }
 
@@ -232,10 +334,12 @@ static void lift_inv(enum wavelet w, void *tmp, int N)
 	case W97S: oracle_line_cdf97_i_s((float *)tmp, N); break;
 	case W53I: oracle_line_cdf53_i_i((int *)tmp, N); break;
 	case W53S: oracle_line_cdf53_i_s((float *)tmp, N); break;
+	case W97D: oracle_line_cdf97_i_d((double *)tmp, N); break;
+	case W53D: oracle_line_cdf53_i_d((double *)tmp, N); break;
 	}
 }
 
-/* element access: 4-byte elements at arbitrary byte strides (possibly unaligned) */
+/* element access: 4- or 8-byte elements at arbitrary byte strides (possibly unaligned) */
 static inline unsigned ld32(const char *p)
 {
 	unsigned v;
@@ -248,49 +352,58 @@ static inline void st32(char *p, unsigned v)
 	memcpy(p, &v, 4);
 }
 
-/* forward line: src -> (dst_l, dst_h); *_ex_stride_* at :10744, :10950, :10986 */
-static void fwd_line(enum wavelet w, const char *src, char *dst_l, char *dst_h,
-	unsigned *tmp, int N, long stride)
+static inline void zero_elem(char *p, int es)
 {
+	memset(p, 0, (size_t)es);
+}
+
+/* forward line: src -> (dst_l, dst_h); *_ex_stride_* at :10744, :10950, :10986, :2024 */
+static void fwd_line(enum wavelet w, const char *src, char *dst_l, char *dst_h,
+	unsigned *tmp32, int N, long stride)
+{
+	const int es = elem_size(w);
+	char *tmp = (char *)tmp32;
 	if (N < 2) {
-		/* float kernels scale the lone sample; the int kernel leaves it (:10961) */
+		/* float/double kernels scale the lone sample; the int kernel leaves it (:10961) */
 		if (N == 1 && w != W53I) {
-			tmp[0] = ld32(src);
+			memcpy(tmp, src, (size_t)es);
 			lift_fwd(w, tmp, 1);
-			st32(dst_l, tmp[0]);
+			memcpy(dst_l, tmp, (size_t)es);
 		}
 		return;
 	}
 	for (int i = 0; i < N; i++)
-		tmp[i] = ld32(src + i * stride);
+		memcpy(tmp + (size_t)i * es, src + i * stride, (size_t)es);
 	lift_fwd(w, tmp, N);
 	const int nl = (N + 1) >> 1, nh = N >> 1;
 	for (int i = 0; i < nl; i++)
-		st32(dst_l + i * stride, tmp[2 * i]);
+		memcpy(dst_l + i * stride, tmp + (size_t)(2 * i) * es, (size_t)es);
 	for (int i = 0; i < nh; i++)
-		st32(dst_h + i * stride, tmp[2 * i + 1]);
+		memcpy(dst_h + i * stride, tmp + (size_t)(2 * i + 1) * es, (size_t)es);
 }
 
-/* inverse line: (src_l, src_h) -> dst; :11530, :11749, :11785 */
+/* inverse line: (src_l, src_h) -> dst; :11530, :11749, :11785, :11423 */
 static void inv_line(enum wavelet w, const char *src_l, const char *src_h, char *dst,
-	unsigned *tmp, int N, long stride)
+	unsigned *tmp32, int N, long stride)
 {
+	const int es = elem_size(w);
+	char *tmp = (char *)tmp32;
 	if (N < 2) {
 		if (N == 1 && w != W53I) {
-			tmp[0] = ld32(src_l);
+			memcpy(tmp, src_l, (size_t)es);
 			lift_inv(w, tmp, 1);
-			st32(dst, tmp[0]);
+			memcpy(dst, tmp, (size_t)es);
 		}
 		return;
 	}
 	const int nl = (N + 1) >> 1, nh = N >> 1;
 	for (int i = 0; i < nl; i++)
-		tmp[2 * i] = ld32(src_l + i * stride);
+		memcpy(tmp + (size_t)(2 * i) * es, src_l + i * stride, (size_t)es);
 	for (int i = 0; i < nh; i++)
-		tmp[2 * i + 1] = ld32(src_h + i * stride);
+		memcpy(tmp + (size_t)(2 * i + 1) * es, src_h + i * stride, (size_t)es);
 	lift_inv(w, tmp, N);
 	for (int i = 0; i < N; i++)
-		st32(dst + i * stride, tmp[i]);
+		memcpy(dst + i * stride, tmp + (size_t)i * es, (size_t)es);
 }
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
@@ -298,7 +411,7 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 
 static unsigned *alloc_tmp(int n, int threads)
 {
-	unsigned *t = (unsigned *)malloc((size_t)threads * (size_t)(n + 8) * sizeof(unsigned));
+	unsigned *t = (unsigned *)malloc((size_t)threads * (size_t)(n + 8) * 2 * sizeof(unsigned));
 	if (!t) {
 		fprintf(stderr, "oracle: out of memory\n");
 		abort();
@@ -317,21 +430,21 @@ static inline int thread_id(void)
 
 /* dwt_zero_padding_f_stride_* (src/libdwt.c:12079-12131): zero [ceil(N/2),N_dst_L)
  * after dst_l and [floor(N/2),N_dst_H) after dst_h */
-static void zero_pad_f(char *dst_l, char *dst_h, int N, int n_dst_l, int n_dst_h, long stride)
+static void zero_pad_f(char *dst_l, char *dst_h, int N, int n_dst_l, int n_dst_h, long stride, int es)
 {
 	if (n_dst_l || n_dst_h) {
 		for (int i = (N + 1) >> 1; i < n_dst_l; i++)
-			st32(dst_l + i * stride, 0);
+			zero_elem(dst_l + i * stride, es);
 		for (int i = N >> 1; i < n_dst_h; i++)
-			st32(dst_h + i * stride, 0);
+			zero_elem(dst_h + i * stride, es);
 	}
 }
 
 /* dwt_zero_padding_i_stride_* (src/libdwt.c:12161-12215) */
-static void zero_pad_i(char *dst, int N, int n_dst, long stride)
+static void zero_pad_i(char *dst, int N, int n_dst, long stride, int es)
 {
 	for (int i = N; i < n_dst; i++)
-		st32(dst + i * stride, 0);
+		zero_elem(dst + i * stride, es);
 }
 
 /* Generic forward driver.  `skip_single` models the `lines_x > 1` / `lines_y > 1`
@@ -361,7 +474,7 @@ static void fwd_2d(enum wavelet w, int skip_single, const void *src0, void *dst,
 		if (!skip_single || so_src_x > 1) {
 #pragma omp parallel for schedule(static) num_threads(threads)
 			for (int y = 0; y < so_src_y; y++) {
-				unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+				unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8) * 2;
 				fwd_line(w, src + (long)y * stride_x, d + (long)y * stride_x,
 					d + (long)y * stride_x + (long)so_dst_x * stride_y,
 					tmp, si_src_x, stride_y);
@@ -371,7 +484,7 @@ static void fwd_2d(enum wavelet w, int skip_single, const void *src0, void *dst,
 		if (!skip_single || so_src_y > 1) {
 #pragma omp parallel for schedule(static) num_threads(threads)
 			for (int x = 0; x < so_src_x; x++) {
-				unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+				unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8) * 2;
 				fwd_line(w, src + (long)x * stride_y, d + (long)x * stride_y,
 					d + (long)so_dst_y * stride_x + (long)x * stride_y,
 					tmp, si_src_y, stride_x);
@@ -381,10 +494,10 @@ static void fwd_2d(enum wavelet w, int skip_single, const void *src0, void *dst,
 		if (zero_padding) {
 			for (int y = 0; y < so_src_y; y++)
 				zero_pad_f(d + (long)y * stride_x, d + (long)y * stride_x + (long)so_dst_x * stride_y,
-					si_src_x, so_dst_x, so_src_x - so_dst_x, stride_y);
+					si_src_x, so_dst_x, so_src_x - so_dst_x, stride_y, elem_size(w));
 			for (int x = 0; x < so_src_x; x++)
 				zero_pad_f(d + (long)x * stride_y, d + (long)so_dst_y * stride_x + (long)x * stride_y,
-					si_src_y, so_dst_y, so_src_y - so_dst_y, stride_x);
+					si_src_y, so_dst_y, so_src_y - so_dst_y, stride_x, elem_size(w));
 		}
 	}
 	free(tmp_all);
@@ -417,7 +530,7 @@ static void inv_2d(enum wavelet w, int skip_single, int cols_first, void *ptr,
 				if (!skip_single || so_dst_x > 1) {
 #pragma omp parallel for schedule(static) num_threads(threads)
 					for (int y = 0; y < so_dst_y; y++) {
-						unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+						unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8) * 2;
 						inv_line(w, p + (long)y * stride_x,
 							p + (long)y * stride_x + (long)so_src_x * stride_y,
 							p + (long)y * stride_x, tmp, si_dst_x, stride_y);
@@ -427,7 +540,7 @@ static void inv_2d(enum wavelet w, int skip_single, int cols_first, void *ptr,
 				if (!skip_single || so_dst_y > 1) {
 #pragma omp parallel for schedule(static) num_threads(threads)
 					for (int x = 0; x < so_dst_x; x++) {
-						unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8);
+						unsigned *tmp = tmp_all + (size_t)thread_id() * (so_max + 8) * 2;
 						inv_line(w, p + (long)x * stride_y,
 							p + (long)so_src_y * stride_x + (long)x * stride_y,
 							p + (long)x * stride_y, tmp, si_dst_y, stride_x);
@@ -437,9 +550,9 @@ static void inv_2d(enum wavelet w, int skip_single, int cols_first, void *ptr,
 		}
 		if (zero_padding) {
 			for (int y = 0; y < so_dst_y; y++)
-				zero_pad_i(p + (long)y * stride_x, si_dst_x, so_dst_x, stride_y);
+				zero_pad_i(p + (long)y * stride_x, si_dst_x, so_dst_x, stride_y, elem_size(w));
 			for (int x = 0; x < so_dst_x; x++)
-				zero_pad_i(p + (long)x * stride_y, si_dst_y, so_dst_y, stride_x);
+				zero_pad_i(p + (long)x * stride_y, si_dst_y, so_dst_y, stride_x, elem_size(w));
 		}
 	}
 	free(tmp_all);
@@ -496,6 +609,32 @@ void oracle_cdf53_2i_s(void *ptr, int stride_x, int stride_y, int sox, int soy, 
 	int j_max, int decompose_one, int zero_padding)
 {
 	inv_2d(W53S, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
+}
+
+/* double precision drivers: src/libdwt.c:12451, 16884 (9/7), :12535, :16962 (5/3); rows
+ * then columns both ways, no single-line guards */
+void oracle_cdf97_2f_d(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	fwd_2d(W97D, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding);
+}
+
+void oracle_cdf97_2i_d(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	inv_2d(W97D, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
+}
+
+void oracle_cdf53_2f_d(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	fwd_2d(W53D, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding);
+}
+
+void oracle_cdf53_2i_d(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	inv_2d(W53D, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
 }
 
 /* ---- 3-D single level, interleaved in place: x lines, then y, then z ----

@@ -59,6 +59,24 @@ void oracle_cdf53_2i_s(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
 	int j_max, int decompose_one, int zero_padding);
 
+/* double precision: src/libdwt.c:12451, 16884, 12535, 16962 */
+void oracle_cdf97_2f_d(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void oracle_cdf97_2i_d(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+void oracle_cdf53_2f_d(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void oracle_cdf53_2i_d(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+void oracle_line_cdf97_f_d(double *a, int N);  /* src/libdwt.c:2024-2083 */
+void oracle_line_cdf97_i_d(double *a, int N);  /* src/libdwt.c:11423-11482 */
+void oracle_line_cdf53_f_d(double *a, int N);  /* src/libdwt.c:2085-2130 */
+void oracle_line_cdf53_i_d(double *a, int N);  /* src/libdwt.c:11484-11530 */
+
 /* 1-D line kernels on a dense temporary (the arithmetic of the path). */
 void oracle_line_cdf97_f_s(float *a, int N);   /* src/libdwt.c:10744-10800 + 10551 */
 void oracle_line_cdf97_i_s(float *a, int N);   /* src/libdwt.c:11530-11571 */

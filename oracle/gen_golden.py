@@ -56,18 +56,31 @@ WAVELETS = {
     "cdf97_s": ("cdf97_2f_s", "cdf97_2i_s", np.float32),
     "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i", np.int32),
     "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32),
+    "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d", np.float64),
+    "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d", np.float64),
 }
+
+# the double-precision drivers get a subset of the cases (they run the same drivers'
+# geometry code; the fixtures pin the arithmetic and the N==1 / sparse-frame behaviour)
+DOUBLE_CASES = {"8x8_rand", "37x53_rand", "64x5_rand", "1x64_rand", "64x1_rand", "2x2_rand", "3x3_rand", "4x4_rand",
+                "100x100_pat_full", "sparse_64x64_50x40_zp", "sparse_33x17_20x9", "sparse_40x24_1x1_zp", "129x65_rand_j4"}
 
 
 def make_input(ref, kind, dt, h, w_alloc, w, seed):
     rng = np.random.default_rng(seed)
     if dt == np.float32:
         buf = rng.random((h, w_alloc), dtype=np.float32)
+    elif dt == np.float64:
+        buf = rng.random((h, w_alloc))
     else:
         buf = rng.integers(-32768, 32768, size=(h, w_alloc), dtype=np.int32)
     if kind == "pattern":
         if dt == np.float32:
             ref.fill_s(buf[:, :w])
+        elif dt == np.float64:
+            tmp = np.zeros((h, w), np.float32)
+            ref.fill_s(tmp)
+            buf[:, :w] = tmp
         else:
             ref.fill_i(buf[:, :w])
     return buf
@@ -82,6 +95,8 @@ def main():
         arrays = {}
         meta = []
         for idx, (name, so, si, j, d1, zp, pad, kind) in enumerate(CASES_2D):
+            if dt == np.float64 and name not in DOUBLE_CASES:
+                continue
             w, h = so
             buf = make_input(ref, kind, dt, h, w + pad, w, seed=1000 + idx)
             src = buf.copy()

@@ -51,4 +51,5 @@ def golden_cases(wname):
 
 
 def bits(a):
-    return np.ascontiguousarray(a).view(np.uint32)
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64 if a.dtype.itemsize == 8 else np.uint32)

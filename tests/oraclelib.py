@@ -35,6 +35,10 @@ ENTRIES = {
     "cdf53_2i_i": (_INV, np.int32),
     "cdf53_2f_s": (_FWD, np.float32),
     "cdf53_2i_s": (_INV, np.float32),
+    "cdf97_2f_d": (_FWD, np.float64),
+    "cdf97_2i_d": (_INV, np.float64),
+    "cdf53_2f_d": (_FWD, np.float64),
+    "cdf53_2i_d": (_INV, np.float64),
 }
 
 
@@ -65,16 +69,17 @@ class _Lib:
         are (x, y) pairs and default to the array shape.  Returns the level count
         the callee reports (forward) or `j` (inverse)."""
         sig, dt = ENTRIES[name]
-        assert img.dtype == dt and img.ndim == 2 and img.strides[1] == 4
+        es = np.dtype(dt).itemsize
+        assert img.dtype == dt and img.ndim == 2 and img.strides[1] == es
         h, w = img.shape
         sox, soy = size_o if size_o else (w, h)
         six, siy = size_i if size_i else (sox, soy)
         fn = getattr(self.lib, self.prefix + name)
         if "2f" in name:
             jj = _I(j)
-            fn(img.ctypes.data, img.strides[0], 4, sox, soy, six, siy, C.byref(jj), decompose_one, zero_padding)
+            fn(img.ctypes.data, img.strides[0], es, sox, soy, six, siy, C.byref(jj), decompose_one, zero_padding)
             return jj.value
-        fn(img.ctypes.data, img.strides[0], 4, sox, soy, six, siy, j, decompose_one, zero_padding)
+        fn(img.ctypes.data, img.strides[0], es, sox, soy, six, siy, j, decompose_one, zero_padding)
         return j
 
     def fwd(self, name, img, j=-1, **kw):

@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 
 NAMES = {"cdf97_s": ("cdf97_2f_s", "cdf97_2i_s", np.float32),
          "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i", np.int32),
-         "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32)}
+         "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32),
+         "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d", np.float64),
+         "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d", np.float64)}
 
 
 @pytest.fixture(scope="module")
@@ -30,6 +32,8 @@ def dwt():
 def rand_img(rng, h, w, dt):
     if dt == np.float32:
         return rng.random((h, w), dtype=np.float32) * 2 - 1
+    if dt == np.float64:
+        return rng.random((h, w)) * 2 - 1
     return rng.integers(-32768, 32768, size=(h, w), dtype=np.int32)
 
 
@@ -61,12 +65,13 @@ def test_golden_host_entry(dwt, wname, case, accel):
             assert np.array_equal(bits(rec), bits(inv))
             return
         buf = src.copy()
+        es = buf.dtype.itemsize
         (sox, soy), (six, siy) = meta["size_o"], meta["size_i"]
-        j = dwt.FORWARD[wname](buf, buf.strides[0], 4, sox, soy, six, siy, meta["j_in"],
+        j = dwt.FORWARD[wname](buf, buf.strides[0], es, sox, soy, six, siy, meta["j_in"],
                                meta["decompose_one"], meta["zero_padding"])
         assert j == meta["j_out"]
         assert np.array_equal(bits(buf), bits(fwd)), "forward differs from the reference's coefficients"
-        dwt.INVERSE[wname](buf, buf.strides[0], 4, sox, soy, six, siy, j, meta["decompose_one"], meta["zero_padding"])
+        dwt.INVERSE[wname](buf, buf.strides[0], es, sox, soy, six, siy, j, meta["decompose_one"], meta["zero_padding"])
         assert np.array_equal(bits(buf), bits(inv)), "inverse differs from the reference's output"
     finally:
         dwt.dwt_util_set_accel(0)
@@ -87,9 +92,12 @@ def test_device_resident_vs_oracle(dwt, oracle, wname, shape, inplace):
     want = img.copy()
     jw = oracle.fwd(ff, want, -1)
     wid = dwt.WAVELET_ID[wname]
-    a = dwt.DeviceImage(h, w).upload(img)
-    b = a if inplace else dwt.DeviceImage(h, w).upload(np.zeros_like(img))
-    j = dwt._fwd(wid, a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, -1, 0, 0, "fwd")
+    es = img.dtype.itemsize
+    if es == 8 and (inplace is False or h * w > 600000):
+        pytest.skip("double precision: in-place entries only, moderate sizes")
+    a = dwt.DeviceImage(h, w, itemsize=es).upload(img)
+    b = a if inplace else dwt.DeviceImage(h, w, itemsize=es).upload(np.zeros_like(img))
+    j = dwt._fwd(wid, a.ptr, b.ptr, a.stride_x, es, w, h, w, h, -1, 0, 0, "fwd")
     got = b.download(dt)
     assert j == jw
     assert np.array_equal(bits(got), bits(want))
@@ -98,7 +106,7 @@ def test_device_resident_vs_oracle(dwt, oracle, wname, shape, inplace):
     if not inplace:
         assert np.array_equal(a.download(dt), img), "_s2 must leave the source untouched"
     # inverse (b -> a for s2, in place otherwise)
-    dwt._inv(wid, b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, j, 0, 0, "inv")
+    dwt._inv(wid, b.ptr, a.ptr, a.stride_x, es, w, h, w, h, j, 0, 0, "inv")
     rec = a.download(dt)
     oracle.inv(fi, want, jw)
     assert np.array_equal(bits(rec), bits(want))
@@ -380,7 +388,12 @@ def test_harness_helpers(dwt):
     # the loop of examples/test/test.c: 256x256, DWT_ARR_SIMPLE (0), opt stride 1, full depth, decompose_one
     for arr in (0, 1, 2):
         assert L.dwt_util_test2_cdf97_2_s(arr, 256, 256, 1, -1, 1) == 0
-        assert L.dwt_util_test2_cdf97_2_s2(arr, 200, 120, 1, -1, 1) == 0
+        assert L.dwt_util_test2_cdf97_2_s2(arr, 256, 256, 1, -1, 1) == 0
+        assert L.dwt_util_test2_cdf97_2_s(arr, 200, 120, 1, -1, 1) == 0
+    # The reference's own `_s2` self-test FAILS on sparse frames (dwt_cdf97_2i_s2 copies only
+    # the inner region, src/libdwt.c:18001-18008, but detail subbands sit at outer-frame
+    # offsets); the drop-in reproduces that, bit for bit (checked against libdwt_ref.so: 1, 1, 0)
+    assert [L.dwt_util_test2_cdf97_2_s2(arr, 200, 120, 1, -1, 1) for arr in (0, 1, 2)] == [1, 1, 0]
     f, i = C.c_float(0), C.c_float(0)
     L.dwt_util_perf_cdf97_2_s.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_float)] * 2
     L.dwt_util_perf_cdf97_2_s(2048 * 4, 4, 2048, 2048, 2048, 2048, 3, 0, 0, 2, 3, 0, C.byref(f), C.byref(i))

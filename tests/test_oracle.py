@@ -14,6 +14,8 @@ WAVELETS = {
     "cdf97_s": ("cdf97_2f_s", "cdf97_2i_s"),
     "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i"),
     "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s"),
+    "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d"),
+    "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d"),
 }
 
 
@@ -72,6 +74,8 @@ def test_oracle_bitwise_equals_reference(oracle, reference, wname):
         for j, d1 in [(-1, 0), (2, 0), (-1, 1)]:
             if dt == np.float32:
                 a = rng.random((h, w), dtype=np.float32) * 2 - 1
+            elif dt == np.float64:
+                a = rng.random((h, w)) * 2 - 1
             else:
                 a = rng.integers(-32768, 32768, size=(h, w), dtype=np.int32)
             b = a.copy()

@@ -68,6 +68,14 @@ void dwt_cdf53_2i_s(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
 	int j_max, int decompose_one, int zero_padding);
 
+/* Fixed-point int32 CDF 9/7.  src/libdwt.h:704, 999. */
+void dwt_cdf97_2f_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void dwt_cdf97_2i_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+
 /* Double precision CDF 9/7 and 5/3 (elements of 8 bytes).  src/libdwt.h:526, 831, 544, 849. */
 void dwt_cdf97_2f_d(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,

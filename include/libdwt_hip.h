@@ -34,7 +34,8 @@ enum dwt_hip_wavelet {
 	DWT_HIP_CDF53_I = 1, /* int32 CDF 5/3: dwt_cdf53_2f_i / dwt_cdf53_2i_i (src/libdwt.c:16304, 18142) */
 	DWT_HIP_CDF53_S = 2, /* float CDF 5/3: dwt_cdf53_2f_s / dwt_cdf53_2i_s (src/libdwt.c:16470, 18296) */
 	DWT_HIP_CDF97_D = 3, /* double CDF 9/7: dwt_cdf97_2f_d / dwt_cdf97_2i_d (src/libdwt.c:12451, 16884) */
-	DWT_HIP_CDF53_D = 4  /* double CDF 5/3: dwt_cdf53_2f_d / dwt_cdf53_2i_d (src/libdwt.c:12535, 16962) */
+	DWT_HIP_CDF53_D = 4, /* double CDF 5/3: dwt_cdf53_2f_d / dwt_cdf53_2i_d (src/libdwt.c:12535, 16962) */
+	DWT_HIP_CDF97_I = 5  /* int32 fixed-point CDF 9/7: dwt_cdf97_2f_i / dwt_cdf97_2i_i (src/libdwt.c:16387, 18219) */
 };
 
 /* Lifecycle.  dwt_hip_init picks the device from DWT_HIP_DEVICE, else LOCAL_RANK,

@@ -22,7 +22,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdwt_hip.so")
 
-CDF97_S, CDF53_I, CDF53_S, CDF97_D, CDF53_D = 0, 1, 2, 3, 4
+CDF97_S, CDF53_I, CDF53_S, CDF97_D, CDF53_D, CDF97_I = 0, 1, 2, 3, 4, 5
 
 
 class DwtError(RuntimeError):
@@ -49,7 +49,7 @@ _INV2 = [_P, _P] + _INV[1:]
 for _n, _sig in (("dwt_cdf97_2f_s", _FWD), ("dwt_cdf97_2i_s", _INV), ("dwt_cdf97_2f_s2", _FWD2),
                  ("dwt_cdf97_2i_s2", _INV2), ("dwt_cdf53_2f_i", _FWD), ("dwt_cdf53_2i_i", _INV),
                  ("dwt_cdf53_2f_s", _FWD), ("dwt_cdf53_2i_s", _INV), ("dwt_cdf97_2f_d", _FWD), ("dwt_cdf97_2i_d", _INV),
-                 ("dwt_cdf53_2f_d", _FWD), ("dwt_cdf53_2i_d", _INV)):
+                 ("dwt_cdf53_2f_d", _FWD), ("dwt_cdf53_2i_d", _INV), ("dwt_cdf97_2f_i", _FWD), ("dwt_cdf97_2i_i", _INV)):
     getattr(lib, _n).argtypes = _sig
     getattr(lib, _n).restype = None
 
@@ -274,11 +274,26 @@ def dwt_cdf53_2i_d(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_b
          j_max, decompose_one, zero_padding, "dwt_cdf53_2i_d")
 
 
+def dwt_cdf97_2f_i(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:16387 (fixed-point int32 CDF 9/7)"""
+    return _fwd(CDF97_I, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                j_max, decompose_one, zero_padding, "dwt_cdf97_2f_i")
+
+
+def dwt_cdf97_2i_i(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                   j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:18219"""
+    _inv(CDF97_I, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+         j_max, decompose_one, zero_padding, "dwt_cdf97_2i_i")
+
+
 FORWARD = {"cdf97_s": dwt_cdf97_2f_s, "cdf53_i": dwt_cdf53_2f_i, "cdf53_s": dwt_cdf53_2f_s,
-           "cdf97_d": dwt_cdf97_2f_d, "cdf53_d": dwt_cdf53_2f_d}
+           "cdf97_d": dwt_cdf97_2f_d, "cdf53_d": dwt_cdf53_2f_d, "cdf97_i": dwt_cdf97_2f_i}
 INVERSE = {"cdf97_s": dwt_cdf97_2i_s, "cdf53_i": dwt_cdf53_2i_i, "cdf53_s": dwt_cdf53_2i_s,
-           "cdf97_d": dwt_cdf97_2i_d, "cdf53_d": dwt_cdf53_2i_d}
-WAVELET_ID = {"cdf97_s": CDF97_S, "cdf53_i": CDF53_I, "cdf53_s": CDF53_S, "cdf97_d": CDF97_D, "cdf53_d": CDF53_D}
+           "cdf97_d": dwt_cdf97_2i_d, "cdf53_d": dwt_cdf53_2i_d, "cdf97_i": dwt_cdf97_2i_i}
+WAVELET_ID = {"cdf97_s": CDF97_S, "cdf53_i": CDF53_I, "cdf53_s": CDF53_S, "cdf97_d": CDF97_D, "cdf53_d": CDF53_D,
+              "cdf97_i": CDF97_I}
 
 
 # ---- batches resident in HBM -----------------------------------------------------------

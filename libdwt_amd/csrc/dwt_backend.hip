@@ -161,7 +161,7 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 {
 	if (n_lines <= 0 || N <= 0)
 		return 0;
-	if (N == 1 && w == kCdf53I)
+	if (N == 1 && (w == kCdf53I || w == kCdf97I))
 		return 0;
 	const bool alias = in.p == out.p;
 	Img dst = out;
@@ -384,7 +384,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 	}
 	if (ensure_ll(ge, batch))
 		return 1;
-	const bool cols_first = (w == kCdf53I);
+	const bool cols_first = (w == kCdf53I || w == kCdf97I); // the int inverses undo columns first
 
 	// reconstruction level j consumes the subbands of size ceil(.,j) and produces the
 	// band of size ceil(.,j-1); it is fused when that PRODUCED frame is dense and >= 2
@@ -734,7 +734,7 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 {
 	if (check_inited())
 		return 1;
-	if (wavelet < 0 || wavelet > 4)
+	if (wavelet < 0 || wavelet > 5)
 		return fail("unknown wavelet %d", wavelet);
 	if (!src || !dst || !j)
 		return fail("null pointer argument");
@@ -823,7 +823,7 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 {
 	if (check_inited())
 		return 1;
-	if (wavelet < 0 || wavelet > 2)
+	if (wavelet < 0 || wavelet > 5 || elem_size((Wavelet)wavelet) != 4)
 		return fail("unknown wavelet %d (batches take the 32-bit wavelets)", wavelet);
 	g_elems_are_32bit = true;
 	if (!src || !dst || !j || batch < 1)

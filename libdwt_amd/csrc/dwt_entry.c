@@ -77,6 +77,19 @@ void dwt_cdf53_2i_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int
 	run(DWT_HIP_CDF53_S, 1, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, zero_padding, __func__);
 }
 
+/* fixed-point int32 CDF 9/7: src/libdwt.c:16387, 18219 */
+void dwt_cdf97_2f_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF97_I, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding, __func__);
+}
+
+void dwt_cdf97_2i_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	run(DWT_HIP_CDF97_I, 1, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, zero_padding, __func__);
+}
+
 /* double precision: src/libdwt.c:12451, 16884, 12535, 16962 (line-pass kernels) */
 void dwt_cdf97_2f_d(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
 	int *j_max_ptr, int decompose_one, int zero_padding)

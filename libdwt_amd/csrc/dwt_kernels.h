@@ -6,9 +6,9 @@
 
 namespace dwt {
 
-enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2, kCdf97D = 3, kCdf53D = 4 };
+enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2, kCdf97D = 3, kCdf53D = 4, kCdf97I = 5 };
 
-inline int elem_size(Wavelet w) { return w >= kCdf97D ? 8 : 4; }
+inline int elem_size(Wavelet w) { return (w == kCdf97D || w == kCdf53D) ? 8 : 4; }
 
 // Tuning knobs of the fused sweep kernels (set through dwt_hip_set_option).
 struct SweepTuning {

@@ -121,6 +121,7 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 	case kCdf53S: return line_pass_t<Cdf53S>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf97D: return line_pass_t<Cdf97D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf53D: return line_pass_t<Cdf53D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
+	case kCdf97I: return line_pass_t<Cdf97I>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	}
 	return hipErrorInvalidValue;
 }
@@ -956,6 +957,7 @@ hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning 
 	case kCdf97S: return fwd_level_t<Cdf97S>(a, t, s);
 	case kCdf53I: return fwd_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return fwd_level_t<Cdf53S>(a, t, s);
+	case kCdf97I: return fwd_level_t<Cdf97I>(a, t, s);
 	default: break; // the double-precision drivers run on the line-pass kernels
 	}
 	return hipErrorInvalidValue;
@@ -967,6 +969,7 @@ hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning 
 	case kCdf97S: return inv_level_t<Cdf97S>(a, t, s);
 	case kCdf53I: return inv_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return inv_level_t<Cdf53S>(a, t, s);
+	case kCdf97I: return inv_level_t<Cdf97I>(a, t, s);
 	default: break;
 	}
 	return hipErrorInvalidValue;

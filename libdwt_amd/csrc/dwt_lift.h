@@ -69,6 +69,35 @@ struct Cdf53I {
 	static __device__ __forceinline__ T inv_single(T v) { return v; }
 };
 
+// Fixed-point int32 CDF 9/7 (src/libdwt.c:10901-10948, 11699-11746): no scaling; the
+// reference's own end formulas are the reflected ones (`a[N-2]+a[N-2]`), so reflection
+// is exact here for any input.
+struct Cdf97I {
+	using T = int;
+	static constexpr int K = 4;
+	static constexpr bool kScaleSingle = false;
+	static constexpr bool kSkipSingleLine = false;
+	static constexpr bool kInvColsFirst = true; // :18256-18274: columns, then rows
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - ((+203 * (l + r) - (1 << 6)) >> 7)
+		     : s == 1 ? c + ((-217 * (l + r) + (1 << 11)) >> 12)
+		     : s == 2 ? c - ((-113 * (l + r) - (1 << 6)) >> 7)
+		              : c + ((1817 * (l + r) + (1 << 11)) >> 12);
+	}
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - ((1817 * (l + r) + (1 << 11)) >> 12)
+		     : s == 1 ? c + ((-113 * (l + r) - (1 << 6)) >> 7)
+		     : s == 2 ? c - ((-217 * (l + r) + (1 << 11)) >> 12)
+		              : c + ((+203 * (l + r) - (1 << 6)) >> 7);
+	}
+	static __device__ __forceinline__ T fwd_scale(int, T v) { return v; }
+	static __device__ __forceinline__ T inv_scale(int, T v) { return v; }
+	static __device__ __forceinline__ T fwd_single(T v) { return v; }
+	static __device__ __forceinline__ T inv_single(T v) { return v; }
+};
+
 struct Cdf53S {
 	using T = float;
 	static constexpr int K = 2;

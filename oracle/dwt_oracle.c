@@ -176,6 +176,55 @@ void oracle_line_cdf53_i_i(int *a, int N)
 		a[i] += (a[i - 1] + a[i + 1]) >> 1;
 }
 
+/* ---- 1-D CDF 9/7 int32 (fixed point), src/libdwt.c:10901-10948 / 11699-11746 ---- */
+void oracle_line_cdf97_f_i(int *a, int N)
+{
+	if (N < 2)
+		return;
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] -= (+203 * (a[i - 1] + a[i + 1]) - (1 << 6)) >> 7;
+	if (N & 1)
+		a[N - 1] += (-217 * (a[N - 2] + a[N - 2]) + (1 << 11)) >> 12;
+	else
+		a[N - 1] -= (+203 * (a[N - 2] + a[N - 2]) - (1 << 6)) >> 7;
+	a[0] += (-217 * (a[1] + a[1]) + (1 << 11)) >> 12;
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] += (-217 * (a[i - 1] + a[i + 1]) + (1 << 11)) >> 12;
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] -= (-113 * (a[i - 1] + a[i + 1]) - (1 << 6)) >> 7;
+	if (N & 1)
+		a[N - 1] += (1817 * (a[N - 2] + a[N - 2]) + (1 << 11)) >> 12;
+	else
+		a[N - 1] -= (-113 * (a[N - 2] + a[N - 2]) - (1 << 6)) >> 7;
+	a[0] += (1817 * (a[1] + a[1]) + (1 << 11)) >> 12;
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] += (1817 * (a[i - 1] + a[i + 1]) + (1 << 11)) >> 12;
+}
+
+void oracle_line_cdf97_i_i(int *a, int N)
+{
+	if (N < 2)
+		return;
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] -= (1817 * (a[i - 1] + a[i + 1]) + (1 << 11)) >> 12;
+	a[0] -= (1817 * (a[1] + a[1]) + (1 << 11)) >> 12;
+	if (N & 1)
+		a[N - 1] -= (1817 * (a[N - 2] + a[N - 2]) + (1 << 11)) >> 12;
+	else
+		a[N - 1] += (-113 * (a[N - 2] + a[N - 2]) - (1 << 6)) >> 7;
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] += (-113 * (a[i - 1] + a[i + 1]) - (1 << 6)) >> 7;
+	for (int i = 2; i < N - (N & 1); i += 2)
+		a[i] -= (-217 * (a[i - 1] + a[i + 1]) + (1 << 11)) >> 12;
+	a[0] -= (-217 * (a[1] + a[1]) + (1 << 11)) >> 12;
+	if (N & 1)
+		a[N - 1] -= (-217 * (a[N - 2] + a[N - 2]) + (1 << 11)) >> 12;
+	else
+		a[N - 1] += (+203 * (a[N - 2] + a[N - 2]) - (1 << 6)) >> 7;
+	for (int i = 1; i < N - 2 + (N & 1); i += 2)
+		a[i] += (+203 * (a[i - 1] + a[i + 1]) - (1 << 6)) >> 7;
+}
+
 /* ---- 1-D CDF 5/3 float: src/libdwt.c:10986-11030 ---- */
 void oracle_line_cdf53_f_s(float *a, int N)
 {
@@ -313,7 +362,7 @@ void oracle_line_cdf53_i_d(double *a, int N)
  * The gather/scatter is dwt_util_memcpy_stride_{s,i} (src/system.c:102-164). */
 typedef void (*line_fn)(void *a, int N);
 
-enum wavelet { W97S, W53I, W53S, W97D, W53D };
+enum wavelet { W97S, W53I, W53S, W97D, W53D, W97I };
 
 static int elem_size(enum wavelet w) { return (w == W97D || w == W53D) ? 8 : 4; }
 
@@ -325,6 +374,7 @@ static void lift_fwd(enum wavelet w, void *tmp, int N)
 	case W53S: oracle_line_cdf53_f_s((float *)tmp, N); break;
 	case W97D: oracle_line_cdf97_f_d((double *)tmp, N); break;
 	case W53D: oracle_line_cdf53_f_d((double *)tmp, N); break;
+	case W97I: oracle_line_cdf97_f_i((int *)tmp, N); break;
 	}
 }
 
@@ -336,6 +386,7 @@ static void lift_inv(enum wavelet w, void *tmp, int N)
 	case W53S: oracle_line_cdf53_i_s((float *)tmp, N); break;
 	case W97D: oracle_line_cdf97_i_d((double *)tmp, N); break;
 	case W53D: oracle_line_cdf53_i_d((double *)tmp, N); break;
+	case W97I: oracle_line_cdf97_i_i((int *)tmp, N); break;
 	}
 }
 
@@ -365,7 +416,7 @@ static void fwd_line(enum wavelet w, const char *src, char *dst_l, char *dst_h,
 	char *tmp = (char *)tmp32;
 	if (N < 2) {
 		/* float/double kernels scale the lone sample; the int kernel leaves it (:10961) */
-		if (N == 1 && w != W53I) {
+		if (N == 1 && w != W53I && w != W97I) {
 			memcpy(tmp, src, (size_t)es);
 			lift_fwd(w, tmp, 1);
 			memcpy(dst_l, tmp, (size_t)es);
@@ -389,7 +440,7 @@ static void inv_line(enum wavelet w, const char *src_l, const char *src_h, char 
 	const int es = elem_size(w);
 	char *tmp = (char *)tmp32;
 	if (N < 2) {
-		if (N == 1 && w != W53I) {
+		if (N == 1 && w != W53I && w != W97I) {
 			memcpy(tmp, src_l, (size_t)es);
 			lift_inv(w, tmp, 1);
 			memcpy(dst, tmp, (size_t)es);
@@ -609,6 +660,19 @@ void oracle_cdf53_2i_s(void *ptr, int stride_x, int stride_y, int sox, int soy, 
 	int j_max, int decompose_one, int zero_padding)
 {
 	inv_2d(W53S, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
+}
+
+/* int32 CDF 9/7: src/libdwt.c:16387-16468 (rows, columns), :18219-18294 (columns, rows) */
+void oracle_cdf97_2f_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	fwd_2d(W97I, 0, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding);
+}
+
+void oracle_cdf97_2i_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	inv_2d(W97I, 0, 1, ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding);
 }
 
 /* double precision drivers: src/libdwt.c:12451, 16884 (9/7), :12535, :16962 (5/3); rows

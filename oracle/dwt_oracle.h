@@ -59,6 +59,16 @@ void oracle_cdf53_2i_s(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
 	int j_max, int decompose_one, int zero_padding);
 
+/* int32 CDF 9/7 (fixed point): src/libdwt.c:16387, 18219; line kernels :10901, :11699 */
+void oracle_cdf97_2f_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void oracle_cdf97_2i_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
+void oracle_line_cdf97_f_i(int *a, int N);
+void oracle_line_cdf97_i_i(int *a, int N);
+
 /* double precision: src/libdwt.c:12451, 16884, 12535, 16962 */
 void oracle_cdf97_2f_d(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,

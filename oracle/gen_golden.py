@@ -58,6 +58,7 @@ WAVELETS = {
     "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32),
     "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d", np.float64),
     "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d", np.float64),
+    "cdf97_i": ("cdf97_2f_i", "cdf97_2i_i", np.int32),
 }
 
 # the double-precision drivers get a subset of the cases (they run the same drivers'

@@ -39,6 +39,8 @@ ENTRIES = {
     "cdf97_2i_d": (_INV, np.float64),
     "cdf53_2f_d": (_FWD, np.float64),
     "cdf53_2i_d": (_INV, np.float64),
+    "cdf97_2f_i": (_FWD, np.int32),
+    "cdf97_2i_i": (_INV, np.int32),
 }
 
 

@@ -14,7 +14,8 @@ NAMES = {"cdf97_s": ("cdf97_2f_s", "cdf97_2i_s", np.float32),
          "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i", np.int32),
          "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32),
          "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d", np.float64),
-         "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d", np.float64)}
+         "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d", np.float64),
+         "cdf97_i": ("cdf97_2f_i", "cdf97_2i_i", np.int32)}
 
 
 @pytest.fixture(scope="module")
@@ -134,7 +135,7 @@ def test_padded_device_pitch(dwt, oracle):
 
 
 # ---- every tile geometry gives the same bits --------------------------------------------
-@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i", "cdf97_i"])
 def test_tile_variants_agree(dwt, oracle, wname):
     ff, fi, dt = NAMES[wname]
     h, w = 1100, 1300

@@ -16,6 +16,7 @@ WAVELETS = {
     "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s"),
     "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d"),
     "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d"),
+    "cdf97_i": ("cdf97_2f_i", "cdf97_2i_i"),
 }
 
 

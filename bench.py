@@ -6,7 +6,7 @@ Metric (BASELINE.json): Gsamples/s of the 2-D forward float CDF 9/7, 8192x8192,
 the algorithmic bytes of SURVEY.md s8(d) (10.656 B per input sample).
 
 A "step" is one pass of the hot path over one batch of `--images` distinct synthetic
-8192^2 images resident in HBM (out-of-place entry dwt_cdf97_2f_s2 semantics, one
+8192^2 images (default 8) resident in HBM (out-of-place entry dwt_cdf97_2f_s2 semantics, one
 kernel launch per level for the whole batch).  With N GPUs every rank transforms its
 own batch (independent images: no data-path collective); value = all ranks' samples
 divided by the slowest rank's time ("scaling": "weak").
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--levels", type=int, default=5)
-    ap.add_argument("--images", type=int, default=4, help="distinct images per step and per GPU")
+    ap.add_argument("--images", type=int, default=8, help="distinct images per step and per GPU")
     ap.add_argument("--inplace", action="store_true", help="time the in-place entry dwt_cdf97_2f_s instead of _s2")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")

@@ -786,7 +786,7 @@ static int pick_cpt(const SweepTuning &t, int W, bool inverse)
 	return W >= 1024 ? 8 : 4;
 }
 
-static int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batch)
+static int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batch, bool inverse = false)
 {
 	if (t.tile_pairs > 0)
 		return t.tile_pairs;
@@ -798,8 +798,10 @@ static int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batc
 	if ((long)W * H * batch <= (4L << 20))
 		return 4;
 	const long ntx = (W + 64 * cpt - 1) / (64 * cpt);
-	int tp = 64;
-	while (tp > 8 && ntx * ((Hd + tp - 1) / tp) * batch < 1024)
+	// the inverse sweep (256-column tiles, twice the waves) peaks at 32 pairs
+	int tp = inverse ? 32 : 64;
+	const long want = inverse ? 2048 : 1024; // inverse tiles are half as wide
+	while (tp > 8 && ntx * ((Hd + tp - 1) / tp) * batch < want)
 		tp >>= 1;
 	return tp;
 }
@@ -924,7 +926,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	const int cpt = a.interleaved ? 4 : pick_cpt(t, a.W, true);
 	const int TW = 64 * cpt;
 	SweepGeom g;
-	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
+	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch, true);
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
 	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;

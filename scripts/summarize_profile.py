@@ -43,11 +43,12 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for k, v in acc.items():
         pmc[k] = sum(v) / len(v)
 
+images = int(os.environ.get("IMAGES_PER_LAUNCH", "8"))
 summary = {
     "tag": tag,
-    "kernel": "dwt::k_fwd_sweep<dwt::Cdf97S, 8, 8, 3> (level 0: 4 images of 8192x8192 float per launch)",
+    "kernel": f"dwt::k_fwd_sweep<dwt::Cdf97S, 8, 16, 7> (level 0: {images} images of 8192x8192 float per launch)",
     "level0_avg_ns": sum(l0) / len(l0), "level0_launches": len(l0),
-    "algorithmic_bytes_per_launch": 2 * 4 * 8192 * 8192 * 4,
+    "algorithmic_bytes_per_launch": 2 * 4 * 8192 * 8192 * images,
     "pmc_per_launch": pmc,
 }
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:

@@ -184,6 +184,39 @@ static __device__ __forceinline__ void lds_read2x3(unsigned a0, unsigned a1, uns
 		: "memory");
 }
 
+static __device__ __forceinline__ void lds_read1(unsigned a0, u4 &r0)
+{
+	asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(a0) : "memory");
+}
+
+static __device__ __forceinline__ void lds_read2o(unsigned a0, unsigned a1, u4 &r0, u4 &r1, u4 &r2)
+{
+	asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+		: "=&v"(r0), "=&v"(r1), "=&v"(r2)
+		: "v"(a0), "v"(a1)
+		: "memory");
+}
+
+static __device__ __forceinline__ void lds_read2(unsigned a0, unsigned a1, u4 &r0, u4 &r1)
+{
+	asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+		: "=&v"(r0), "=&v"(r1)
+		: "v"(a0), "v"(a1)
+		: "memory");
+}
+
+// Wavefront shifts by one lane (DPP, no LDS traffic): lane t receives lane t-1 / t+1;
+// the wave's first / last lane keeps its own value (replaced by the caller).
+static __device__ __forceinline__ unsigned from_left_lane(unsigned v)
+{
+	return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+static __device__ __forceinline__ unsigned from_right_lane(unsigned v)
+{
+	return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
 static __device__ __forceinline__ unsigned lds_offset(const void *p)
 {
 	return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const void *)p);
@@ -223,6 +256,9 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	// the LL band is read again by the next level: bit 2 keeps its stores temporal so it
 	// can stay in L2 / Infinity Cache
 	[[maybe_unused]] constexpr bool kNtStoreLL = kNtStore && !(NT & 4);
+	// bit 3: take the 4-sample neighbour taps from the adjacent lanes' registers with
+	// wavefront shifts (DPP) instead of re-reading them from LDS
+	constexpr bool kShuffle = (NT & 8) != 0;
 	constexpr int TW = 64 * CPT;
 	constexpr int RS = TW + 8; // LDS row slot: [main TW | left halo 4 | right halo 4]
 	constexpr int NARR = CPT + 2 * K;
@@ -315,7 +351,30 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			const unsigned ra = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
 			T x[NARR];
 			u4 L4, R4, O0, O1;
-			if constexpr (CPT == 8) {
+			if constexpr (kShuffle) {
+				// own columns from LDS; the tile's outer halo (one 16 B block per side) is
+				// read by every lane as a broadcast and used by lanes 0 and 63 only
+				u4 H4;
+				const unsigned ha = base + TW * 4 + (lane == 63 ? 16 : 0);
+				if constexpr (CPT == 8) {
+					lds_read2o(own, ha, O0, O1, H4);
+				} else {
+					lds_read2(own, ha, O0, H4);
+					O1 = O0;
+				}
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
+					const unsigned l = from_left_lane(O1[e]);  // neighbour's last four columns
+					const unsigned r = from_right_lane(O0[e]); // neighbour's first four columns
+					L4[e] = lane == 0 ? H4[e] : l;
+					R4[e] = lane == 63 ? H4[e] : r;
+				}
+				if constexpr (CPT == 8) {
+#pragma unroll
+					for (int e = 0; e < 4; e++)
+						x[K + 4 + e] = from_bits<T>(O1[e]);
+				}
+			} else if constexpr (CPT == 8) {
 				lds_read4(la, own, ra, L4, O0, O1, R4);
 #pragma unroll
 				for (int e = 0; e < 4; e++)
@@ -830,17 +889,23 @@ static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 gri
 template <class W, int CPT>
 static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, const SweepTuning &t, hipStream_t s)
 {
-	const int nt = t.nt & 7;
+	// bits 0-2: cache policy (all eight built for A/B runs); bit 3 (wavefront shuffles
+	// for the neighbour taps) is built on top of the default policy 7 and of policy 0
+	int nt = t.nt & 15;
+	if ((nt & 8) && nt != 15 && nt != 8)
+		nt = 15;
 #define DWT_FWD_CASE(R, N) case N: return fwd_launch<W, CPT, R, N>(a, g, grid, waves, s)
 	if (t.ring == 16) {
 		switch (nt) {
 			DWT_FWD_CASE(16, 0); DWT_FWD_CASE(16, 1); DWT_FWD_CASE(16, 2); DWT_FWD_CASE(16, 3);
 			DWT_FWD_CASE(16, 4); DWT_FWD_CASE(16, 5); DWT_FWD_CASE(16, 6); DWT_FWD_CASE(16, 7);
+			DWT_FWD_CASE(16, 8); DWT_FWD_CASE(16, 15);
 		}
 	}
 	switch (nt) {
 		DWT_FWD_CASE(8, 0); DWT_FWD_CASE(8, 1); DWT_FWD_CASE(8, 2); DWT_FWD_CASE(8, 3);
 		DWT_FWD_CASE(8, 4); DWT_FWD_CASE(8, 5); DWT_FWD_CASE(8, 6); DWT_FWD_CASE(8, 7);
+		DWT_FWD_CASE(8, 8); DWT_FWD_CASE(8, 15);
 	}
 #undef DWT_FWD_CASE
 	return hipErrorInvalidValue;

@@ -181,7 +181,7 @@ def test_ring_layout_and_cache_policy_variants_agree(dwt, oracle):
     try:
         for ring in (8, 16):
             for horiz in (0, 1):
-                for nt in (0, 3, 7):
+                for nt in (0, 3, 7, 8, 15):
                     for cpt in (4, 8):
                         for k, v in (("ring", ring), ("wave_horiz", horiz), ("nt", nt), ("nt_inv", nt & 3), ("cpt", cpt), ("tile_pairs", 16)):
                             dwt.set_option(k, v)

@@ -15,6 +15,10 @@ ctypes binding with the reference's function names and argument order
 
 There is no CPU fallback anywhere: if the library is missing, importing this module
 raises; if no gfx950 device is usable, every transform raises ``DwtError``.
+
+When PyTorch is used in the same process (device tensors, streams, HIP graphs), import
+``torch`` BEFORE this module: the library then binds to the HIP runtime torch ships
+instead of loading a second one, and tensors' ``data_ptr()`` are valid for it.
 """
 import ctypes as C
 import os

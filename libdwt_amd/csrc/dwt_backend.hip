@@ -60,6 +60,11 @@ struct Ctx {
 	static constexpr int kMaxLanes = 4;
 	Lane lanes[kMaxLanes];
 	hipEvent_t fork = nullptr;
+	// side stream: the copy-back of an in-place level 0 (and the copy-aside of an in-place
+	// final inverse level) overlaps the small levels instead of preceding/following them
+	hipStream_t side = nullptr;
+	hipEvent_t side_a = nullptr, side_b = nullptr;
+	bool side_pending = false;
 	int pipeline = 0; // 0: one launch per level for the whole batch; n>=2: n lanes
 	// options
 	SweepTuning tune;
@@ -137,12 +142,42 @@ struct Geom {
 
 bool skip_single(Wavelet w) { return w == kCdf97S; } // only the 9/7 drivers guard on lines > 1
 
-int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h)
+int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h)
 {
 	if (w <= 0 || h <= 0)
 		return 0;
 	HIP_TRY(hipMemcpy2DAsync(dst.p + dy * dst.sx + dx * dst.es, dst.sx, src.p + sy_ * src.sx + sx_ * src.es, src.sx, w * dst.es, h,
-		hipMemcpyDeviceToDevice, g.stream));
+		hipMemcpyDeviceToDevice, st));
+	return 0;
+}
+
+int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h)
+{
+	return copy_rect_on(g.stream, dst, dx, dy, src, sx_, sy_, w, h);
+}
+
+// fork: work queued on the side stream from now on starts after everything already
+// queued on the main stream; join: the main stream waits for the side stream
+int side_fork()
+{
+	if (!g.side) {
+		HIP_TRY(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&g.side_a, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&g.side_b, hipEventDisableTiming));
+	}
+	HIP_TRY(hipEventRecord(g.side_a, g.stream));
+	HIP_TRY(hipStreamWaitEvent(g.side, g.side_a, 0));
+	g.side_pending = true;
+	return 0;
+}
+
+int side_join()
+{
+	if (!g.side_pending)
+		return 0;
+	g.side_pending = false;
+	HIP_TRY(hipEventRecord(g.side_b, g.side));
+	HIP_TRY(hipStreamWaitEvent(g.stream, g.side_b, 0));
 	return 0;
 }
 
@@ -163,6 +198,8 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 		return 0;
 	if (N == 1 && (w == kCdf53I || w == kCdf97I))
 		return 0;
+	if (side_join())
+		return 1;
 	const bool alias = in.p == out.p;
 	Img dst = out;
 	if (alias) {
@@ -324,11 +361,14 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			if (e != hipSuccess)
 				return fail("forward level %d launch failed: %s", j, hipGetErrorString(e));
 			if (detour) {
-				// copy the staged subbands to their place: right half, bottom-left, and
-				// the LL quadrant too when it was written here
-				if (copy_rect(dst, Wd, 0, hdst, Wd, 0, Wo - Wd, Ho) || copy_rect(dst, 0, Hd, hdst, 0, Hd, Wd, Ho - Hd))
+				// copy the staged subbands to their place: right half, bottom-left, and the LL
+				// quadrant too when it was written here.  On the side stream: the deeper levels
+				// only touch the top-left quadrant and run meanwhile.
+				if (side_fork())
 					return 1;
-				if (last && copy_rect(dst, 0, 0, hdst, 0, 0, Wd, Hd))
+				if (copy_rect_on(g.side, dst, Wd, 0, hdst, Wd, 0, Wo - Wd, Ho) || copy_rect_on(g.side, dst, 0, Hd, hdst, 0, Hd, Wd, Ho - Hd))
+					return 1;
+				if (last && copy_rect_on(g.side, dst, 0, 0, hdst, 0, 0, Wd, Hd))
 					return 1;
 			}
 			ll_in = ll_out;
@@ -365,7 +405,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				return 1;
 		}
 	}
-	return 0;
+	return side_join();
 }
 
 // ---- inverse ---------------------------------------------------------------------
@@ -394,6 +434,26 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 	long cur_bstride = src_bstride;
 	int ll_in = -1;         // -1: LL band is in `cur`; else scratch index
 	bool copied = false;
+	// In place with every level fused: the detail subbands of level 1 have to be moved
+	// aside before the final level overwrites them.  Start that copy now, on the side
+	// stream, so that it overlaps the deeper (small) levels.
+	bool aside_early = false;
+	if (src.p == dst.p && J >= 2 && batch == 1) {
+		bool all_fused = true;
+		for (int j = 1; j <= J; j++)
+			all_fused = all_fused && fused_ok(j);
+		if (all_fused) {
+			const int Ws = ge.Wo(1), Hs = ge.Ho(1), Wo = ge.Wo(0), Ho = ge.Ho(0);
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
+				return 1;
+			Img st{(char *)g.stage_img, dst.sx};
+			if (side_fork())
+				return 1;
+			if (copy_rect_on(g.side, st, Ws, 0, src, Ws, 0, Wo - Ws, Ho) || copy_rect_on(g.side, st, 0, Hs, src, 0, Hs, Ws, Ho - Hs))
+				return 1;
+			aside_early = true;
+		}
+	}
 	for (int j = J; j >= 1; j--) {
 		const int Ws = ge.Wo(j), Hs = ge.Ho(j);       // subband sizes (= Mallat offsets)
 		const int Wo = ge.Wo(j - 1), Ho = ge.Ho(j - 1); // produced frame
@@ -429,10 +489,15 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 					if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 						return 1;
 					Img st{(char *)g.stage_img, dst.sx};
-					if (copy_rect(st, Ws, 0, cur, Ws, 0, Wo - Ws, Ho) || copy_rect(st, 0, Hs, cur, 0, Hs, Ws, Ho - Hs))
-						return 1;
-					if (ll_in < 0 && copy_rect(st, 0, 0, cur, 0, 0, Ws, Hs))
-						return 1;
+					if (aside_early) {
+						if (side_join()) // the copy started before the deeper levels
+							return 1;
+					} else {
+						if (copy_rect(st, Ws, 0, cur, Ws, 0, Wo - Ws, Ho) || copy_rect(st, 0, Hs, cur, 0, Hs, Ws, Ho - Hs))
+							return 1;
+						if (ll_in < 0 && copy_rect(st, 0, 0, cur, 0, 0, Ws, Hs))
+							return 1;
+					}
 					a.in_h = st.p;
 					a.h_bstride = 0;
 					if (ll_in < 0)
@@ -489,7 +554,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				return 1;
 		}
 	}
-	return 0;
+	return side_join();
 }
 
 int check_inited()
@@ -826,8 +891,8 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 	if (wavelet < 0 || wavelet > 5 || elem_size((Wavelet)wavelet) != 4)
 		return fail("unknown wavelet %d (batches take the 32-bit wavelets)", wavelet);
 	g_elems_are_32bit = true;
-	if (!src || !dst || !j || batch < 1)
-		return fail("bad argument");
+	if (!src || !dst || !j || batch < 1 || batch > 65535)
+		return fail("bad argument (batch must be 1..65535)");
 	if (!dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
 		return fail("batched transforms take device pointers");
 	if ((stride_x & 3) || stride_x < size_x * 4 || (batch_stride & 3) || batch_stride < (size_t)stride_x * size_y)

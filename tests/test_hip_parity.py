@@ -416,3 +416,45 @@ def test_harness_helpers(dwt):
     assert L.dwt_hip_memcpy_d2h(row.ctypes.data, p.value, 64) == 0
     assert np.array_equal(row, full[16, 16:32])
     d.free()
+
+
+GRAPH_SCRIPT = r"""
+import sys, numpy as np
+import torch                      # first: this process then shares torch's HIP runtime
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+import libdwt_amd as dwt
+from oraclelib import Oracle
+dwt.dwt_util_init()
+n, nb = 1024, 3
+x = torch.rand((nb, n, n), device="cuda"); y = torch.empty_like(x)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    dwt.use_torch_stream()
+    dwt.transform2d_batch("cdf97_s", 0, x, y, n * n * 4, nb, n * 4, n, n, 4)   # warm-up: allocates scratch
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        dwt.use_torch_stream()
+        dwt.transform2d_batch("cdf97_s", 0, x, y, n * n * 4, nb, n * 4, n, n, 4)
+y.zero_(); x.copy_(torch.rand((nb, n, n), device="cuda"))
+g.replay(); torch.cuda.synchronize()
+want = x[1].cpu().numpy().copy()
+Oracle().fwd("cdf97_2f_s", want, 4)
+assert np.array_equal(y[1].cpu().numpy().view(np.uint32), want.view(np.uint32)), "graph replay differs"
+print("graph OK")
+"""
+
+
+def test_hip_graph_capture_replay():
+    """After one warm-up call (workspace allocated) a device-resident transform issues only
+    kernel launches on the caller's stream, so it can be captured into a HIP graph and
+    replayed.  Own process: torch has to be imported before the library so that both use
+    one HIP runtime."""
+    import os
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + GRAPH_SCRIPT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "graph OK" in out.stdout, out.stderr[-2000:]

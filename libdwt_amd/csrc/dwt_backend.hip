@@ -69,6 +69,7 @@ struct Ctx {
 	// options
 	SweepTuning tune;
 	int force_generic = 0;
+	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
 	// profiling
 	int prof_on = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -356,7 +357,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				a.ll_bstride = a.ll_pitch * Hd;
 			}
 			prof_before(j);
-			hipError_t e = launch_fwd_level(w, a, g.tune, g.stream);
+			hipError_t e = launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
 			prof_after(j);
 			if (e != hipSuccess)
 				return fail("forward level %d launch failed: %s", j, hipGetErrorString(e));
@@ -510,7 +511,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				a.out_bstride = a.out_pitch * Ho;
 			}
 			prof_before(j - 1);
-			hipError_t e = launch_inv_level(w, a, g.tune, g.stream);
+			hipError_t e = launch_inv_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
 			prof_after(j - 1);
 			if (e != hipSuccess)
 				return fail("inverse level %d launch failed: %s", j, hipGetErrorString(e));
@@ -674,6 +675,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.ring_inv = value;
 	else if (!strcmp(name, "wave_horiz_inv"))
 		g.tune.wave_horiz_inv = value;
+	else if (!strcmp(name, "fma"))
+		g.fma = value;
 	else if (!strcmp(name, "pipeline"))
 		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else
@@ -703,6 +706,8 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.nt_inv;
 	if (!strcmp(name, "pipeline"))
 		return g.pipeline;
+	if (!strcmp(name, "fma"))
+		return g.fma;
 	return -1;
 }
 

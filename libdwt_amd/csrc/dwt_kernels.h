@@ -6,7 +6,8 @@
 
 namespace dwt {
 
-enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2, kCdf97D = 3, kCdf53D = 4, kCdf97I = 5 };
+enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2, kCdf97D = 3, kCdf53D = 4, kCdf97I = 5,
+	kCdf97SFma = 6 /* internal: float 9/7 with contracted steps, option "fma" */ };
 
 inline int elem_size(Wavelet w) { return (w == kCdf97D || w == kCdf53D) ? 8 : 4; }
 

@@ -122,6 +122,7 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 	case kCdf97D: return line_pass_t<Cdf97D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf53D: return line_pass_t<Cdf53D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf97I: return line_pass_t<Cdf97I>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
+	case kCdf97SFma: break; // the contracted variant exists for the fused sweeps only
 	}
 	return hipErrorInvalidValue;
 }
@@ -949,7 +950,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	if (a.interleaved) {
 		// 3-D path: float 9/7 only; always 4 columns per lane so that each row leaves the
 		// wave as ONE contiguous 16 B/lane store (two strided stores per row cost 40 %)
-		if constexpr (std::is_same<W, Cdf97S>::value) {
+		if constexpr (std::is_base_of<Cdf97S, W>::value) {
 			g.out_vec_ok = aligned16(a.out_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
 			if (tt.ring == 16)
 				return fwd_launch<W, 4, 16, 3, true>(a, g, grid, waves, s);
@@ -1008,7 +1009,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
-		if constexpr (std::is_same<W, Cdf97S>::value) {
+		if constexpr (std::is_base_of<Cdf97S, W>::value) {
 			g.in_vec_ok = aligned16(a.in_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
 			return cpt == 8 ? inv_launch<W, 8, 8, 0, true>(a, g, grid, waves, s) : inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
 		} else {
@@ -1025,6 +1026,7 @@ hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning 
 	case kCdf53I: return fwd_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return fwd_level_t<Cdf53S>(a, t, s);
 	case kCdf97I: return fwd_level_t<Cdf97I>(a, t, s);
+	case kCdf97SFma: return fwd_level_t<Cdf97SFma>(a, t, s);
 	default: break; // the double-precision drivers run on the line-pass kernels
 	}
 	return hipErrorInvalidValue;
@@ -1037,6 +1039,7 @@ hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning 
 	case kCdf53I: return inv_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return inv_level_t<Cdf53S>(a, t, s);
 	case kCdf97I: return inv_level_t<Cdf97I>(a, t, s);
+	case kCdf97SFma: return inv_level_t<Cdf97SFma>(a, t, s);
 	default: break;
 	}
 	return hipErrorInvalidValue;

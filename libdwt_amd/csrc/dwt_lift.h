@@ -49,6 +49,14 @@ struct Cdf97S {
 	static __device__ __forceinline__ T inv_single(T v) { return v * (float)(1 / 1.1496043988602); }
 };
 
+// Same wavelet with each lifting step contracted to one fused multiply-add.  NOT the
+// reference's rounding (it has no FMA): results differ in the last bits, well inside the
+// 1e-5 relative tolerance of the north star.  Opt-in only (option "fma").
+struct Cdf97SFma : Cdf97S {
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r) { return __builtin_fmaf(fc(s), l + r, c); }
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r) { return __builtin_fmaf(ic(s), l + r, c); }
+};
+
 struct Cdf53I {
 	using T = int;
 	static constexpr int K = 2;

@@ -458,3 +458,26 @@ def test_hip_graph_capture_replay():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + GRAPH_SCRIPT], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "graph OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_fma_option_within_tolerance(dwt, oracle):
+    """Option "fma" contracts the float 9/7 steps: not bit-identical, but inside the 1e-5
+    relative tolerance the north star states for float CDF 9/7."""
+    n = 2048
+    img = np.random.default_rng(77).random((n, n), dtype=np.float32)
+    want = img.copy()
+    oracle.fwd("cdf97_2f_s", want, 5)
+    try:
+        dwt.set_option("fma", 1)
+        a = dwt.DeviceImage(n, n).upload(img)
+        b = dwt.DeviceImage(n, n)
+        dwt.dwt_cdf97_2f_s2(a.ptr, b.ptr, n * 4, 4, n, n, n, n, 5)
+        got = b.download(np.float32)
+        assert not np.array_equal(bits(got), bits(want))  # it really is a different rounding
+        assert rel_err(got, want) <= 1e-5
+        dwt.dwt_cdf97_2i_s2(b.ptr, a.ptr, n * 4, 4, n, n, n, n, 5)
+        assert np.abs(a.download(np.float32) - img).max() < 1e-4
+        a.free()
+        b.free()
+    finally:
+        dwt.set_option("fma", 0)

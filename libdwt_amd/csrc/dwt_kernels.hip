@@ -266,7 +266,9 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	constexpr int kDmaPerIter = 2 * (CPT / 4 + 1); // fewest DMA instructions an iteration issues
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int bid = tile_block_id(g.swz);
 	int tx, ty;
 	if (g.wave_horiz) {
@@ -519,7 +521,9 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	constexpr int kDmaPerIter = 2 * (kDmaMain + 1);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int bid = tile_block_id(g.swz);
 	int tx, ty;
 	if (g.wave_horiz) {
@@ -1063,7 +1067,9 @@ __global__ __launch_bounds__(256) void k_fwd2_sweep(Fwd2LevelArgs a, Fwd2Geom g)
 	constexpr int kWaveLds = RING * RS * 4 + kLLRing * 1024;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int bid = tile_block_id(g.swz);
 	const int ntxb = (g.ntx + nwv - 1) / nwv;
 	const int tx = (bid % ntxb) * nwv + wv;
@@ -1440,7 +1446,9 @@ __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, lon
 {
 	using W = Cdf97S;
 	constexpr int K = 4, CPT = 4;
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int c = ((blockIdx.x * nwv + wv) * 64 + lane) * CPT;
 	const int y = blockIdx.y;
 	const int Zd = (nz + 1) >> 1;

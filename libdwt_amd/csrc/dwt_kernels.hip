@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 {
 	using T = typename W::T;
 	constexpr int K = W::K;
-	constexpr int kRing = RING;           // ring rows per wave (power of two)
+	constexpr int kRing = RING;           // ring rows per wave (any even number)
 	constexpr int kAhead = kRing / 2 - 1; // sweep iterations of DMA lookahead (2 rows each)
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
 	constexpr bool kNtStore = (NT & 1) != 0;
@@ -305,11 +305,12 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 		colmap[i] = reflect(c0 + i * 64 + lane, a.W);
 	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
 
+	int islot = 0, rslot = 0; // ring slots of the next rows to fill / to consume
 	auto issue = [&](int it) {
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
 			const int r = reflect(2 * (q0 + it) - 1 + rr, a.H);
-			char *lrow = ring + (size_t)((2 * it + rr) & (kRing - 1)) * RS * 4;
+			char *lrow = ring + (size_t)(islot + rr) * RS * 4;
 			const T *grow = in + (long)r * a.in_pitch;
 			if (main16) {
 #pragma unroll
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			if (lane < 8)
 				dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
 		}
+		islot = islot + 2 >= kRing ? 0 : islot + 2;
 	};
 
 	T st[K][CPT];
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 		T row[2][CPT];
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
-			const unsigned base = ring_off + (unsigned)((2 * it + rr) & (kRing - 1)) * RS * 4;
+			const unsigned base = ring_off + (unsigned)(rslot + rr) * RS * 4;
 			const unsigned own = base + lane * CPT * 4;
 			const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
 			const unsigned ra = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
@@ -398,6 +400,8 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			for (int v = 0; v < CPT; v++)
 				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
 		}
+
+		rslot = rslot + 2 >= kRing ? 0 : rslot + 2;
 
 		// vertical pass: streaming lifting, state in registers
 		T lo[CPT], hi[CPT];
@@ -900,6 +904,13 @@ static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid,
 	if ((nt & 8) && nt != 15 && nt != 8)
 		nt = 15;
 #define DWT_FWD_CASE(R, N) case N: return fwd_launch<W, CPT, R, N>(a, g, grid, waves, s)
+	if (nt == 7 && (t.ring == 10 || t.ring == 12 || t.ring == 14)) {
+		if (t.ring == 10)
+			return fwd_launch<W, CPT, 10, 7>(a, g, grid, waves, s);
+		if (t.ring == 12)
+			return fwd_launch<W, CPT, 12, 7>(a, g, grid, waves, s);
+		return fwd_launch<W, CPT, 14, 7>(a, g, grid, waves, s);
+	}
 	if (t.ring == 16) {
 		switch (nt) {
 			DWT_FWD_CASE(16, 0); DWT_FWD_CASE(16, 1); DWT_FWD_CASE(16, 2); DWT_FWD_CASE(16, 3);
@@ -941,10 +952,10 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	// side-by-side waves beat 8 waves/CU with an 8-row ring (5.5 -> 6.0 TB/s at level 0);
 	// smaller launches prefer more resident waves.
 	SweepTuning tt = t;
-	if (tt.ring != 8 && tt.ring != 16)
+	if (tt.ring != 8 && tt.ring != 16 && tt.ring != 10 && tt.ring != 12 && tt.ring != 14)
 		tt.ring = (cpt == 8 && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
 	if (tt.wave_horiz < 0)
-		tt.wave_horiz = tt.ring == 16;
+		tt.wave_horiz = tt.ring >= 10;
 	g.wave_horiz = tt.wave_horiz;
 	dim3 grid;
 	if (g.wave_horiz)

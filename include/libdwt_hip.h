@@ -78,6 +78,13 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z,
 	int size_x, int size_y, int size_z, int levels);
 
+/* Device-side twins of dwt_util_conv_show_{s,i} (src/libdwt.c:21075, 21020) and
+ * dwt_util_compare_{s,i} (:1593, :1531) for images that stay in HBM between a forward and
+ * an inverse transform.  compare returns 0 equal / 1 differ (float: 1e-3 absolute, NaN or
+ * Inf => differ) / -1 error. */
+int dwt_hip_conv_show(int is_int, const void *src, void *dst, int stride_x, int stride_y, int size_x, int size_y);
+int dwt_hip_compare(int is_int, const void *ptr1, const void *ptr2, int stride_x, int stride_y, int size_x, int size_y);
+
 /* Device memory helpers so that C callers need no HIP headers. */
 void *dwt_hip_malloc(size_t bytes);
 void dwt_hip_free(void *dev_ptr);

@@ -991,6 +991,48 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 	               : forward2d((Wavelet)wavelet, s, d, ge, j, 0, 0, batch, (long)batch_stride, (long)batch_stride);
 }
 
+int dwt_hip_conv_show(int is_int, const void *src, void *dst, int stride_x, int stride_y, int size_x, int size_y)
+{
+	if (check_inited())
+		return 1;
+	if (!dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
+		return fail("dwt_hip_conv_show takes device images (host images: dwt_util_conv_show_s/_i)");
+	if (stride_y != 4 || (stride_x & 3))
+		return fail("device images need stride_y == 4 and stride_x a multiple of 4");
+	hipError_t e = launch_conv_show(is_int != 0, src, dst, stride_x, size_x, size_y, g.stream);
+	if (e != hipSuccess)
+		return fail("conv_show launch failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
+int dwt_hip_compare(int is_int, const void *ptr1, const void *ptr2, int stride_x, int stride_y, int size_x, int size_y)
+{
+	if (check_inited())
+		return -1;
+	if (!dwt_hip_is_device_pointer(ptr1) || !dwt_hip_is_device_pointer(ptr2)) {
+		fail("dwt_hip_compare takes device images (host images: dwt_util_compare_s/_i)");
+		return -1;
+	}
+	if (stride_y != 4 || (stride_x & 3)) {
+		fail("device images need stride_y == 4 and stride_x a multiple of 4");
+		return -1;
+	}
+	static unsigned *counter = nullptr;
+	if (!counter && hipMalloc((void **)&counter, sizeof(unsigned)) != hipSuccess) {
+		fail("hipMalloc failed");
+		return -1;
+	}
+	unsigned host = 0;
+	if (hipMemsetAsync(counter, 0, sizeof(unsigned), g.stream) != hipSuccess ||
+		launch_compare(is_int != 0, ptr1, ptr2, stride_x, size_x, size_y, counter, g.stream) != hipSuccess ||
+		hipMemcpyAsync(&host, counter, sizeof(unsigned), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+		hipStreamSynchronize(g.stream) != hipSuccess) {
+		fail("compare failed: %s", hipGetErrorString(hipGetLastError()));
+		return -1;
+	}
+	return host ? 1 : 0;
+}
+
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
 {
 	if (check_inited())

@@ -96,4 +96,8 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
 	int nx, int ny, int nz, hipStream_t s);
 
+// device-side view helpers: pitch in BYTES, 4-byte elements
+hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s);
+hipError_t launch_compare(bool is_int, const void *p1, const void *p2, long pitch, int w, int h, unsigned *result, hipStream_t s);
+
 } // namespace dwt

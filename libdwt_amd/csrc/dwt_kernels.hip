@@ -1611,3 +1611,81 @@ hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz
 bool have_fused_inverse(Wavelet) { return true; }
 
 } // namespace dwt
+
+// ---------------------------------------------------------------------------------
+// 4. device-side view helpers: conv_show and compare on images
+//    that stay in HBM between the forward and the inverse transform
+// ---------------------------------------------------------------------------------
+namespace dwt {
+
+// dwt_util_conv_show_s (src/libdwt.c:21075-21117): log(1 + |c|*100) / 10 with the log
+// taken in double as log_i_s does (:21010); non-finite results become 0.
+__global__ __launch_bounds__(256) void k_conv_show_s(const char *__restrict__ src, char *__restrict__ dst, long pitch, int w, int h)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= w || y >= h)
+		return;
+	const float c = *(const float *)(src + (long)y * pitch + (long)x * 4);
+	float t = (float)log((double)(1.f + fabsf(c) * 100.f));
+	t /= 10.f;
+	if (!isfinite(t))
+		t = 0.f;
+	*(float *)(dst + (long)y * pitch + (long)x * 4) = t;
+}
+
+// dwt_util_conv_show_i (src/libdwt.c:21020-21044): |c|
+__global__ __launch_bounds__(256) void k_conv_show_i(const char *__restrict__ src, char *__restrict__ dst, long pitch, int w, int h)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= w || y >= h)
+		return;
+	const int c = *(const int *)(src + (long)y * pitch + (long)x * 4);
+	*(int *)(dst + (long)y * pitch + (long)x * 4) = c < 0 ? -c : c;
+}
+
+// dwt_util_compare_s / _i (src/libdwt.c:1593-1620, 1531-1558): count of differing
+// elements (float: |a-b| > 1e-3 or any NaN/Inf; int: a != b) accumulated in *result
+template <bool IS_INT>
+__global__ __launch_bounds__(256) void k_compare(const char *__restrict__ p1, const char *__restrict__ p2, long pitch, int w, int h, unsigned *result)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	bool differ = false;
+	if (x < w && y < h) {
+		if (IS_INT) {
+			differ = *(const int *)(p1 + (long)y * pitch + (long)x * 4) != *(const int *)(p2 + (long)y * pitch + (long)x * 4);
+		} else {
+			const float a = *(const float *)(p1 + (long)y * pitch + (long)x * 4);
+			const float b = *(const float *)(p2 + (long)y * pitch + (long)x * 4);
+			differ = isnan(a) || isinf(a) || isnan(b) || isinf(b) || fabsf(a - b) > 1e-3f;
+		}
+	}
+	const unsigned long long m = __ballot(differ);
+	if ((threadIdx.x & 63) == 0 && m)
+		atomicAdd(result, (unsigned)__popcll(m));
+}
+
+hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s)
+{
+	if (w <= 0 || h <= 0)
+		return hipSuccess;
+	dim3 grid((w + 255) / 256, h);
+	if (is_int)
+		k_conv_show_i<<<grid, 256, 0, s>>>((const char *)src, (char *)dst, pitch, w, h);
+	else
+		k_conv_show_s<<<grid, 256, 0, s>>>((const char *)src, (char *)dst, pitch, w, h);
+	return hipGetLastError();
+}
+
+hipError_t launch_compare(bool is_int, const void *p1, const void *p2, long pitch, int w, int h, unsigned *result, hipStream_t s)
+{
+	if (w <= 0 || h <= 0)
+		return hipSuccess;
+	dim3 grid((w + 255) / 256, h);
+	if (is_int)
+		k_compare<true><<<grid, 256, 0, s>>>((const char *)p1, (const char *)p2, pitch, w, h, result);
+	else
+		k_compare<false><<<grid, 256, 0, s>>>((const char *)p1, (const char *)p2, pitch, w, h, result);
+	return hipGetLastError();
+}
+
+} // namespace dwt

@@ -528,3 +528,51 @@ def test_two_level_fused_sweep(dwt, oracle, wname):
         dwt.lib.dwt_hip_free(dst)
     finally:
         dwt.set_option("fuse2", 0)
+
+
+def test_device_side_conv_show_and_compare(dwt):
+    """dwt_hip_conv_show / dwt_hip_compare: the view and the comparison of examples/simple
+    (src/libdwt.c:21075, 1593) on images that stay in HBM."""
+    import ctypes as C
+
+    L = dwt.lib
+    L.dwt_hip_conv_show.argtypes = [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    L.dwt_hip_conv_show.restype = C.c_int
+    L.dwt_hip_compare.argtypes = [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    L.dwt_hip_compare.restype = C.c_int
+    h, w = 300, 500
+    rng = np.random.default_rng(2)
+    img = (rng.random((h, w), dtype=np.float32) - 0.5) * 8
+    a = dwt.DeviceImage(h, w).upload(img)
+    b = dwt.DeviceImage(h, w)
+    assert L.dwt_hip_conv_show(0, a.ptr, b.ptr, w * 4, 4, w, h) == 0
+    host = np.zeros_like(img)
+    L.dwt_util_conv_show_s(img.ctypes.data, host.ctypes.data, w * 4, 4, w, h)
+    assert np.allclose(b.download(np.float32), host, rtol=2e-6, atol=1e-7)
+    ii = rng.integers(-1000, 1000, size=(h, w), dtype=np.int32)
+    a.upload(ii)
+    assert L.dwt_hip_conv_show(1, a.ptr, b.ptr, w * 4, 4, w, h) == 0
+    assert np.array_equal(b.download(np.int32), np.abs(ii))
+    # compare
+    a.upload(img)
+    b.upload(img)
+    assert L.dwt_hip_compare(0, a.ptr, b.ptr, w * 4, 4, w, h) == 0
+    img2 = img.copy()
+    img2[123, 77] += 5e-4
+    b.upload(img2)
+    assert L.dwt_hip_compare(0, a.ptr, b.ptr, w * 4, 4, w, h) == 0
+    img2[123, 77] += 1e-2
+    b.upload(img2)
+    assert L.dwt_hip_compare(0, a.ptr, b.ptr, w * 4, 4, w, h) == 1
+    img2 = img.copy()
+    img2[0, 0] = np.nan
+    b.upload(img2)
+    assert L.dwt_hip_compare(0, b.ptr, b.ptr, w * 4, 4, w, h) == 1
+    a.upload(ii)
+    b.upload(ii)
+    assert L.dwt_hip_compare(1, a.ptr, b.ptr, w * 4, 4, w, h) == 0
+    ii[299, 499] += 1
+    b.upload(ii)
+    assert L.dwt_hip_compare(1, a.ptr, b.ptr, w * 4, 4, w, h) == 1
+    a.free()
+    b.free()

@@ -15,6 +15,11 @@
  * crosses PCIe).  The double-precision wavelets run on the exact line-pass kernels
  * (two passes per level); the fused sweeps exist for the 32-bit types.
  *
+ * Threading: one context per process, not reentrant -- like the reference, whose 2-D
+ * drivers mutate process globals (src/libdwt.c:12839-12862).  Calls are asynchronous for
+ * device pointers (stream-ordered on the stream given to dwt_hip_set_stream) and
+ * synchronous for host pointers.
+ *
  * Error rule: every int function returns 0 on success and non-zero on failure with
  * a message retrievable by dwt_hip_last_error().  There is NO CPU fallback: without
  * a usable gfx950 device every transform entry fails.

@@ -576,3 +576,22 @@ def test_device_side_conv_show_and_compare(dwt):
     assert L.dwt_hip_compare(1, a.ptr, b.ptr, w * 4, 4, w, h) == 1
     a.free()
     b.free()
+
+
+def test_finish_releases_and_context_stays_usable(dwt, oracle):
+    """dwt_util_finish frees the workspace (src/libdwt.c:19186 is the release hook); a later
+    call re-allocates it.  init is idempotent."""
+    img = np.random.default_rng(9).random((256, 256), dtype=np.float32)
+    want = img.copy()
+    oracle.fwd("cdf97_2f_s", want, 3)
+    for _ in range(2):
+        dwt.dwt_util_init()
+        got = img.copy()
+        dwt.dwt_cdf97_2f_s(got, 1024, 4, 256, 256, 256, 256, 3)
+        assert np.array_equal(bits(got), bits(want))
+        d = dwt.DeviceImage(256, 256).upload(img)
+        dwt.dwt_cdf97_2f_s(d.ptr, 1024, 4, 256, 256, 256, 256, 3)
+        assert np.array_equal(bits(d.download(np.float32)), bits(want))
+        d.free()
+        dwt.dwt_util_finish()
+    dwt.dwt_util_init()

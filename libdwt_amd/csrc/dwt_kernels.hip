@@ -306,10 +306,12 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
 
 	int islot = 0, rslot = 0; // ring slots of the next rows to fill / to consume
+	const bool tall = a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
 	auto issue = [&](int it) {
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
-			const int r = reflect(2 * (q0 + it) - 1 + rr, a.H);
+			const int ri = 2 * (q0 + it) - 1 + rr;
+			const int r = tall ? reflect1(ri, a.H) : reflect(ri, a.H);
 			char *lrow = ring + (size_t)(islot + rr) * RS * 4;
 			const T *grow = in + (long)r * a.in_pitch;
 			if (main16) {

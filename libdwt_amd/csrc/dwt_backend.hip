@@ -68,6 +68,7 @@ struct Ctx {
 	int pipeline = 0; // 0: one launch per level for the whole batch; n>=2: n lanes
 	// options
 	SweepTuning tune;
+	VolTuning vol;
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
 	// profiling
@@ -723,6 +724,12 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fma = value;
 	else if (!strcmp(name, "fuse2"))
 		g.tune.fuse2 = value;
+	else if (!strcmp(name, "vol_cpt"))
+		g.vol.cpt = value;
+	else if (!strcmp(name, "vol_tile_pairs"))
+		g.vol.tile_pairs = value;
+	else if (!strcmp(name, "vol_nt"))
+		g.vol.nt = value;
 	else if (!strcmp(name, "pipeline"))
 		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else
@@ -756,6 +763,12 @@ int dwt_hip_get_option(const char *name)
 		return g.fma;
 	if (!strcmp(name, "fuse2"))
 		return g.tune.fuse2;
+	if (!strcmp(name, "vol_cpt"))
+		return g.vol.cpt;
+	if (!strcmp(name, "vol_tile_pairs"))
+		return g.vol.tile_pairs;
+	if (!strcmp(name, "vol_nt"))
+		return g.vol.nt;
 	return -1;
 }
 
@@ -1046,71 +1059,91 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 	// every level needs at least 2 samples per axis (the reference asserts >= 5, dwt-simple.c:2172)
 	if (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2)
 		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
-	float *v = (float *)vol;
-	const long vsy = (long)stride_y / 4, vsz = (long)stride_z / 4;
-
-	// scratch: S (pass-to-pass buffer) and, for levels >= 1, the packed lattice P
+	// scratch: S (pass-to-pass buffer) and, for levels >= 1, dense copies P[j] of the
+	// level-j lattice (even-even-even samples of level j-1), all carved from one buffer
 	const long s_sy = align_up(nx, 4), s_sz = s_sy * ny;
 	if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
 		return 1;
 	float *S = (float *)g.stage_img;
-	float *P = nullptr;
-	long p_sy = 0, p_sz = 0;
-	if (levels > 1) {
-		const int px = ceil_div_pow2(nx, 1), py = ceil_div_pow2(ny, 1), pz = ceil_div_pow2(nz, 1);
-		p_sy = align_up(px, 4);
-		p_sz = p_sy * py;
-		if (grow(&g.host_a, &g.host_a_bytes, (size_t)p_sz * pz * 4))
-			return 1;
-		P = (float *)g.host_a;
+	constexpr int kMaxLevels = 24;
+	if (levels > kMaxLevels)
+		return fail("too many levels");
+	struct Lvl { float *p; long sy, sz; int lx, ly, lz; } L[kMaxLevels];
+	L[0] = {(float *)vol, (long)stride_y / 4, (long)stride_z / 4, nx, ny, nz};
+	size_t p_total = 0;
+	for (int j = 1; j < levels; j++) {
+		L[j].lx = ceil_div_pow2(nx, j); L[j].ly = ceil_div_pow2(ny, j); L[j].lz = ceil_div_pow2(nz, j);
+		L[j].sy = align_up(L[j].lx, 4);
+		L[j].sz = L[j].sy * L[j].ly;
+		p_total += (size_t)L[j].sz * L[j].lz;
 	}
+	if (levels > 1) {
+		if (grow(&g.host_a, &g.host_a_bytes, p_total * 4))
+			return 1;
+		float *p = (float *)g.host_a;
+		for (int j = 1; j < levels; j++) {
+			L[j].p = p;
+			p += (size_t)L[j].sz * L[j].lz;
+		}
+	}
+	for (int j = 0; j < levels; j++)
+		if (L[j].lz > 65535 || L[j].ly > 65535)
+			return fail("volume too large for the launch grid");
 
-	auto one_level = [&](float *buf, long bsy, long bsz, int lx, int ly, int lz) -> int {
+	auto one_level = [&](const Lvl &b, const Lvl *next) -> int {
 		// x then y fused per slice, then z (src/volume-dwt.c:677-725; inverse :1115-1163)
 		hipError_t e;
 		if (!inverse) {
 			FwdLevelArgs a;
-			a.in = buf; a.in_pitch = bsy; a.in_bstride = bsz;
+			a.in = b.p; a.in_pitch = b.sy; a.in_bstride = b.sz;
 			a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
 			a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
-			a.W = lx; a.H = ly; a.batch = lz; a.interleaved = 1;
+			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
 			e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
 		} else {
 			InvLevelArgs a;
-			a.in_ll = buf; a.ll_pitch = bsy; a.ll_bstride = bsz;
-			a.in_h = buf; a.h_pitch = bsy; a.h_bstride = bsz;
+			a.in_ll = b.p; a.ll_pitch = b.sy; a.ll_bstride = b.sz;
+			a.in_h = b.p; a.h_pitch = b.sy; a.h_bstride = b.sz;
 			a.out = S; a.out_pitch = s_sy; a.out_bstride = s_sz;
-			a.W = lx; a.H = ly; a.batch = lz; a.interleaved = 1;
+			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
 			e = launch_inv_level(kCdf97S, a, g.tune, g.stream);
 		}
 		if (e != hipSuccess)
 			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
-		e = launch_vol_z(inverse != 0, S, s_sy, s_sz, buf, bsy, bsz, lx, ly, lz, g.stream);
+		// forward: the z pass also writes the next level's input densely (no lattice gather)
+		e = launch_vol_z(inverse != 0, S, s_sy, s_sz, b.p, b.sy, b.sz, b.lx, b.ly, b.lz, g.vol, g.stream,
+			next ? next->p : nullptr, next ? next->sy : 0, next ? next->sz : 0);
 		if (e != hipSuccess)
 			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
 		return 0;
 	};
+	// level j lives on the stride-2 lattice (even-even-even samples) of level j-1
+	auto lattice = [&](int j, bool pack) -> int {
+		const Lvl &c = L[j], &par = L[j - 1];
+		hipError_t e = pack
+			? launch_lattice_copy(par.p, 2, par.sy * 2, par.sz * 2, c.p, 1, c.sy, c.sz, c.lx, c.ly, c.lz, g.stream)
+			: launch_lattice_copy(c.p, 1, c.sy, c.sz, par.p, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice %s failed: %s", pack ? "pack" : "unpack", hipGetErrorString(e));
+		return 0;
+	};
 
-	for (int step = 0; step < levels; step++) {
-		const int j = inverse ? levels - 1 - step : step;
-		const int lx = ceil_div_pow2(nx, j), ly = ceil_div_pow2(ny, j), lz = ceil_div_pow2(nz, j);
-		if (lz > 65535 || ly > 65535)
-			return fail("volume too large for the launch grid");
-		if (j == 0) {
-			if (one_level(v, vsy, vsz, lx, ly, lz))
+	if (!inverse) {
+		for (int j = 0; j < levels; j++)
+			if (one_level(L[j], j + 1 < levels ? &L[j + 1] : nullptr))
 				return 1;
-		} else {
-			// level j lives on the lattice of stride 2^j (even-even-even samples): pack it,
-			// transform the dense copy, put it back
-			const long st = 1L << j;
-			hipError_t e = launch_lattice_copy(v, st, vsy * st, vsz * st, P, 1, p_sy, p_sz, lx, ly, lz, g.stream);
-			if (e != hipSuccess)
-				return fail("lattice pack failed: %s", hipGetErrorString(e));
-			if (one_level(P, p_sy, p_sz, lx, ly, lz))
+		for (int j = levels - 1; j >= 1; j--)
+			if (lattice(j, false))
 				return 1;
-			e = launch_lattice_copy(P, 1, p_sy, p_sz, v, st, vsy * st, vsz * st, lx, ly, lz, g.stream);
-			if (e != hipSuccess)
-				return fail("lattice unpack failed: %s", hipGetErrorString(e));
+	} else {
+		for (int j = 1; j < levels; j++)
+			if (lattice(j, true))
+				return 1;
+		for (int j = levels - 1; j >= 0; j--) {
+			if (one_level(L[j], nullptr))
+				return 1;
+			if (j >= 1 && lattice(j, false))
+				return 1;
 		}
 	}
 	return 0;

@@ -86,10 +86,18 @@ bool have_fused_inverse(Wavelet w);
 hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
 	int n_lines, int N, int hoff, bool lanes_along_lines, hipStream_t s);
 
+// z-pass knobs of the 3-D path (measured defaults; options vol_cpt / vol_tile_pairs / vol_nt)
+struct VolTuning {
+	int cpt = 8;        // columns per lane: 4 or 8 (two groups of 4, 256 columns apart; +4 % at 1024^3)
+	int tile_pairs = 0; // slice pairs per wave; 0 = choose from the volume depth
+	int nt = 0;         // bit 0 non-temporal stores, bit 1 non-temporal loads
+};
+
 // z pass of the 3-D path: CDF 9/7 float along the slice axis of an interleaved volume,
-// out of place (in != out), x dense; strides in ELEMENTS.
+// out of place (in != out), x dense; strides in ELEMENTS.  Forward only: when `lll` is set the
+// even-x/even-y/even-z samples (the next level's input) are also written densely there.
 hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
-	int nx, int ny, int nz, hipStream_t s);
+	int nx, int ny, int nz, const VolTuning &vt, hipStream_t s, float *lll = nullptr, long lll_sy = 0, long lll_sz = 0);
 
 // Strided 3-D copy (lattice pack/unpack for the levels >= 1 of the 3-D path);
 // strides in ELEMENTS, including the x strides.

@@ -853,7 +853,9 @@ static int pick_cpt(const SweepTuning &t, int W, bool inverse)
 	// take the narrower tile so that more waves share the work.
 	if (inverse)
 		return 4;
-	return W >= 1024 ? 8 : 4;
+	// (below 2048 columns 8/lane leaves fewer than 4 tiles per row: a workgroup of four
+	// side-by-side waves would be half idle; measured 4.15 vs 4.85 TB/s on 1024 x 1024^2)
+	return W >= 2048 ? 8 : 4;
 }
 
 static int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batch, bool inverse = false)
@@ -955,7 +957,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	// smaller launches prefer more resident waves.
 	SweepTuning tt = t;
 	if (tt.ring != 8 && tt.ring != 16 && tt.ring != 10 && tt.ring != 12 && tt.ring != 14)
-		tt.ring = (cpt == 8 && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
+		tt.ring = (g.ntx >= waves && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
 	if (tt.wave_horiz < 0)
 		tt.wave_horiz = tt.ring >= 10;
 	g.wave_horiz = tt.wave_horiz;
@@ -1453,16 +1455,19 @@ hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning 
 // each access is a contiguous 1 KiB row segment).  Same streaming recurrences as the
 // vertical pass of the 2-D sweeps; out of place, because the symmetric extension at
 // the far end re-reads slices the sweep has already produced.
-template <bool INV>
+template <bool INV, int CPT, int NT>
 __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, long in_sy, long in_sz,
-	float *__restrict__ out, long out_sy, long out_sz, int nx, int ny, int nz, int tile_pairs, int vec_ok)
+	float *__restrict__ out, long out_sy, long out_sz, int nx, int ny, int nz, int tile_pairs, int vec_ok,
+	float *__restrict__ lll, long lll_sy, long lll_sz)
 {
 	using W = Cdf97S;
-	constexpr int K = 4, CPT = 4;
+	constexpr int K = 4, NV = CPT / 4;
 	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
 	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int c = ((blockIdx.x * nwv + wv) * 64 + lane) * CPT;
+	// a lane owns NV groups of 4 columns, 256 columns apart: every load/store instruction
+	// of the wave is one contiguous 1 KiB segment
+	const int c = (blockIdx.x * nwv + wv) * 64 * CPT + lane * 4;
 	const int y = blockIdx.y;
 	const int Zd = (nz + 1) >> 1;
 	const int A = blockIdx.z * tile_pairs;
@@ -1471,32 +1476,44 @@ __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, lon
 	const int B = min(A + tile_pairs, Zd);
 	const int n_iter = (B - A) + K;
 	const int q0 = A - K / 2;
-	const bool vec = vec_ok && (c + CPT <= nx);
+	const bool vec = vec_ok && (c + 256 * (NV - 1) + 4 <= nx);
 	const float *src = in + (long)y * in_sy + c;
 	float *dst = out + (long)y * out_sy + c;
 
 	auto load = [&](int slice, float (&v)[CPT]) {
 		const float *p = src + (long)reflect(slice, nz) * in_sz;
 		if (vec) {
-			const u4 t = *(const u4 *)p;
 #pragma unroll
-			for (int e = 0; e < CPT; e++)
-				v[e] = from_bits<float>(t[e]);
+			for (int g = 0; g < NV; g++) {
+				const u4 t = (NT & 2) ? __builtin_nontemporal_load((const u4 *)(p + 256 * g)) : *(const u4 *)(p + 256 * g);
+#pragma unroll
+				for (int e = 0; e < 4; e++)
+					v[4 * g + e] = from_bits<float>(t[e]);
+			}
 		} else {
 #pragma unroll
-			for (int e = 0; e < CPT; e++)
-				v[e] = (c + e < nx) ? p[e] : 0.f;
+			for (int e = 0; e < CPT; e++) {
+				const int x = c + 256 * (e >> 2) + (e & 3);
+				v[e] = (x < nx) ? p[256 * (e >> 2) + (e & 3)] : 0.f;
+			}
 		}
 	};
 	auto store = [&](int slice, const float (&v)[CPT]) {
 		float *p = dst + (long)slice * out_sz;
 		if (vec) {
-			*(u4 *)p = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
+#pragma unroll
+			for (int g = 0; g < NV; g++) {
+				const u4 t = u4{to_bits(v[4 * g]), to_bits(v[4 * g + 1]), to_bits(v[4 * g + 2]), to_bits(v[4 * g + 3])};
+				if (NT & 1)
+					__builtin_nontemporal_store(t, (u4 *)(p + 256 * g));
+				else
+					*(u4 *)(p + 256 * g) = t;
+			}
 		} else {
 #pragma unroll
 			for (int e = 0; e < CPT; e++)
-				if (c + e < nx)
-					p[e] = v[e];
+				if (c + 256 * (e >> 2) + (e & 3) < nx)
+					p[256 * (e >> 2) + (e & 3)] = v[e];
 		}
 	};
 
@@ -1558,6 +1575,22 @@ __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, lon
 				store(2 * k, o0);
 				if (2 * k + 1 < nz)
 					store(2 * k + 1, o1);
+				// forward multi-level: the next level's input (even x, even y, even z = LLL)
+				// also goes out densely, so that no lattice gather is needed
+				if (lll && !(y & 1)) {
+					float *p = lll + (long)k * lll_sz + (long)(y >> 1) * lll_sy + (c >> 1);
+#pragma unroll
+					for (int g = 0; g < NV; g++) {
+						if (vec) {
+							*(u2 *)(p + 128 * g) = u2{to_bits(o0[4 * g]), to_bits(o0[4 * g + 2])};
+						} else {
+							if (c + 256 * g < nx)
+								p[128 * g] = o0[4 * g];
+							if (c + 256 * g + 2 < nx)
+								p[128 * g + 1] = o0[4 * g + 2];
+						}
+					}
+				}
 			}
 		} else {
 			const int pe = q - 1, po = q - 2;
@@ -1569,25 +1602,49 @@ __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, lon
 	}
 }
 
-hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
-	int nx, int ny, int nz, hipStream_t s)
+template <bool INV, int CPT>
+static void vol_z_nt(int nt, dim3 grid, int threads, hipStream_t s, const float *in, long in_sy, long in_sz, float *out,
+	long out_sy, long out_sz, int nx, int ny, int nz, int tp, int vec_ok, float *lll, long lll_sy, long lll_sz)
 {
-	if (nx < 1 || ny < 1 || nz < 2 || ny > 65535)
+	switch (nt & 3) {
+	case 0: k_vol_z<INV, CPT, 0><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	case 1: k_vol_z<INV, CPT, 1><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	case 2: k_vol_z<INV, CPT, 2><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	default: k_vol_z<INV, CPT, 3><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	}
+}
+
+hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
+	int nx, int ny, int nz, const VolTuning &vt, hipStream_t s, float *lll, long lll_sy, long lll_sz)
+{
+	if (nx < 1 || ny < 1 || nz < 2 || ny > 65535 || (lll && (inverse || lll_sy % 2 || lll_sz % 2 || ((uintptr_t)lll & 7))))
 		return hipErrorInvalidValue;
 	const int Zd = (nz + 1) / 2;
-	const int ntx = (nx + 255) / 256;
+	const int cpt = (vt.cpt == 8 && nx >= 512) ? 8 : 4;
+	const int ntx = (nx + 64 * cpt - 1) / (64 * cpt);
 	// long z lines: split them so that at least ~2048 waves exist
 	int tp = 64;
 	while (tp > 8 && (long)ntx * ny * ((Zd + tp - 1) / tp) < 2048)
 		tp >>= 1;
+	if (vt.tile_pairs >= 4)
+		tp = vt.tile_pairs;
 	const int nzt = (Zd + tp - 1) / tp;
+	if (nzt > 65535)
+		return hipErrorInvalidValue;
 	const int waves = ntx >= 4 ? 4 : ntx;
 	dim3 grid((ntx + waves - 1) / waves, ny, nzt);
 	const int vec_ok = aligned16(in) && aligned16(out) && in_sy % 4 == 0 && in_sz % 4 == 0 && out_sy % 4 == 0 && out_sz % 4 == 0;
-	if (inverse)
-		k_vol_z<true><<<grid, 64 * waves, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok);
-	else
-		k_vol_z<false><<<grid, 64 * waves, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok);
+	if (inverse) {
+		if (cpt == 8)
+			vol_z_nt<true, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+		else
+			vol_z_nt<true, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+	} else {
+		if (cpt == 8)
+			vol_z_nt<false, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+		else
+			vol_z_nt<false, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+	}
 	return hipGetLastError();
 }
 

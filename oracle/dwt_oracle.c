@@ -750,6 +750,214 @@ void oracle_cdf97_3i_s(void *ptr, long sx, long sy, long sz, int nx, int ny, int
 	vol3(ptr, sx, sy, sz, nx, ny, nz, 1);
 }
 
+/* ---- 2-D transforms in the INTERLEAVED (in-place lifting) layout ----
+ * No de-interleave: level j works on the stride-2^j lattice of the image, even lattice
+ * index = low-pass, odd = high-pass (src/dwt-simple.c:2224-2354 fdwt2_cdf97_horizontal_s,
+ * :2356-2489 fdwt2_cdf53_horizontal_s; src/libdwt.c:12926 dwt_cdf97_2f_inplace_s,
+ * :17474 dwt_cdf97_2i_inplace_s, :16553 dwt_cdf53_2f_inplace_s, :17886
+ * dwt_cdf53_2i_inplace_s).
+ *
+ * The 9/7 drivers and fdwt2_cdf53 do not finish the rows before they start the columns:
+ * a line transform is cut into phases -- SHORT (whole line, lines too short for the
+ * rest), PROLOG (first few coefficients), CORE (pairs), EPILOG (the remainder) -- and
+ * each phase runs over all rows, then over all columns, before the next phase starts
+ * (dwt-simple.c:2266-2350, libdwt.c:17517-17594).  Mathematically that is the separable
+ * transform; in fp32 the rounding in the border bands depends on this order, so it is
+ * restated: a phase is, per lifting step, the index range whose coefficients the step
+ * updates (from dwt-simple.c:580-611 prolog, :981-1029 core, :1469-1528 epilog, :424-510
+ * short; libdwt.c:9591-9668, 7661-7740, 9929-10010, 10375-10540 for the inverse).
+ * The 5/3 `_inplace_` drivers are plain rows-then-columns (libdwt.c:16595-16604,
+ * 17917-17926) over whole-line kernels (libdwt.c:11032-11067, 11831-11866). */
+struct il_kind {
+	int nsteps;      /* lifting steps: 4 (9/7) or 2 (5/3) */
+	float c[4];      /* step coefficients in application order */
+	float k_even, k_odd; /* scale factors: applied after the steps (forward) or before (inverse) */
+	int inverse;     /* forward: step 0 updates odd indices; inverse: step 0 updates even ones */
+	int min_phased;  /* shortest line the prolog/core/epilog split handles */
+};
+
+enum il_phase { IL_SHORT, IL_PROLOG, IL_CORE, IL_EPILOG };
+
+static inline float *il_at(char *line, long stride, int i) { return (float *)(line + (long)i * stride); }
+
+/* one lifting step restricted to target indices lo..hi of the step's parity */
+static void il_step(char *line, long stride, int N, int parity, float c, int lo, int hi)
+{
+	if (lo < 0)
+		lo = 0;
+	if (hi > N - 1)
+		hi = N - 1;
+	if ((lo & 1) != parity)
+		lo++;
+	for (int t = lo; t <= hi; t += 2) {
+		float *x = il_at(line, stride, t);
+		if (t == 0)
+			*x += 2 * c * *il_at(line, stride, 1);
+		else if (t == N - 1)
+			*x += 2 * c * *il_at(line, stride, N - 2);
+		else
+			*x += c * (*il_at(line, stride, t - 1) + *il_at(line, stride, t + 1));
+	}
+}
+
+static void il_scale(char *line, long stride, int N, const struct il_kind *k, int lo, int hi)
+{
+	if (lo < 0)
+		lo = 0;
+	if (hi > N - 1)
+		hi = N - 1;
+	for (int t = lo; t <= hi; t++)
+		*il_at(line, stride, t) *= (t & 1) ? k->k_odd : k->k_even;
+}
+
+static void il_line_phase(char *line, long stride, int N, const struct il_kind *k, enum il_phase ph)
+{
+	const int K = k->nsteps;
+	int slo[4], shi[4], sc_lo, sc_hi;
+	if (ph == IL_SHORT) {
+		for (int s = 0; s < K; s++) { slo[s] = 0; shi[s] = N - 1; }
+		sc_lo = 0; sc_hi = N - 1;
+	} else if (!k->inverse) {
+		const int M = (((N - 1) & ~1) - K) / 2; /* core pairs, counted from index 1 */
+		for (int s = 0; s < K; s++) {
+			if (ph == IL_PROLOG) { slo[s] = 0; shi[s] = K - 1 - s; }
+			else if (ph == IL_CORE) { slo[s] = K + 1 - s; shi[s] = K - 1 - s + 2 * M; }
+			else { slo[s] = K + 1 - s + 2 * M; shi[s] = N - 1; }
+		}
+		if (ph == IL_PROLOG) { sc_lo = 0; sc_hi = 0; }
+		else if (ph == IL_CORE) { sc_lo = 1; sc_hi = 2 * M; }
+		else { sc_lo = 2 * M + 1; sc_hi = N - 1; }
+	} else {
+		const int M = ((N & ~1) - K) / 2; /* core pairs, counted from index 0 */
+		for (int s = 0; s < K; s++) {
+			if (ph == IL_PROLOG) { slo[s] = 0; shi[s] = K - 2 - s; }
+			else if (ph == IL_CORE) { slo[s] = K - s; shi[s] = K - 2 - s + 2 * M; }
+			else { slo[s] = K - s + 2 * M; shi[s] = N - 1; }
+		}
+		if (ph == IL_PROLOG) { sc_lo = 0; sc_hi = K - 1; }
+		else if (ph == IL_CORE) { sc_lo = K; sc_hi = K - 1 + 2 * M; }
+		else { sc_lo = K + 2 * M; sc_hi = N - 1; }
+	}
+	if (k->inverse)
+		il_scale(line, stride, N, k, sc_lo, sc_hi);
+	for (int s = 0; s < K; s++)
+		il_step(line, stride, N, k->inverse ? (s & 1) : !(s & 1), k->c[s], slo[s], shi[s]);
+	if (!k->inverse)
+		il_scale(line, stride, N, k, sc_lo, sc_hi);
+}
+
+/* one level on the lattice: phases outermost, rows before columns inside each phase */
+static void il_level_phased(char *ptr, long sx, long sy, int nx, int ny, const struct il_kind *k)
+{
+	for (int ph = IL_SHORT; ph <= IL_EPILOG; ph++) {
+		if (nx > 1 && (ph == IL_SHORT) == (nx < k->min_phased))
+			for (int y = 0; y < ny; y++)
+				il_line_phase(ptr + (long)y * sx, sy, nx, k, (enum il_phase)ph);
+		if (ny > 1 && (ph == IL_SHORT) == (ny < k->min_phased))
+			for (int x = 0; x < nx; x++)
+				il_line_phase(ptr + (long)x * sy, sx, ny, k, (enum il_phase)ph);
+	}
+}
+
+/* one level, rows completely, then columns completely; single-sample lines are scaled */
+static void il_level_separable(char *ptr, long sx, long sy, int nx, int ny, const struct il_kind *k, float single)
+{
+	for (int pass = 0; pass < 2; pass++) {
+		const int n = pass ? ny : nx, lines = pass ? nx : ny;
+		const long ls = pass ? sy : sx, es = pass ? sx : sy;
+		for (int l = 0; l < lines; l++) {
+			char *line = ptr + (long)l * ls;
+			if (n == 1)
+				*il_at(line, es, 0) *= single;
+			else if (n > 1)
+				il_line_phase(line, es, n, k, IL_SHORT);
+		}
+	}
+}
+
+static const struct il_kind IL_97_F = {4, {-C97_P1, C97_U1, -C97_P2, C97_U2}, C97_S1, 1 / C97_S1, 0, 5};
+static const struct il_kind IL_97_I = {4, {-C97_U2, C97_P2, -C97_U1, C97_P1}, 1 / C97_S1, C97_S1, 1, 4};
+static const struct il_kind IL_53_F_NEW = {2, {-C53_P1, C53_U1}, C53_S1, 1 / C53_S1, 0, 3};
+static const struct il_kind IL_53_F = {2, {-C53_P1, C53_U1}, C53_S1, C53_S2, 0, 0};
+static const struct il_kind IL_53_I = {2, {-C53_U1, C53_P1}, C53_S2, C53_S1, 1, 0};
+
+static int il_levels(int sox, int soy, int j_max, int decompose_one)
+{
+	const int j_limit = oracle_ceil_log2(decompose_one ? imax(sox, soy) : imin(sox, soy));
+	return (j_max < 0 || j_max > j_limit) ? j_limit : j_max;
+}
+
+static void il_forward(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy, int *j_max_ptr,
+	int decompose_one, const struct il_kind *k, int phased)
+{
+	*j_max_ptr = il_levels(sox, soy, *j_max_ptr, decompose_one);
+	for (int j = 0; j < *j_max_ptr; j++) {
+		const int nx = oracle_ceil_div_pow2(six, j), ny = oracle_ceil_div_pow2(siy, j);
+		if (phased)
+			il_level_phased((char *)ptr, (long)stride_x << j, (long)stride_y << j, nx, ny, k);
+		else
+			il_level_separable((char *)ptr, (long)stride_x << j, (long)stride_y << j, nx, ny, k, C53_S1);
+	}
+}
+
+static void il_inverse(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy, int j_max,
+	int decompose_one, const struct il_kind *k, int phased)
+{
+	for (int j = il_levels(sox, soy, j_max, decompose_one); j > 0; j--) {
+		const int nx = oracle_ceil_div_pow2(six, j - 1), ny = oracle_ceil_div_pow2(siy, j - 1);
+		if (phased)
+			il_level_phased((char *)ptr, (long)stride_x << (j - 1), (long)stride_y << (j - 1), nx, ny, k);
+		else
+			il_level_separable((char *)ptr, (long)stride_x << (j - 1), (long)stride_y << (j - 1), nx, ny, k, C53_S2);
+	}
+}
+
+/* src/libdwt.c:12926 (and, with size_o == size_i, src/dwt-simple.c:2224, :1615, :3034:
+ * the horizontal / vertical / diagonal schedules give identical bits) */
+void oracle_cdf97_2f_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	il_forward(ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, &IL_97_F, 1);
+}
+
+/* src/libdwt.c:17474 */
+void oracle_cdf97_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	il_inverse(ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, &IL_97_I, 1);
+}
+
+/* src/libdwt.c:16553 */
+void oracle_cdf53_2f_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	il_forward(ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, &IL_53_F, 0);
+}
+
+/* src/libdwt.c:17886 */
+void oracle_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	il_inverse(ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, &IL_53_I, 0);
+}
+
+/* src/dwt-simple.c:2224 (fdwt2_cdf97_{horizontal,vertical,diagonal}_s) */
+void oracle_fdwt2_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
+{
+	il_forward(ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, &IL_97_F, 1);
+}
+
+/* src/dwt-simple.c:2356 (fdwt2_cdf53_{horizontal,vertical,diagonal}_s): phased like the 9/7
+ * one, odd coefficients scaled by 1/zeta computed in float, single-sample lines untouched */
+void oracle_fdwt2_cdf53_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
+{
+	il_forward(ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, &IL_53_F_NEW, 1);
+}
+
 /* ---- libdwt's synthetic test patterns ---- */
 /* float, type 0: x,y made 1-based, x >>= rand, 2xy/(float)(x^2+y^2+1)
  * (src/libdwt.c:1209-1217, filled by :1338) */

@@ -103,6 +103,19 @@ void oracle_cdf97_3f_s(void *ptr, long stride_x, long stride_y, long stride_z,
 void oracle_cdf97_3i_s(void *ptr, long stride_x, long stride_y, long stride_z,
 	int size_x, int size_y, int size_z);
 
+/* interleaved (in-place lifting) layout: src/libdwt.c:12926, 17474, 16553, 17886;
+ * src/dwt-simple.c:2224 (= :1615, :3034), :2356 (= :1927, :3166) */
+void oracle_cdf97_2f_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void oracle_cdf97_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding);
+void oracle_cdf53_2f_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void oracle_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding);
+void oracle_fdwt2_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
+void oracle_fdwt2_cdf53_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
+
 /* libdwt's synthetic inputs (src/libdwt.c:1201-1244, 1142-1167, 1338, 1270). */
 void oracle_test_image_fill_s(void *ptr, int stride_x, int stride_y, int size_x, int size_y, int rnd);
 void oracle_test_image_fill_i(void *ptr, int stride_x, int stride_y, int size_x, int size_y, int rnd);

@@ -67,6 +67,12 @@ DOUBLE_CASES = {"8x8_rand", "37x53_rand", "64x5_rand", "1x64_rand", "64x1_rand",
                 "100x100_pat_full", "sparse_64x64_50x40_zp", "sparse_33x17_20x9", "sparse_40x24_1x1_zp", "129x65_rand_j4"}
 
 
+# cases of CASES_2D that also pin the interleaved-layout entries
+IL_CASES = {"8x8_rand", "16x16_pat", "37x53_rand", "53x37_rand_j2", "64x5_rand", "5x64_rand_d1", "1x64_rand", "2x2_rand",
+            "3x3_rand", "4x4_rand", "2x7_rand_d1", "100x100_pat_full", "129x65_rand_j4", "sparse_64x64_50x40",
+            "sparse_33x17_20x9", "256x192_rand_j5"}
+
+
 def make_input(ref, kind, dt, h, w_alloc, w, seed):
     rng = np.random.default_rng(seed)
     if dt == np.float32:
@@ -131,6 +137,39 @@ def main():
         sha = hashlib.sha256(open(path, "rb").read()).hexdigest()
         manifest["files"][f"{wname}.npz"] = {"sha256": sha, "cases": meta}
         print(path, os.path.getsize(path), "bytes", len(meta), "cases")
+
+    # interleaved (in-place lifting) layout: dwt-simple.h fdwt2_* and libdwt.h *_inplace_s
+    ref.lib.dwt_util_set_num_workers(1)
+    arrays, meta = {}, []
+    il_cases = [c for c in CASES_2D if c[0] in IL_CASES] + [
+        ("5x5_rand", (5, 5), None, -1, 0, 0, 0, "rand"), ("6x6_rand", (6, 6), None, -1, 0, 0, 0, "rand"),
+        ("17x1_rand_d1", (17, 1), None, -1, 1, 0, 0, "rand"), ("12x4_rand_d1", (12, 4), None, -1, 1, 0, 2, "rand"),
+    ]
+    for idx, (name, so, si, j, d1, zp, pad, kind) in enumerate(il_cases):
+        w, h = so
+        src = make_input(ref, kind, np.float32, h, w + pad, w, seed=4000 + idx)
+        arrays[f"{name}.in"] = src
+        m = {"name": name, "size_o": so, "size_i": si or so, "j_in": j, "decompose_one": d1, "pitch_elems": w + pad, "input": kind}
+        for wv in ("cdf97", "cdf53"):
+            buf = src.copy()
+            m[f"{wv}.j_out"] = ref.fwd(f"{wv}_2f_inplace_s", buf[:, :w], j, size_o=so, size_i=si, decompose_one=d1)
+            arrays[f"{name}.{wv}.fwd"] = buf.copy()
+            ref.inv(f"{wv}_2i_inplace_s", buf[:, :w], m[f"{wv}.j_out"], size_o=so, size_i=si, decompose_one=d1)
+            arrays[f"{name}.{wv}.inv"] = buf.copy()
+            if si is None:
+                outs = []
+                for sched in ("horizontal", "vertical", "diagonal"):
+                    buf = src.copy()
+                    jn = ref.fdwt2(wv, buf[:, :w], j, d1, sched)
+                    outs.append(buf)
+                    assert jn == m[f"{wv}.j_out"]
+                assert all(np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)) for o in outs[1:])
+                arrays[f"{name}.{wv}.fdwt2"] = outs[0]
+        meta.append(m)
+    path = os.path.join(OUT, "interleaved_s.npz")
+    np.savez_compressed(path, **arrays)
+    manifest["files"]["interleaved_s.npz"] = {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "cases": meta}
+    print(path, os.path.getsize(path), "bytes", len(meta), "cases")
 
     # 3-D single-level float 9/7 (volume-dwt.c sep_horizontal), interleaved layout
     import ctypes as C

@@ -53,3 +53,17 @@ def golden_cases(wname):
 def bits(a):
     a = np.ascontiguousarray(a)
     return a.view(np.uint64 if a.dtype.itemsize == 8 else np.uint32)
+
+
+def interleaved_cases():
+    """[(meta, arrays)] of tests/golden/interleaved_s.npz: arrays holds "in" and, per
+    wavelet ("cdf97", "cdf53"), "<w>.fwd" / "<w>.inv" (libdwt.h *_inplace_s entries) and,
+    for dense frames, "<w>.fdwt2" (dwt-simple.h entries)."""
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)
+    z = np.load(os.path.join(GOLDEN, "interleaved_s.npz"))
+    out = []
+    for m in man["files"]["interleaved_s.npz"]["cases"]:
+        pre = m["name"] + "."
+        out.append((m, {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}))
+    return out

@@ -41,7 +41,15 @@ ENTRIES = {
     "cdf53_2i_d": (_INV, np.float64),
     "cdf97_2f_i": (_FWD, np.int32),
     "cdf97_2i_i": (_INV, np.int32),
+    # interleaved (in-place lifting) layout
+    "cdf97_2f_inplace_s": (_FWD, np.float32),
+    "cdf97_2i_inplace_s": (_INV, np.float32),
+    "cdf53_2f_inplace_s": (_FWD, np.float32),
+    "cdf53_2i_inplace_s": (_INV, np.float32),
 }
+
+# dwt-simple.h entries: (ptr, size_x, size_y, stride_x, stride_y, int *j, decompose_one)
+_NEW = [_P, _I, _I, _I, _I, C.POINTER(_I), _I]
 
 
 def build_oracle(force=False):
@@ -90,6 +98,16 @@ class _Lib:
     def inv(self, name, img, j=-1, **kw):
         return self._call(name, img, j, **kw)
 
+    def fdwt2(self, wavelet, img, j=-1, decompose_one=0, schedule="horizontal"):
+        """dwt-simple.h forward transform, interleaved layout, in place; returns j."""
+        assert img.dtype == np.float32 and img.ndim == 2 and img.strides[1] == 4
+        fn = self._fdwt2_fn(wavelet, schedule)
+        fn.argtypes = _NEW
+        fn.restype = None
+        jj = _I(j)
+        fn(img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], 4, C.byref(jj), decompose_one)
+        return jj.value
+
     def call2(self, name, src, dst, j, size_o=None, size_i=None, decompose_one=0, zero_padding=0):
         """Out-of-place `_s2` entries; src and dst share the pitch of `dst`."""
         assert src.strides == dst.strides and src.dtype == dst.dtype == np.float32
@@ -132,6 +150,9 @@ class Oracle(_Lib):
         except AttributeError:
             avail = os.cpu_count() or 1
         L.oracle_set_threads(max(1, min(16, avail)))
+
+    def _fdwt2_fn(self, wavelet, schedule):
+        return getattr(self.lib, "oracle_fdwt2_%s_s" % wavelet)
 
     def line(self, name, a):
         getattr(self.lib, "oracle_line_" + name)(a.ctypes.data, a.shape[0])
@@ -178,6 +199,9 @@ class Reference(_Lib):
         L.dwt_util_get_opt_stride.restype = _I
         L.dwt_util_get_stride.argtypes = [_I, _I]
         L.dwt_util_get_stride.restype = _I
+
+    def _fdwt2_fn(self, wavelet, schedule):
+        return getattr(self.lib, "fdwt2_%s_%s_s" % (wavelet, schedule))
 
     def fill_s(self, img, rnd=0):
         self.lib.dwt_util_test_image_fill_s(img.ctypes.data, img.strides[0], 4, img.shape[1], img.shape[0], rnd)

@@ -76,6 +76,17 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst,
 int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *dst,
 	size_t batch_stride, int batch, int stride_x, int size_x, int size_y, int *j);
 
+/* 2-D transforms in the INTERLEAVED (in-place lifting) layout: no de-interleave, level j
+ * works on the stride-2^j lattice of the image (even lattice index = low-pass).
+ * `wavelet` is DWT_HIP_CDF97_S or DWT_HIP_CDF53_S.  `flavour` 0 = libdwt.h's
+ * dwt_cdf97_2f_inplace_s / dwt_cdf97_2i_inplace_s / dwt_cdf53_2f_inplace_s /
+ * dwt_cdf53_2i_inplace_s (src/libdwt.c:12926, 17474, 16553, 17886); flavour 1 =
+ * dwt-simple.h's forward fdwt2_cdf97_* / fdwt2_cdf53_* (src/dwt-simple.c:2224, 2356).
+ * Host or device pointers, in place (src == dst) or out of place. */
+int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const void *src, void *dst,
+	int stride_x, int stride_y, int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j, int decompose_one);
+
 /* Single-level 3-D CDF 9/7 float over the interleaved in-place layout of
  * cdf97_3f_ip_sep_horizontal_s / cdf97_3i_ip_sep_horizontal_s
  * (src/volume-dwt.c:677, 1115); `levels` > 1 re-applies it on the LLL lattice

@@ -70,6 +70,8 @@ lib.dwt_hip_transform2d.argtypes = [_I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.PO
 lib.dwt_hip_transform2d.restype = _I
 lib.dwt_hip_transform2d_batch.argtypes = [_I, _I, _P, _P, _S, _I, _I, _I, _I, C.POINTER(_I)]
 lib.dwt_hip_transform2d_batch.restype = _I
+lib.dwt_hip_transform2d_interleaved.argtypes = [_I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_I), _I]
+lib.dwt_hip_transform2d_interleaved.restype = _I
 lib.dwt_hip_transform3d.argtypes = [_I, _P, _S, _S, _I, _I, _I, _I]
 lib.dwt_hip_transform3d.restype = _I
 lib.dwt_hip_malloc.argtypes = [_S]
@@ -298,6 +300,60 @@ INVERSE = {"cdf97_s": dwt_cdf97_2i_s, "cdf53_i": dwt_cdf53_2i_i, "cdf53_s": dwt_
            "cdf97_d": dwt_cdf97_2i_d, "cdf53_d": dwt_cdf53_2i_d, "cdf97_i": dwt_cdf97_2i_i}
 WAVELET_ID = {"cdf97_s": CDF97_S, "cdf53_i": CDF53_I, "cdf53_s": CDF53_S, "cdf97_d": CDF97_D, "cdf53_d": CDF53_D,
               "cdf97_i": CDF97_I}
+
+
+# ---- interleaved (in-place lifting) layout ------------------------------------------------
+def transform2d_interleaved(wavelet, inverse, flavour, src, dst, stride_x, stride_y, size_o_big_x, size_o_big_y,
+                            size_i_big_x=None, size_i_big_y=None, j_max=-1, decompose_one=0):
+    """dwt_hip_transform2d_interleaved: host or device pointers, in place (src is dst) or out of place.
+    flavour 0 = libdwt.h *_inplace_s entries, 1 = dwt-simple.h fdwt2_* (forward only).  Returns j."""
+    j = _I(j_max)
+    six = size_o_big_x if size_i_big_x is None else size_i_big_x
+    siy = size_o_big_y if size_i_big_y is None else size_i_big_y
+    rc = lib.dwt_hip_transform2d_interleaved(WAVELET_ID.get(wavelet, wavelet), int(inverse), flavour, _addr(src), _addr(dst),
+                                             stride_x, stride_y, size_o_big_x, size_o_big_y, six, siy, C.byref(j), decompose_one)
+    _check(rc, "dwt_hip_transform2d_interleaved")
+    return j.value
+
+
+def dwt_cdf97_2f_inplace_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                           j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:12926.  Returns the level count."""
+    return transform2d_interleaved(CDF97_S, 0, 0, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y,
+                                   size_i_big_x, size_i_big_y, j_max, decompose_one)
+
+
+def dwt_cdf97_2i_inplace_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                           j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:17474"""
+    transform2d_interleaved(CDF97_S, 1, 0, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y,
+                            size_i_big_x, size_i_big_y, j_max, decompose_one)
+
+
+def dwt_cdf53_2f_inplace_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                           j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:16553.  Returns the level count."""
+    return transform2d_interleaved(CDF53_S, 0, 0, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y,
+                                   size_i_big_x, size_i_big_y, j_max, decompose_one)
+
+
+def dwt_cdf53_2i_inplace_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                           j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:17886"""
+    transform2d_interleaved(CDF53_S, 1, 0, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y,
+                            size_i_big_x, size_i_big_y, j_max, decompose_one)
+
+
+def _newapi(wavelet):
+    def f(ptr, size_x, size_y, stride_x, stride_y, j_max=-1, decompose_one=0):
+        return transform2d_interleaved(wavelet, 0, 1, ptr, ptr, stride_x, stride_y, size_x, size_y, size_x, size_y,
+                                       j_max, decompose_one)
+    return f
+
+
+# src/dwt-simple.c:2224 / :1615 / :3034 and :2356 / :1927 / :3166 (argument order of dwt-simple.h)
+fdwt2_cdf97_horizontal_s = fdwt2_cdf97_vertical_s = fdwt2_cdf97_diagonal_s = _newapi(CDF97_S)
+fdwt2_cdf53_horizontal_s = fdwt2_cdf53_vertical_s = fdwt2_cdf53_diagonal_s = _newapi(CDF53_S)
 
 
 # ---- batches resident in HBM -----------------------------------------------------------

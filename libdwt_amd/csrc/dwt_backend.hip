@@ -949,6 +949,227 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	return download(dst, B.p);
 }
 
+// ---------------------------------------------------------------------------------
+// Interleaved (in-place lifting) layout: libdwt.h dwt_cdf97_2f_inplace_s (src/libdwt.c:12926),
+// dwt_cdf97_2i_inplace_s (:17474), dwt_cdf53_2f_inplace_s (:16553), dwt_cdf53_2i_inplace_s
+// (:17886) and dwt-simple.h fdwt2_cdf97_* / fdwt2_cdf53_* (src/dwt-simple.c:2224, :2356).
+// Level j transforms the stride-2^j lattice of the image in place.  On the device every
+// level runs on a DENSE image instead: the forward sweep of level j writes its low-pass
+// samples a second time, densely, as the input of level j+1, and the results of the levels
+// >= 1 are scattered into the lattice afterwards (deepest last); the inverse gathers the
+// lattices first.  Rows are finished before columns at every level; the 9/7 entries of the
+// reference interleave the two in phases (prolog / core / epilog), which changes fp32
+// rounding in the 8-sample border bands only (tests/test_oracle_interleaved.py).
+// ---------------------------------------------------------------------------------
+struct IlLevel {
+	float *a = nullptr, *b = nullptr; // dense input / output of the level (levels >= 1)
+	long pitch = 0;                   // elements
+	int lx = 0, ly = 0;
+};
+
+// one level on dense images with a common pitch: rows completely, then columns
+static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch)
+{
+	const bool fused = !g.force_generic && lx >= 2 && ly >= 2 && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
+	if (fused) {
+		hipError_t e;
+		if (!inverse) {
+			FwdLevelArgs a;
+			a.in = in.p; a.in_pitch = in.sx / 4; a.in_bstride = 0;
+			a.out_ll = ll; a.ll_pitch = ll_pitch; a.ll_bstride = 0;
+			a.out_h = out.p; a.h_pitch = out.sx / 4; a.h_bstride = 0;
+			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1; a.il_ll = ll != nullptr;
+			e = launch_fwd_level(w, a, g.tune, g.stream);
+		} else {
+			InvLevelArgs a;
+			a.in_ll = in.p; a.ll_pitch = in.sx / 4; a.ll_bstride = 0;
+			a.in_h = in.p; a.h_pitch = in.sx / 4; a.h_bstride = 0;
+			a.out = out.p; a.out_pitch = out.sx / 4; a.out_bstride = 0;
+			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1;
+			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream);
+		}
+		if (e != hipSuccess)
+			return fail("interleaved sweep launch failed: %s", hipGetErrorString(e));
+		return 0;
+	}
+	// generic: two exact line passes through a temporary with the same pitch
+	if (in.sx != out.sx)
+		return fail("interleaved generic level: pitches differ");
+	if (grow(&g.host_b, &g.host_b_bytes, (size_t)in.sx * ly))
+		return 1;
+	Img tmp{(char *)g.host_b, in.sx, 4};
+	auto pass = [&](bool rows, Img from, Img to) -> int {
+		const int N = rows ? lx : ly, lines = rows ? ly : lx;
+		if (N == 1 && !scale_single)
+			return copy_rect(to, 0, 0, from, 0, 0, lx, ly);
+		hipError_t e = launch_line_pass(w, inverse, from.p, to.p, rows ? from.sx : 4, rows ? 4 : from.sx, lines, N, -1, !rows, g.stream);
+		if (e != hipSuccess)
+			return fail("interleaved line pass launch failed: %s", hipGetErrorString(e));
+		return 0;
+	};
+	if (pass(true, in, tmp) || pass(false, tmp, out))
+		return 1;
+	if (ll && !inverse) {
+		hipError_t e = launch_lattice_copy((const float *)out.p, 2, out.sx / 4 * 2, 0, ll, 1, ll_pitch, 0, (lx + 1) / 2, (ly + 1) / 2, 1, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice gather failed: %s", hipGetErrorString(e));
+	}
+	return 0;
+}
+
+static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
+	int *jp, int decompose_one)
+{
+	const int j_limit = ceil_log2(decompose_one ? (sox > soy ? sox : soy) : (sox < soy ? sox : soy));
+	int J = *jp;
+	if (J < 0 || J > j_limit)
+		J = j_limit;
+	if (!inverse)
+		*jp = J;
+	if (side_join())
+		return 1;
+	const bool alias = src.p == dst.p;
+	// everything outside the transformed region keeps the caller's values
+	if (!alias && (J == 0 || six < sox || siy < soy || inverse) && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))
+		return 1;
+	if (J == 0 || six < 1 || siy < 1)
+		return 0;
+	constexpr int kMax = 32;
+	IlLevel L[kMax];
+	size_t pool = 0;
+	for (int j = 0; j < J; j++) {
+		L[j].lx = ceil_div_pow2(six, j);
+		L[j].ly = ceil_div_pow2(siy, j);
+		L[j].pitch = align_up(L[j].lx, 4);
+		if (j >= 1)
+			pool += (size_t)L[j].pitch * L[j].ly;
+	}
+	if (J > 1) {
+		if (grow(&g.ll[0], &g.ll_bytes[0], pool * 4) || grow(&g.ll[1], &g.ll_bytes[1], pool * 4))
+			return 1;
+		float *pa = (float *)g.ll[0], *pb = (float *)g.ll[1];
+		for (int j = 1; j < J; j++) {
+			L[j].a = pa; L[j].b = pb;
+			pa += (size_t)L[j].pitch * L[j].ly;
+			pb += (size_t)L[j].pitch * L[j].ly;
+		}
+	}
+	auto dense = [&](float *p, const IlLevel &l) { return Img{(char *)p, l.pitch * 4, 4}; };
+	auto scatter = [&](const float *from, long from_pitch, char *to, long to_pitch_bytes, long step, const IlLevel &l) -> int {
+		// dense level -> lattice of stride `step` (elements) of an image
+		hipError_t e = launch_lattice_copy(from, 1, from_pitch, 0, (float *)to, step, to_pitch_bytes / 4 * step, 0, l.lx, l.ly, 1, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice scatter failed: %s", hipGetErrorString(e));
+		return 0;
+	};
+	auto gather = [&](const char *from, long from_pitch_bytes, long step, float *to, const IlLevel &l) -> int {
+		hipError_t e = launch_lattice_copy((const float *)from, step, from_pitch_bytes / 4 * step, 0, to, 1, l.pitch, 0, l.lx, l.ly, 1, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice gather failed: %s", hipGetErrorString(e));
+		return 0;
+	};
+	// level 0 works on the caller's image; in place it detours through the staging image
+	Img stage{nullptr, dst.sx, 4};
+	if (alias || inverse) {
+		if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * siy))
+			return 1;
+		stage.p = (char *)g.stage_img;
+	}
+
+	if (!inverse) {
+		for (int j = 0; j < J; j++) {
+			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
+			const Img out = j == 0 ? (alias ? stage : dst) : dense(L[j].b, L[j]);
+			float *ll = j + 1 < J ? L[j + 1].a : nullptr;
+			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0))
+				return 1;
+		}
+		if (alias && copy_rect(dst, 0, 0, stage, 0, 0, six, siy))
+			return 1;
+		for (int j = 1; j < J; j++)
+			if (scatter(L[j].b, L[j].pitch, dst.p, dst.sx, 1L << j, L[j]))
+				return 1;
+		return 0;
+	}
+	// inverse: dst already holds the coefficients (copied above when out of place)
+	for (int j = 1; j < J; j++)
+		if (gather(dst.p, dst.sx, 1L << j, L[j].a, L[j]))
+			return 1;
+	for (int j = J - 1; j >= 1; j--) {
+		if (il_level(w, true, scale_single, dense(L[j].a, L[j]), dense(L[j].b, L[j]), L[j].lx, L[j].ly, nullptr, 0))
+			return 1;
+		// the reconstructed low-pass band is the even-even lattice of the level above
+		if (j >= 2) {
+			if (scatter(L[j].b, L[j].pitch, (char *)L[j - 1].a, L[j - 1].pitch * 4, 2, L[j]))
+				return 1;
+		} else if (scatter(L[j].b, L[j].pitch, dst.p, dst.sx, 2, L[j])) {
+			return 1;
+		}
+	}
+	if (il_level(w, true, scale_single, dst, stage, L[0].lx, L[0].ly, nullptr, 0))
+		return 1;
+	return copy_rect(dst, 0, 0, stage, 0, 0, six, siy);
+}
+
+int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const void *src, void *dst, int stride_x, int stride_y,
+	int sox, int soy, int six, int siy, int *j, int decompose_one)
+{
+	if (check_inited())
+		return 1;
+	if (wavelet != kCdf97S && wavelet != kCdf53S)
+		return fail("the interleaved layout takes the float wavelets (CDF 9/7, CDF 5/3), not %d", wavelet);
+	if (flavour != 0 && flavour != 1)
+		return fail("unknown flavour %d", flavour);
+	if (flavour == 1 && inverse)
+		return fail("dwt-simple.h has forward transforms only; use flavour 0 for the inverse");
+	if (!src || !dst || !j)
+		return fail("null pointer argument");
+	if (sox <= 0 || soy <= 0 || six < 0 || siy < 0 || six > sox || siy > soy)
+		return fail("bad sizes: outer %dx%d inner %dx%d", sox, soy, six, siy);
+	g_elems_are_32bit = true;
+	// single-sample lines: the 9/7 drivers and fdwt2_* leave them (guards `size > 1`,
+	// libdwt.c:12978, dwt-simple.c:2266), the 5/3 _inplace_ drivers scale them (:11041, :11840)
+	const bool scale_single = wavelet == kCdf53S && flavour == 0;
+	const Wavelet w = wavelet == kCdf97S ? ((g.fma && !inverse) ? kCdf97SFma : kCdf97S) : (flavour == 1 ? kCdf53SNew : kCdf53S);
+	const bool dev_src = dwt_hip_is_device_pointer(src), dev_dst = dwt_hip_is_device_pointer(dst);
+	if (dev_src != dev_dst)
+		return fail("src and dst must both be host or both be device pointers");
+	if (dev_dst) {
+		if (stride_y != 4 || (stride_x % 4) || stride_x < sox * 4)
+			return fail("device images need stride_y == 4 and stride_x a multiple of it >= width*4 (got %d, %d)", stride_x, stride_y);
+		return interleaved2d(w, inverse != 0, scale_single, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
+	}
+	// host pointers: stage the outer frame through HBM (any byte strides)
+	const long pitch = align_up((long)sox * 4, 256);
+	if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * soy))
+		return 1;
+	std::vector<char> packed;
+	if (stride_y == 4) {
+		HIP_TRY(hipMemcpy2DAsync(g.host_a, pitch, src, stride_x, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
+	} else {
+		packed.resize((size_t)sox * soy * 4);
+		for (int y = 0; y < soy; y++)
+			for (int x = 0; x < sox; x++)
+				memcpy(&packed[((size_t)y * sox + x) * 4], (const char *)src + (long)y * stride_x + (long)x * stride_y, 4);
+		HIP_TRY(hipMemcpy2DAsync(g.host_a, pitch, packed.data(), (size_t)sox * 4, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	Img A{(char *)g.host_a, pitch, 4};
+	if (interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one))
+		return 1;
+	if (stride_y == 4) {
+		HIP_TRY(hipMemcpy2DAsync(dst, stride_x, g.host_a, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	} else {
+		HIP_TRY(hipMemcpy2DAsync(packed.data(), (size_t)sox * 4, g.host_a, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		for (int y = 0; y < soy; y++)
+			for (int x = 0; x < sox; x++)
+				memcpy((char *)dst + (long)y * stride_x + (long)x * stride_y, &packed[((size_t)y * sox + x) * 4], 4);
+	}
+	return 0;
+}
+
 int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *dst, size_t batch_stride, int batch,
 	int stride_x, int size_x, int size_y, int *j)
 {

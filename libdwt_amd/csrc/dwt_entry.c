@@ -7,6 +7,7 @@
  */
 #include "../../include/libdwt.h"
 #include "../../include/libdwt_hip.h"
+#include "../../include/dwt-simple.h"
 
 #include <stdlib.h>
 
@@ -114,6 +115,57 @@ void dwt_cdf53_2i_d(void *ptr, int stride_x, int stride_y, int sox, int soy, int
 {
 	run(DWT_HIP_CDF53_D, 1, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, zero_padding, __func__);
 }
+
+/* interleaved (in-place lifting) layout: src/libdwt.c:12926, 17474, 16553, 17886 */
+static void run_il(int wavelet, int inverse, int flavour, void *ptr, int stride_x, int stride_y,
+	int sox, int soy, int six, int siy, int *j, int decompose_one, const char *who)
+{
+	if (dwt_hip_transform2d_interleaved(wavelet, inverse, flavour, ptr, ptr, stride_x, stride_y, sox, soy, six, siy, j, decompose_one))
+		dwt_util_error("%s: %s\n", who, dwt_hip_last_error());
+}
+
+void dwt_cdf97_2f_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	(void)zero_padding; /* unused by the reference too (its padding code is commented out) */
+	run_il(DWT_HIP_CDF97_S, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, __func__);
+}
+
+void dwt_cdf97_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	run_il(DWT_HIP_CDF97_S, 1, 0, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, __func__);
+}
+
+void dwt_cdf53_2f_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	run_il(DWT_HIP_CDF53_S, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, __func__);
+}
+
+void dwt_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	run_il(DWT_HIP_CDF53_S, 1, 0, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, __func__);
+}
+
+/* dwt-simple.h: src/dwt-simple.c:2224 / :1615 / :3034 and :2356 / :1927 / :3166 -- three
+ * CPU schedules per wavelet with identical results, one device path here */
+#define DWT_NEWAPI(name, wavelet)                                                                      \
+	void name(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one) \
+	{                                                                                                  \
+		run_il(wavelet, 0, 1, ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, __func__); \
+	}
+DWT_NEWAPI(fdwt2_cdf97_horizontal_s, DWT_HIP_CDF97_S)
+DWT_NEWAPI(fdwt2_cdf97_vertical_s, DWT_HIP_CDF97_S)
+DWT_NEWAPI(fdwt2_cdf97_diagonal_s, DWT_HIP_CDF97_S)
+DWT_NEWAPI(fdwt2_cdf53_horizontal_s, DWT_HIP_CDF53_S)
+DWT_NEWAPI(fdwt2_cdf53_vertical_s, DWT_HIP_CDF53_S)
+DWT_NEWAPI(fdwt2_cdf53_diagonal_s, DWT_HIP_CDF53_S)
+#undef DWT_NEWAPI
 
 /* src/libdwt.c:19158: platform bring-up.  The reference loads accelerator firmware
  * on ASVP and does nothing on x86; here the device context is created. */

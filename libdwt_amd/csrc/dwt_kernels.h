@@ -7,7 +7,8 @@
 namespace dwt {
 
 enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2, kCdf97D = 3, kCdf53D = 4, kCdf97I = 5,
-	kCdf97SFma = 6 /* internal: float 9/7 with contracted steps, option "fma" */ };
+	kCdf97SFma = 6 /* internal: float 9/7 with contracted steps, option "fma" */,
+	kCdf53SNew = 7 /* internal: float 5/3 of dwt-simple.c (odd scale 1/zeta in float), interleaved layout only */ };
 
 inline int elem_size(Wavelet w) { return (w == kCdf97D || w == kCdf53D) ? 8 : 4; }
 
@@ -40,7 +41,8 @@ struct FwdLevelArgs {
 	void *out_h;
 	long h_pitch, h_bstride;
 	int W, H, batch;
-	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path layout)
+	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path / in-place lifting layout)
+	int il_ll = 0;       // interleaved only: also write the LL samples densely to out_ll
 };
 
 // One reconstruction level, inverse, dense frame.  Reads LL from `in_ll` and the

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_line_pass(const char *__restrict__ src,
 	char *d = dst + (long)line * line_stride;
 	auto ld = [&](int idx) { return *(const T *)(s + (long)idx * elem_stride); };
 	auto st = [&](int idx, T v) { *(T *)(d + (long)idx * elem_stride) = v; };
+	const bool il = hoff < 0; // interleaved layout on both sides: L_k at 2k, H_k at 2k+1
 
 	if (N == 1) {
 		// the float kernels scale a lone sample, the int kernel leaves it
@@ -76,15 +77,15 @@ __global__ __launch_bounds__(256) void k_line_pass(const char *__restrict__ src,
 		for (int j = 0; j <= 2 * K; j++)
 			w[j] = ld(reflect(2 * k - K + j, N));
 		lift_fwd_regs<W, 2 * K + 1>(w);
-		st(k, W::fwd_scale(0, w[K]));
+		st(il ? 2 * k : k, W::fwd_scale(0, w[K]));
 		if (2 * k + 1 < N)
-			st(hoff + k, W::fwd_scale(1, w[K + 1]));
+			st(il ? 2 * k + 1 : hoff + k, W::fwd_scale(1, w[K + 1]));
 	} else {
 		// w[j] = a[2k-K+1+j] of the interleaved signal; w[0] is an odd sample
 #pragma unroll
 		for (int j = 0; j <= 2 * K; j++) {
 			const int i = reflect(2 * k - K + 1 + j, N);
-			const T raw = (i & 1) ? ld(hoff + (i >> 1)) : ld(i >> 1);
+			const T raw = il ? ld(i) : (i & 1) ? ld(hoff + (i >> 1)) : ld(i >> 1);
 			w[j] = W::inv_scale(i & 1, raw);
 		}
 		lift_inv_regs<W, 2 * K + 1>(w);
@@ -122,6 +123,7 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 	case kCdf97D: return line_pass_t<Cdf97D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf53D: return line_pass_t<Cdf53D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf97I: return line_pass_t<Cdf97I>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
+	case kCdf53SNew: return line_pass_t<Cdf53SNew>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf97SFma: break; // the contracted variant exists for the fused sweeps only
 	}
 	return hipErrorInvalidValue;
@@ -238,6 +240,7 @@ static __device__ __forceinline__ int tile_block_id(int swz)
 
 struct SweepGeom {
 	int tile_pairs, ntx, swz, in_vec_ok, out_vec_ok;
+	int ll_vec_ok = 0; // interleaved layout with a dense LL copy: that copy takes 8 B stores
 	int wave_horiz; // 1: the waves of a workgroup take horizontally adjacent tiles
 };
 
@@ -453,6 +456,21 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 							if (hrow)
 								r1[e] = hi[e];
 						}
+				}
+				// multi-level: the next level's input (even row, even column) also goes
+				// out densely, so that no level has to gather a strided lattice
+				if (a.il_ll) {
+					T *ll = out_ll + (long)k * a.ll_pitch + (c >> 1);
+					if (full && g.ll_vec_ok) {
+#pragma unroll
+						for (int e = 0; e < CPT; e += 4)
+							store_vec<false>((u2 *)(ll + (e >> 1)), u2{to_bits(lo[e]), to_bits(lo[e + 2])});
+					} else {
+#pragma unroll
+						for (int e = 0; e < CPT; e += 2)
+							if (c + e < a.W)
+								ll[e >> 1] = lo[e];
+					}
 				}
 			}
 		} else
@@ -969,8 +987,9 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	if (a.interleaved) {
 		// 3-D path: float 9/7 only; always 4 columns per lane so that each row leaves the
 		// wave as ONE contiguous 16 B/lane store (two strided stores per row cost 40 %)
-		if constexpr (std::is_base_of<Cdf97S, W>::value) {
+		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
 			g.out_vec_ok = aligned16(a.out_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
+			g.ll_vec_ok = a.il_ll && ((uintptr_t)a.out_ll % 8 == 0) && (a.ll_pitch % 2 == 0) && (a.ll_bstride % 2 == 0);
 			if (tt.ring == 16)
 				return fwd_launch<W, 4, 16, 3, true>(a, g, grid, waves, s);
 			return fwd_launch<W, 4, 8, 3, true>(a, g, grid, waves, s);
@@ -1028,7 +1047,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
-		if constexpr (std::is_base_of<Cdf97S, W>::value) {
+		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
 			g.in_vec_ok = aligned16(a.in_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
 			return cpt == 8 ? inv_launch<W, 8, 8, 0, true>(a, g, grid, waves, s) : inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
 		} else {
@@ -1429,6 +1448,7 @@ hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning 
 	case kCdf53S: return fwd_level_t<Cdf53S>(a, t, s);
 	case kCdf97I: return fwd_level_t<Cdf97I>(a, t, s);
 	case kCdf97SFma: return fwd_level_t<Cdf97SFma>(a, t, s);
+	case kCdf53SNew: return a.interleaved ? fwd_level_t<Cdf53SNew>(a, t, s) : hipErrorInvalidValue;
 	default: break; // the double-precision drivers run on the line-pass kernels
 	}
 	return hipErrorInvalidValue;

@@ -128,6 +128,12 @@ struct Cdf53S {
 	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
 };
 
+// dwt-simple.c's 5/3 (fdwt2_cdf53_*, :1031-1078, :1531-1570): same steps, but the odd
+// coefficients are scaled by `1/zeta` computed in float instead of the stored s2.
+struct Cdf53SNew : Cdf53S {
+	static __device__ __forceinline__ T fwd_scale(int parity, T v) { return parity ? v * (1.0f / s1()) : v * s1(); }
+};
+
 // Double precision (src/libdwt.c:2024-2083, 11423-11482; constants src/inline.h:317-323).
 // The reference writes the steps as `a -= p*(l+r)` / `a += u*(l+r)` and scales by the
 // two stored constants s1, s2 = 1/1.1496043988602.

@@ -1,0 +1,209 @@
+"""GPU parity tests of the interleaved (in-place lifting) layout entries, all through the
+C-ABI: libdwt.h dwt_cdf{97,53}_2{f,i}_inplace_s and dwt-simple.h fdwt2_cdf{97,53}_*.
+
+Bars (written here on purpose):
+ * 5/3 `_inplace_` pair: the reference finishes rows before columns -> BIT-EXACT.
+ * 9/7 pair and fdwt2_*: the reference interleaves row and column work in phases; the
+   device finishes the rows first.  Same arithmetic, different fp32 rounding order in
+   the 8-sample border bands: |diff| <= 1e-5 * max|coefficient| (the north star's float
+   tolerance), and the interior is still bit-identical."""
+import numpy as np
+import pytest
+
+from conftest import bits, interleaved_cases
+
+pytestmark = pytest.mark.gpu
+
+CASES = interleaved_cases()
+IDS = [m["name"] for m, _ in CASES]
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dwt():
+    import libdwt_amd as d
+
+    d.dwt_util_init()
+    yield d
+    d.dwt_util_set_accel(0)
+    d.dwt_util_finish()
+
+
+def close(a, b, what):
+    scale = max(1e-30, float(np.abs(b).max()))
+    err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+    assert err <= TOL * scale, f"{what}: max abs diff {err:.3e} vs scale {scale:.3e}"
+
+
+def check(got, want, exact, what):
+    if exact:
+        assert np.array_equal(bits(got), bits(want)), what + " differs from the reference bit pattern"
+    else:
+        close(got, want, what)
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+@pytest.mark.parametrize("wv", ["cdf97", "cdf53"])
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_golden_inplace_entries_host(dwt, case, wv, accel):
+    m, z = case
+    dwt.dwt_util_set_accel(accel)
+    try:
+        buf = z["in"].copy()
+        (sox, soy), (six, siy) = m["size_o"], m["size_i"]
+        fwd = getattr(dwt, f"dwt_{wv}_2f_inplace_s")
+        inv = getattr(dwt, f"dwt_{wv}_2i_inplace_s")
+        j = fwd(buf, buf.strides[0], 4, sox, soy, six, siy, m["j_in"], m["decompose_one"])
+        assert j == m[f"{wv}.j_out"]
+        exact = wv == "cdf53"
+        check(buf, z[f"{wv}.fwd"], exact, "forward")
+        # the inverse is checked on the reference's own coefficients
+        buf = z[f"{wv}.fwd"].copy()
+        inv(buf, buf.strides[0], 4, sox, soy, six, siy, j, m["decompose_one"])
+        check(buf, z[f"{wv}.inv"], exact, "inverse")
+    finally:
+        dwt.dwt_util_set_accel(0)
+
+
+@pytest.mark.parametrize("sched", ["horizontal", "vertical", "diagonal"])
+@pytest.mark.parametrize("wv", ["cdf97", "cdf53"])
+@pytest.mark.parametrize("case", [c for c in CASES if "cdf97.fdwt2" in c[1]], ids=[m["name"] for m, z in CASES if "cdf97.fdwt2" in z])
+def test_golden_fdwt2_host(dwt, case, wv, sched):
+    m, z = case
+    buf = z["in"].copy()
+    w, h = m["size_o"]
+    j = getattr(dwt, f"fdwt2_{wv}_{sched}_s")(buf, w, h, buf.strides[0], 4, m["j_in"], m["decompose_one"])
+    assert j == m[f"{wv}.j_out"]
+    close(buf, z[f"{wv}.fdwt2"], "fdwt2")
+    # pitch padding untouched
+    assert np.array_equal(bits(buf[:, w:]), bits(z["in"][:, w:]))
+
+
+SHAPES = [(512, 512), (1000, 1000), (300, 513), (64, 2048), (2050, 130), (5, 7), (2, 2), (1536, 2048), (1, 300), (300, 1)]
+
+
+def to_device(dwt, a, pitch):
+    h, w = a.shape
+    buf = np.zeros((h, pitch // 4), np.float32)
+    buf[:, :w] = a
+    return dwt.DeviceImage(h, w, 4, pitch).upload(buf)
+
+
+def from_device(img):
+    return img.download(np.float32)[:, :img.w]
+
+
+def _oracle_fwd(oracle, kind, a, j, d1=0):
+    b = a.copy()
+    if kind == "fdwt2_cdf97":
+        return b, oracle.fdwt2("cdf97", b, j, d1)
+    if kind == "fdwt2_cdf53":
+        return b, oracle.fdwt2("cdf53", b, j, d1)
+    jj = oracle.fwd(f"{kind}_2f_inplace_s", b, j, decompose_one=d1)
+    return b, jj
+
+
+@pytest.mark.parametrize("kind", ["cdf97", "cdf53", "fdwt2_cdf97", "fdwt2_cdf53"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("inplace", [True, False], ids=["inplace", "outofplace"])
+def test_device_resident_vs_oracle(dwt, oracle, kind, shape, inplace):
+    h, w = shape
+    rng = np.random.default_rng(h * 7 + w)
+    a = (rng.random((h, w), dtype=np.float32) * 2 - 1)
+    d1 = 1 if min(h, w) == 1 else 0
+    want, jw = _oracle_fwd(oracle, kind, a, -1, d1)
+    flavour = 1 if kind.startswith("fdwt2") else 0
+    wname = "cdf97_s" if kind.endswith("97") else "cdf53_s"
+    pitch = ((w * 4 + 255) // 256) * 256
+    src = to_device(dwt, a, pitch)
+    dst = src if inplace else to_device(dwt, np.full_like(a, 7.0), pitch)
+    j = dwt.transform2d_interleaved(wname, 0, flavour, src.ptr, dst.ptr, pitch, 4, w, h, None, None, -1, d1)
+    assert j == jw
+    got = from_device(dst)
+    exact = kind == "cdf53"
+    check(got, want, exact, "forward")
+    if not inplace:
+        assert np.array_equal(bits(from_device(src)), bits(a)), "source image modified"
+    if min(h, w) > 16:
+        # the interior of level 0 (odd rows / columns are final there) is bit-identical in every flavour
+        gi, wi = got[9:-9, 9:-9], want[9:-9, 9:-9]
+        odd = np.zeros_like(gi, dtype=bool)
+        odd[(np.arange(gi.shape[0]) + 9) % 2 == 1, :] = True
+        odd[:, (np.arange(gi.shape[1]) + 9) % 2 == 1] = True
+        assert np.array_equal(bits(gi)[odd], bits(wi)[odd])
+    if flavour == 0:
+        # inverse of the reference's coefficients, in place on the device
+        rec_want = want.copy()
+        oracle.inv(f"{kind}_2i_inplace_s", rec_want, jw, decompose_one=d1)
+        src.free()
+        src = to_device(dwt, want, pitch)
+        if inplace:
+            dst = src
+        dwt.transform2d_interleaved(wname, 1, 0, src.ptr, dst.ptr, pitch, 4, w, h, None, None, jw, d1)
+        check(from_device(dst), rec_want, exact, "inverse")
+        close(from_device(dst), a, "round trip")
+    src.free()
+    if not inplace:
+        dst.free()
+
+
+@pytest.mark.parametrize("wv", ["cdf97", "cdf53"])
+def test_sparse_frame_and_levels(dwt, oracle, wv):
+    rng = np.random.default_rng(11)
+    a = rng.random((200, 300), dtype=np.float32)
+    for (six, siy, j, d1) in [(300, 200, 3, 0), (250, 160, -1, 0), (33, 200, 2, 1), (300, 1, -1, 1)]:
+        want = a.copy()
+        jw = oracle.fwd(f"{wv}_2f_inplace_s", want, j, size_o=(300, 200), size_i=(six, siy), decompose_one=d1)
+        got = a.copy()
+        jg = getattr(dwt, f"dwt_{wv}_2f_inplace_s")(got, got.strides[0], 4, 300, 200, six, siy, j, d1)
+        assert jg == jw
+        check(got, want, wv == "cdf53", f"sparse forward {six}x{siy}")
+        rec = want.copy()
+        oracle.inv(f"{wv}_2i_inplace_s", rec, jw, size_o=(300, 200), size_i=(six, siy), decompose_one=d1)
+        got = want.copy()
+        getattr(dwt, f"dwt_{wv}_2i_inplace_s")(got, got.strides[0], 4, 300, 200, six, siy, jw, d1)
+        check(got, rec, wv == "cdf53", f"sparse inverse {six}x{siy}")
+
+
+def test_full_size_round_trip_and_linearity(dwt):
+    """8192^2, 5 levels, device resident: properties that need no CPU transform of the image."""
+    n, J = 8192, 5
+    rng = np.random.default_rng(42)
+    a = rng.random((n, n), dtype=np.float32)
+    b = rng.random((n, n), dtype=np.float32)
+    out = {}
+    src = dwt.DeviceImage(n, n)
+    dst = dwt.DeviceImage(n, n)
+    for name, t in (("a", a), ("b", b), ("ab", a + 2 * b)):
+        src.upload(t)
+        assert dwt.transform2d_interleaved("cdf97_s", 0, 0, src.ptr, dst.ptr, n * 4, 4, n, n, None, None, J) == J
+        out[name] = dst.download(np.float32)
+    lin = np.abs(out["ab"] - (out["a"] + 2 * out["b"])).max()
+    assert lin <= 1e-4 * np.abs(out["ab"]).max()
+    # in-place inverse of the coefficients of a
+    src.upload(out["a"])
+    dwt.transform2d_interleaved("cdf97_s", 1, 0, src.ptr, src.ptr, n * 4, 4, n, n, None, None, J)
+    assert np.abs(src.download(np.float32) - a).max() < 1e-4
+    # the level-0 detail samples equal the Mallat transform's bit for bit (same sweep arithmetic)
+    src.upload(a)
+    dwt.transform2d_batch("cdf97_s", 0, src.ptr, dst.ptr, n * n * 4, 1, n * 4, n, n, J)
+    mal = dst.download(np.float32)
+    h = n // 2
+    assert np.array_equal(bits(out["a"][1::2, 1::2]), bits(mal[h:, h:]))  # HH
+    assert np.array_equal(bits(out["a"][0::2, 1::2]), bits(mal[:h, h:]))  # HL
+    assert np.array_equal(bits(out["a"][1::2, 0::2]), bits(mal[h:, :h]))  # LH
+    # and the deepest LL band sits on the stride-2^J lattice
+    q = n >> J
+    assert np.array_equal(bits(out["a"][:: 1 << J, :: 1 << J]), bits(mal[:q, :q]))
+    src.free()
+    dst.free()
+
+
+def test_errors(dwt):
+    a = np.zeros((8, 8), np.float32)
+    with pytest.raises(dwt.DwtError):
+        dwt.transform2d_interleaved("cdf53_i", 0, 0, a, a, 32, 4, 8, 8)
+    with pytest.raises(dwt.DwtError):
+        dwt.transform2d_interleaved("cdf97_s", 1, 1, a, a, 32, 4, 8, 8)
+    with pytest.raises(dwt.DwtError):
+        dwt.transform2d_interleaved("cdf97_s", 0, 0, a, a, 32, 4, 8, 8, 9, 8)

@@ -29,20 +29,20 @@ def declared_functions(header):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     text = re.sub(r"enum\s+\w+\s*\{.*?\};", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dwt_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:dwt|fdwt2)_\w+)\s*\(", text)))
 
 
-@pytest.mark.parametrize("header", ["libdwt.h", "libdwt_hip.h"])
+@pytest.mark.parametrize("header", ["libdwt.h", "libdwt_hip.h", "dwt-simple.h"])
 def test_exports_every_declared_symbol(dwt, header):
     names = declared_functions(header)
-    assert len(names) > 15
+    assert len(names) > (15 if header != "dwt-simple.h" else 5)
     missing = [n for n in names if not hasattr(dwt.lib, n)]
     assert not missing, missing
 
 
 def test_headers_compile_as_c99_and_cxx(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "libdwt.h"\n#include "libdwt_hip.h"\nint main(void){int j=-1;(void)j;return 0;}\n')
+    src.write_text('#include "libdwt.h"\n#include "libdwt_hip.h"\n#include "dwt-simple.h"\nint main(void){int j=-1;(void)j;return 0;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", INCLUDE, "-c", str(src), "-o", str(tmp_path / "t.o")])
     subprocess.check_call(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-I", INCLUDE, "-c", str(src), "-o", str(tmp_path / "t2.o")])
 
@@ -126,7 +126,7 @@ def test_conv_show_copy_pgm(dwt, tmp_path):
 
 def test_reference_examples_link_unchanged(dwt, tmp_path):
     """The reference's own programs around the path -- examples/simple, simple-int,
-    simple-perf, subbands, perf-plot -- compile against include/libdwt.h and link against
+    simple-perf, subbands, perf-plot, simple-newapi -- compile against include/*.h and link against
     libdwt_hip.so without modification."""
     ref = "/root/reference/examples"
     if not os.path.isdir(ref):
@@ -134,7 +134,7 @@ def test_reference_examples_link_unchanged(dwt, tmp_path):
     libdir = os.path.join(ROOT, "libdwt_amd")
     import glob
 
-    for ex in ("simple", "simple-int", "simple-perf", "subbands", "perf-plot"):
+    for ex in ("simple", "simple-int", "simple-perf", "subbands", "perf-plot", "simple-newapi"):
         exe = tmp_path / (ex + ".bin")
         src = sorted(glob.glob(os.path.join(ref, ex, "*.c")))[0]
         subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", INCLUDE, src,

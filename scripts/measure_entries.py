@@ -30,6 +30,11 @@ def main():
     m = timeit(lambda: dwt.dwt_cdf97_2f_s(c, n*4, 4, n, n, n, n, J)); rep("cdf97 fwd 8192^2 J=5 single image, in-place", *m, n*n, alg)
     m = timeit(lambda: dwt.dwt_cdf97_2i_s2(b, c, n*4, 4, n, n, n, n, J)); rep("cdf97 inv 8192^2 J=5 single image, out-of-place (_s2)", *m, n*n, alg)
     m = timeit(lambda: dwt.dwt_cdf97_2i_s(c, n*4, 4, n, n, n, n, J)); rep("cdf97 inv 8192^2 J=5 single image, in-place", *m, n*n, alg)
+    # interleaved (in-place lifting) layout
+    m = timeit(lambda: dwt.transform2d_interleaved("cdf97_s", 0, 0, a, b, n*4, 4, n, n, None, None, J)); rep("cdf97 interleaved fwd 8192^2 J=5, out-of-place", *m, n*n, alg)
+    m = timeit(lambda: dwt.dwt_cdf97_2f_inplace_s(c, n*4, 4, n, n, n, n, J)); rep("cdf97 interleaved fwd 8192^2 J=5, in-place", *m, n*n, alg)
+    m = timeit(lambda: dwt.transform2d_interleaved("cdf97_s", 1, 0, b, c, n*4, 4, n, n, None, None, J)); rep("cdf97 interleaved inv 8192^2 J=5, out-of-place", *m, n*n, alg)
+    m = timeit(lambda: dwt.dwt_cdf97_2i_inplace_s(c, n*4, 4, n, n, n, n, J)); rep("cdf97 interleaved inv 8192^2 J=5, in-place", *m, n*n, alg)
     nb = 8
     A = torch.rand((nb, n, n), device="cuda"); B = torch.empty_like(A)
     m = timeit(lambda: dwt.transform2d_batch("cdf97_s", 0, A, B, n*n*4, nb, n*4, n, n, J)); rep(f"cdf97 fwd 8192^2 J=5 batch of {nb}", *m, nb*n*n, nb*alg)

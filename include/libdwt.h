@@ -153,6 +153,16 @@ int dwt_util_save_to_pgm_s(const char *filename, float max_value, const void *pt
 	int size_i_big_x, int size_i_big_y);
 int dwt_util_save_to_pgm_i(const char *filename, int max_value, const void *ptr, int stride_x, int stride_y,
 	int size_i_big_x, int size_i_big_y);
+/* ASCII PGM readers: allocate the image with the optimal stride (src/libdwt.h:1894, 1926);
+ * 0 on success, 1 open, 2 header, 3 depth, 4 data, 5 sample out of range */
+int dwt_util_load_from_pgm_s(const char *filename, float max_value, void **pptr, int *pstride_x, int *pstride_y,
+	int *psize_x, int *psize_y);
+int dwt_util_load_from_pgm_i(const char *filename, int max_value, void **pptr, int *pstride_x, int *pstride_y,
+	int *psize_x, int *psize_y);
+/* text matrices ("MAT": one row per line, comma separated), src/libdwt.h:1829, 1909, 1951 */
+int dwt_util_save_to_mat_s(const char *path, const void *ptr, int size_x, int size_y, int stride_x, int stride_y);
+int dwt_util_load_from_mat_s(const char *path, void **ptr, int *size_x, int *size_y, int *stride_x, int *stride_y);
+int dwt_util_load_from_mat_i(const char *path, void **ptr, int *size_x, int *size_y, int *stride_x, int *stride_y);
 
 /* ---- subband addressing (src/libdwt.h:2276-2330, src/libdwt.c:20731-20950) -------- */
 enum dwt_subbands { DWT_LL, DWT_HL, DWT_LH, DWT_HH };

@@ -140,3 +140,83 @@ def test_reference_examples_link_unchanged(dwt, tmp_path):
         subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", INCLUDE, src,
                                "-o", str(exe), "-L", libdir, "-l:libdwt_hip.so", "-Wl,-rpath," + libdir, "-lm"])
         assert exe.exists()
+
+
+def _io_sigs(lib):
+    import ctypes as C
+    P, I = C.c_void_p, C.c_int
+    PI = C.POINTER(I)
+    lib.dwt_util_load_from_pgm_s.argtypes = [C.c_char_p, C.c_float, C.POINTER(P), PI, PI, PI, PI]
+    lib.dwt_util_load_from_pgm_i.argtypes = [C.c_char_p, I, C.POINTER(P), PI, PI, PI, PI]
+    lib.dwt_util_save_to_mat_s.argtypes = [C.c_char_p, P, I, I, I, I]
+    lib.dwt_util_load_from_mat_s.argtypes = [C.c_char_p, C.POINTER(P), PI, PI, PI, PI]
+    lib.dwt_util_load_from_mat_i.argtypes = [C.c_char_p, C.POINTER(P), PI, PI, PI, PI]
+    lib.dwt_util_save_to_pgm_s.argtypes = [C.c_char_p, C.c_float, P, I, I, I, I]
+    lib.dwt_util_free_image.argtypes = [C.POINTER(P)]
+    for n in ("dwt_util_load_from_pgm_s", "dwt_util_load_from_pgm_i", "dwt_util_save_to_mat_s", "dwt_util_load_from_mat_s",
+              "dwt_util_load_from_mat_i", "dwt_util_save_to_pgm_s"):
+        getattr(lib, n).restype = I
+
+
+def _load(lib, fn, path, dtype, *lead, mat=False):
+    """Call a loader; returns (rc, array copy or None, (stride_x, stride_y))."""
+    import ctypes as C
+    ptr = C.c_void_p()
+    a, b, c, d = (C.c_int() for _ in range(4))
+    rc = getattr(lib, fn)(path.encode(), *lead, C.byref(ptr), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+    if rc or not ptr.value:
+        return rc, None, None
+    # PGM loaders: stride_x, stride_y, size_x, size_y; MAT loaders: size_x, size_y, stride_x, stride_y
+    sx, sy, w, h = (c.value, d.value, a.value, b.value) if mat else (a.value, b.value, c.value, d.value)
+    raw = (C.c_char * (sx * h)).from_address(ptr.value)
+    buf = np.frombuffer(raw, dtype=np.uint8).copy()
+    img = np.stack([np.frombuffer(buf[y * sx:y * sx + w * 4].tobytes(), dtype=dtype) for y in range(h)]) if h and w else np.zeros((h, w), dtype)
+    lib.dwt_util_free_image(C.byref(ptr))
+    return rc, img, (sx, sy)
+
+
+def test_pgm_and_mat_io_match_reference(dwt, reference, tmp_path):
+    """File IO around the path: same bytes out, same images in."""
+    import ctypes as C
+    _io_sigs(dwt.lib)
+    _io_sigs(reference.lib)
+    rng = np.random.default_rng(9)
+    a = (rng.random((13, 17), dtype=np.float32) * 3 - 1).astype(np.float32)
+    outs = []
+    for tag, lib in (("ours", dwt.lib), ("ref", reference.lib)):
+        p = str(tmp_path / f"{tag}.mat")
+        assert lib.dwt_util_save_to_mat_s(p.encode(), a.ctypes.data, 17, 13, a.strides[0], 4) == 0
+        outs.append(open(p, "rb").read())
+    assert outs[0] == outs[1]
+    mat = tmp_path / "hand.mat"
+    mat.write_text("1.5,2;3\t4 5\n-1e1,+2.25,7,8\n\n9;10;11\n12,13,14\n")  # ragged rows, empty line, mixed delimiters
+    mati = tmp_path / "hand_i.mat"
+    mati.write_text("1,2;3\t4 5\n-10,225,7,8\n\n9;10;11\n12,13,14\n")
+    pgm = tmp_path / "hand.pgm"
+    pgm.write_text("P2\n# a comment\n5 3 # width height\n1000\n" + " ".join(str((i * 77) % 1001) for i in range(15)) + "\n")
+    for fn, path, dt, lead, is_mat in (("dwt_util_load_from_mat_s", str(tmp_path / "ref.mat"), np.float32, (), True),
+                                       ("dwt_util_load_from_mat_s", str(mat), np.float32, (), True),
+                                       ("dwt_util_load_from_mat_i", str(mati), np.int32, (), True),
+                                       ("dwt_util_load_from_pgm_s", str(pgm), np.float32, (C.c_float(2.5),), False),
+                                       ("dwt_util_load_from_pgm_i", str(pgm), np.int32, (255,), False)):
+        r0, i0, s0 = _load(dwt.lib, fn, path, dt, *lead, mat=is_mat)
+        r1, i1, s1 = _load(reference.lib, fn, path, dt, *lead, mat=is_mat)
+        assert r0 == r1 == 0, fn
+        assert s0 == s1 and i0.shape == i1.shape, (fn, s0, s1, i0.shape, i1.shape)
+        assert np.array_equal(i0.view(np.uint32), i1.view(np.uint32)), fn
+    # a last line without a newline is not counted as a row (the reference writes past the image there)
+    cut = tmp_path / "cut.mat"
+    cut.write_text("1,2\n3,4")
+    rc, img, _ = _load(dwt.lib, "dwt_util_load_from_mat_s", str(cut), np.float32, mat=True)
+    assert rc == 0 and img.shape == (1, 2) and img.tolist() == [[1.0, 2.0]]
+    # error codes
+    bad = tmp_path / "bad.pgm"
+    bad.write_text("P5\n1 1\n255\n0\n")
+    assert _load(dwt.lib, "dwt_util_load_from_pgm_s", str(bad), np.float32, C.c_float(1.0))[0] == 2
+    assert _load(dwt.lib, "dwt_util_load_from_pgm_s", str(tmp_path / "missing.pgm"), np.float32, C.c_float(1.0))[0] == 1
+    deep = tmp_path / "deep.pgm"
+    deep.write_text("P2\n1 1\n70000\n0\n")
+    assert _load(dwt.lib, "dwt_util_load_from_pgm_i", str(deep), np.int32, 255)[0] == 3
+    badm = tmp_path / "bad.mat"
+    badm.write_text("1,2\nx,3\n")
+    assert _load(dwt.lib, "dwt_util_load_from_mat_s", str(badm), np.float32, mat=True)[0] == 2

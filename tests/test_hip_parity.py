@@ -595,3 +595,23 @@ def test_finish_releases_and_context_stays_usable(dwt, oracle):
         d.free()
         dwt.dwt_util_finish()
     dwt.dwt_util_init()
+
+
+def test_extreme_shapes_fused_equals_line_passes():
+    """Maximum sizes (SURVEY s8c edge cases): 32768^2 (4 GiB), 64 x 2^20, 2^20 x 64, odd
+    70001-wide rows, 12 levels: the fused sweeps equal the exact line-pass kernels bit for
+    bit and the round trip closes.  Own process (torch supplies the device tensors)."""
+    import os
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "large_sanity.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "round-trip" in l]
+    assert len(lines) == 5, out.stdout
+    for l in lines:
+        assert "fused == line passes: True" in l, l
+        err = float(l.rsplit(" ", 1)[1])
+        assert err == 0.0 if "cdf53_i" in l else err < 1e-5, l

@@ -968,9 +968,12 @@ struct IlLevel {
 };
 
 // one level on dense images with a common pitch: rows completely, then columns
-static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch)
+static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
+	const Img *even_rows = nullptr)
 {
 	const bool fused = !g.force_generic && lx >= 2 && ly >= 2 && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
+	if (even_rows && !fused)
+		return fail("internal: split rows need the fused sweep");
 	if (fused) {
 		hipError_t e;
 		if (!inverse) {
@@ -982,8 +985,9 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 			e = launch_fwd_level(w, a, g.tune, g.stream);
 		} else {
 			InvLevelArgs a;
-			a.in_ll = in.p; a.ll_pitch = in.sx / 4; a.ll_bstride = 0;
-			a.in_h = in.p; a.h_pitch = in.sx / 4; a.h_bstride = 0;
+			// the even rows may live in a buffer of their own (packed), see interleaved2d
+			a.in_ll = even_rows ? even_rows->p : in.p; a.ll_pitch = even_rows ? even_rows->sx / 4 : in.sx / 4 * 2; a.ll_bstride = 0;
+			a.in_h = in.p + in.sx; a.h_pitch = in.sx / 4 * 2; a.h_bstride = 0;
 			a.out = out.p; a.out_pitch = out.sx / 4; a.out_bstride = 0;
 			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1;
 			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream);
@@ -1030,7 +1034,8 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 		return 1;
 	const bool alias = src.p == dst.p;
 	// everything outside the transformed region keeps the caller's values
-	if (!alias && (J == 0 || six < sox || siy < soy || inverse) && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))
+	const bool sparse = six < sox || siy < soy;
+	if (!alias && (J == 0 || sparse) && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))
 		return 1;
 	if (J == 0 || six < 1 || siy < 1)
 		return 0;
@@ -1062,12 +1067,6 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			return fail("lattice scatter failed: %s", hipGetErrorString(e));
 		return 0;
 	};
-	auto gather = [&](const char *from, long from_pitch_bytes, long step, float *to, const IlLevel &l) -> int {
-		hipError_t e = launch_lattice_copy((const float *)from, step, from_pitch_bytes / 4 * step, 0, to, 1, l.pitch, 0, l.lx, l.ly, 1, g.stream);
-		if (e != hipSuccess)
-			return fail("lattice gather failed: %s", hipGetErrorString(e));
-		return 0;
-	};
 	// level 0 works on the caller's image; in place it detours through the staging image
 	Img stage{nullptr, dst.sx, 4};
 	if (alias || inverse) {
@@ -1075,6 +1074,20 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			return 1;
 		stage.p = (char *)g.stage_img;
 	}
+
+	auto pyramid = [&](bool results, int levels) {
+		IlPyramid py;
+		py.J = levels;
+		for (int j = 1; j < levels; j++) {
+			py.p[j] = results ? L[j].b : L[j].a;
+			py.pitch[j] = L[j].pitch;
+		}
+		return py;
+	};
+	// rows 1, 3, 5, ... of the transformed region from one image to another
+	auto copy_odd_rows = [&](Img to, Img from) -> int {
+		return copy_rect(Img{to.p + to.sx, to.sx * 2, 4}, 0, 0, Img{from.p + from.sx, from.sx * 2, 4}, 0, 0, six, siy / 2);
+	};
 
 	if (!inverse) {
 		for (int j = 0; j < J; j++) {
@@ -1084,31 +1097,56 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0))
 				return 1;
 		}
-		if (alias && copy_rect(dst, 0, 0, stage, 0, 0, six, siy))
+		if (J == 1)
+			return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
+		// the even rows receive the samples of the levels >= 1 in ONE pass (in place that pass
+		// also brings them back from the staging image; the odd rows are final after level 0)
+		if (alias && copy_odd_rows(dst, stage))
 			return 1;
-		for (int j = 1; j < J; j++)
-			if (scatter(L[j].b, L[j].pitch, dst.p, dst.sx, 1L << j, L[j]))
-				return 1;
+		const Img base = alias ? stage : dst;
+		hipError_t e = launch_il_compose((const float *)base.p, base.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream);
+		if (e != hipSuccess)
+			return fail("interleaved compose failed: %s", hipGetErrorString(e));
 		return 0;
 	}
-	// inverse: dst already holds the coefficients (copied above when out of place)
-	for (int j = 1; j < J; j++)
-		if (gather(dst.p, dst.sx, 1L << j, L[j].a, L[j]))
+	// inverse: the coefficients are read from the source image (never modified before the last
+	// sweep has read it, so out of place needs no copy)
+	const Img cin = src;
+	if (J == 1) {
+		if (!alias)
+			return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0);
+		if (il_level(w, true, scale_single, dst, stage, L[0].lx, L[0].ly, nullptr, 0))
 			return 1;
+		return copy_rect(dst, 0, 0, stage, 0, 0, six, siy);
+	}
+	hipError_t e = launch_il_decompose((const float *)cin.p, cin.sx / 4, six, siy, pyramid(false, J), g.stream);
+	if (e != hipSuccess)
+		return fail("interleaved decompose failed: %s", hipGetErrorString(e));
 	for (int j = J - 1; j >= 1; j--) {
 		if (il_level(w, true, scale_single, dense(L[j].a, L[j]), dense(L[j].b, L[j]), L[j].lx, L[j].ly, nullptr, 0))
 			return 1;
 		// the reconstructed low-pass band is the even-even lattice of the level above
-		if (j >= 2) {
-			if (scatter(L[j].b, L[j].pitch, (char *)L[j - 1].a, L[j - 1].pitch * 4, 2, L[j]))
-				return 1;
-		} else if (scatter(L[j].b, L[j].pitch, dst.p, dst.sx, 2, L[j])) {
+		if (j >= 2 && scatter(L[j].b, L[j].pitch, (char *)L[j - 1].a, L[j - 1].pitch * 4, 2, L[j]))
 			return 1;
-		}
 	}
-	if (il_level(w, true, scale_single, dst, stage, L[0].lx, L[0].ly, nullptr, 0))
+	// level 0.  Out of place (fused sweep): odd rows straight from the coefficient image, even
+	// rows from a packed copy that carries the reconstructed LL band (one compose pass).  In
+	// place the sweep must not read what it overwrites: its whole input is built in the staging
+	// image (odd rows copied, even rows composed) and the sweep writes the caller's image.
+	const bool split = !alias && !g.force_generic && L[0].lx >= 2 && L[0].ly >= 2;
+	if (split) {
+		const Img even{stage.p, stage.sx, 4}; // (siy+1)/2 packed rows
+		e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)even.p, even.sx / 4, six, siy, pyramid(true, 2), g.stream, true);
+		if (e != hipSuccess)
+			return fail("interleaved compose failed: %s", hipGetErrorString(e));
+		return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0, &even);
+	}
+	if (copy_odd_rows(stage, cin))
 		return 1;
-	return copy_rect(dst, 0, 0, stage, 0, 0, six, siy);
+	e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)stage.p, stage.sx / 4, six, siy, pyramid(true, 2), g.stream);
+	if (e != hipSuccess)
+		return fail("interleaved compose failed: %s", hipGetErrorString(e));
+	return il_level(w, true, scale_single, stage, dst, L[0].lx, L[0].ly, nullptr, 0);
 }
 
 int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const void *src, void *dst, int stride_x, int stride_y,
@@ -1323,8 +1361,8 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 			e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
 		} else {
 			InvLevelArgs a;
-			a.in_ll = b.p; a.ll_pitch = b.sy; a.ll_bstride = b.sz;
-			a.in_h = b.p; a.h_pitch = b.sy; a.h_bstride = b.sz;
+			a.in_ll = b.p; a.ll_pitch = 2 * b.sy; a.ll_bstride = b.sz;
+			a.in_h = b.p + b.sy; a.h_pitch = 2 * b.sy; a.h_bstride = b.sz;
 			a.out = S; a.out_pitch = s_sy; a.out_bstride = s_sz;
 			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
 			e = launch_inv_level(kCdf97S, a, g.tune, g.stream);

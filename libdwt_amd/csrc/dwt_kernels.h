@@ -56,7 +56,7 @@ struct InvLevelArgs {
 	void *out;
 	long out_pitch, out_bstride;
 	int W, H, batch;
-	int interleaved = 0; // 1: read an interleaved image from in_h (3-D path layout)
+	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
 };
 
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
@@ -105,6 +105,22 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 // strides in ELEMENTS, including the x strides.
 hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
 	int nx, int ny, int nz, hipStream_t s);
+
+// Interleaved (in-place lifting) layout, multi-level: the dense per-level images of the
+// levels 1..J-1 (level j has ceil(W/2^j) x ceil(H/2^j) samples and lives on the stride-2^j
+// lattice of the W x H image).  Pitches in ELEMENTS.
+struct IlPyramid {
+	float *p[24];
+	long pitch[24];
+	int J; // levels 1 .. J-1 are valid
+};
+// compose: even rows of `out` = even rows of `base` with every lattice point replaced by
+// the sample of the deepest level (< J) that owns it.  base may equal out.  out_dense: `out`
+// holds only the even rows, packed (row q of `out` = image row 2q).
+hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H,
+	const IlPyramid &py, hipStream_t s, bool out_dense = false);
+// decompose: every level's lattice gathered from `img` into its dense image, one pass
+hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s);
 
 // device-side view helpers: pitch in BYTES, 4-byte elements
 hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s);

@@ -609,7 +609,9 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 			for (int rr = 0; rr < 2; rr++) {
 				const int r = reflect(2 * p + rr, a.H);
 				char *lrow = ring + (size_t)((2 * it + rr) & (kRing - 1)) * RS * 4;
-				const T *grow = in_h + (long)r * a.h_pitch;
+				// even rows come from in_ll, odd rows from in_h (reflection keeps the parity): the
+				// two may be different buffers (multi-level inverse: composed even rows)
+				const T *grow = (r & 1) ? in_h + (long)(r >> 1) * a.h_pitch : in_ll + (long)(r >> 1) * a.ll_pitch;
 				if (main16) {
 #pragma unroll
 					for (int i = 0; i < CPT / 4; i++)
@@ -1048,7 +1050,8 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
 		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
-			g.in_vec_ok = aligned16(a.in_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
+			g.in_vec_ok = aligned16(a.in_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0) &&
+				aligned16(a.in_ll) && (a.ll_pitch % 4 == 0) && (a.ll_bstride % 4 == 0);
 			return cpt == 8 ? inv_launch<W, 8, 8, 0, true>(a, g, grid, waves, s) : inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
 		} else {
 			return hipErrorInvalidValue;
@@ -1669,10 +1672,11 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 }
 
 __global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ src, long s_sx, long s_sy, long s_sz,
-	float *__restrict__ dst, long d_sx, long d_sy, long d_sz, int nx, int ny)
+	float *__restrict__ dst, long d_sx, long d_sy, long d_sz, int nx, int ny, int nxb)
 {
-	const int x = blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = blockIdx.y, z = blockIdx.z;
+	// grid.x = column blocks x rows (rows can exceed the 65535 limit of grid.y), grid.y = slices
+	const int x = (blockIdx.x % nxb) * blockDim.x + threadIdx.x;
+	const int y = blockIdx.x / nxb, z = blockIdx.y;
 	if (x < nx && y < ny)
 		dst[(long)z * d_sz + (long)y * d_sy + (long)x * d_sx] = src[(long)z * s_sz + (long)y * s_sy + (long)x * s_sx];
 }
@@ -1680,10 +1684,131 @@ __global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ 
 hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
 	int nx, int ny, int nz, hipStream_t s)
 {
-	if (nx < 1 || ny < 1 || nz < 1 || ny > 65535 || nz > 65535)
+	const int nxb = (nx + 255) / 256;
+	if (nx < 1 || ny < 1 || nz < 1 || nz > 65535 || (long)nxb * ny > 0x7fffffffL)
 		return hipErrorInvalidValue;
-	dim3 grid((nx + 255) / 256, ny, nz);
-	k_lattice_copy<<<grid, 256, 0, s>>>(src, s_sx, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny);
+	dim3 grid(nxb * ny, nz);
+	k_lattice_copy<<<grid, 256, 0, s>>>(src, s_sx, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny, nxb);
+	return hipGetLastError();
+}
+
+// ---- interleaved layout: all levels' lattices in one pass over the even rows ----
+// A lattice-1 point (p, q) (image column 2p, row 2q) belongs to level
+// j = 1 + min(ctz(p), ctz(q)) capped at J-1; its sample sits at (p >> (j-1), q >> (j-1))
+// of that level's dense image.  One thread owns 8 image columns of one even row.
+static __device__ __forceinline__ int il_level_of(int p, int q, int J)
+{
+	const int t = __builtin_ctz((unsigned)(p | q) | (1u << 30)); // ctz(0) -> 30
+	const int j = 1 + t;
+	return j < J ? j : J - 1;
+}
+
+__global__ __launch_bounds__(256) void k_il_compose(const float *__restrict__ base, long base_pitch, float *__restrict__ out,
+	long out_pitch, int W, int H, IlPyramid py, int vec_ok, int out_dense)
+{
+	// grid.x = even rows (may exceed 65535), grid.y = blocks of 2048 columns
+	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
+	const int q = blockIdx.x, y = 2 * q;
+	if (x0 >= W || y >= H)
+		return;
+	const float *b = base + (long)y * base_pitch + x0;
+	float *o = out + (long)(out_dense ? q : y) * out_pitch + x0;
+	const int p0 = x0 >> 1;
+	float v[8];
+	const bool vec = vec_ok && x0 + 8 <= W;
+	if (vec) {
+		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			v[e] = from_bits<float>(t0[e]);
+			v[4 + e] = from_bits<float>(t1[e]);
+		}
+		const u4 l1 = *(const u4 *)(py.p[1] + (long)q * py.pitch[1] + p0);
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			v[2 * i] = from_bits<float>(l1[i]);
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			if (x0 + e < W)
+				v[e] = (e & 1) ? b[e] : py.p[1][(long)q * py.pitch[1] + p0 + (e >> 1)];
+	}
+	if (py.J > 2 && !(q & 1)) {
+		// p0 is a multiple of 4: the points p0 and p0+2 lie on deeper lattices
+#pragma unroll
+		for (int i = 0; i < 4; i += 2)
+			if (x0 + 2 * i < W) {
+				const int p = p0 + i, j = il_level_of(p, q, py.J);
+				v[2 * i] = py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + (p >> (j - 1))];
+			}
+	}
+	if (vec) {
+		*(u4 *)o = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
+		*(u4 *)(o + 4) = u4{to_bits(v[4]), to_bits(v[5]), to_bits(v[6]), to_bits(v[7])};
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			if (x0 + e < W)
+				o[e] = v[e];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_il_decompose(const float *__restrict__ img, long pitch, int W, int H, IlPyramid py, int vec_ok)
+{
+	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
+	const int q = blockIdx.x, y = 2 * q;
+	if (x0 >= W || y >= H)
+		return;
+	const float *b = img + (long)y * pitch + x0;
+	const int p0 = x0 >> 1;
+	float v[4];
+	const bool vec = vec_ok && x0 + 8 <= W;
+	if (vec) {
+		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
+		v[0] = from_bits<float>(t0[0]); v[1] = from_bits<float>(t0[2]);
+		v[2] = from_bits<float>(t1[0]); v[3] = from_bits<float>(t1[2]);
+		*(u4 *)(py.p[1] + (long)q * py.pitch[1] + p0) = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			if (x0 + 2 * i < W) {
+				v[i] = b[2 * i];
+				py.p[1][(long)q * py.pitch[1] + p0 + i] = v[i];
+			}
+	}
+	// deeper lattices: level j takes the points whose p and q are multiples of 2^(j-1)
+	for (int j = 2; j < py.J; j++) {
+		const int m = (1 << (j - 1)) - 1;
+		if (q & m)
+			break;
+#pragma unroll
+		for (int i = 0; i < 4; i += 2)
+			if (!((p0 + i) & m) && x0 + 2 * i < W)
+				py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + ((p0 + i) >> (j - 1))] = v[i];
+	}
+}
+
+static int il_vec_ok(const float *a, long ap, const float *b, long bp, const IlPyramid &py)
+{
+	return aligned16(a) && aligned16(b) && ap % 4 == 0 && bp % 4 == 0 && py.J > 1 && aligned16(py.p[1]) && py.pitch[1] % 4 == 0;
+}
+
+hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H, const IlPyramid &py, hipStream_t s,
+	bool out_dense)
+{
+	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
+		return hipErrorInvalidValue;
+	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
+	k_il_compose<<<grid, 256, 0, s>>>(base, base_pitch, out, out_pitch, W, H, py, il_vec_ok(base, base_pitch, out, out_pitch, py), out_dense);
+	return hipGetLastError();
+}
+
+hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s)
+{
+	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
+		return hipErrorInvalidValue;
+	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
+	k_il_decompose<<<grid, 256, 0, s>>>(img, pitch, W, H, py, il_vec_ok(img, pitch, img, pitch, py));
 	return hipGetLastError();
 }
 

@@ -610,7 +610,7 @@ def test_extreme_shapes_fused_equals_line_passes():
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "large_sanity.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if "round-trip" in l]
-    assert len(lines) == 5, out.stdout
+    assert len(lines) == 9, out.stdout
     for l in lines:
         assert "fused == line passes: True" in l, l
         err = float(l.rsplit(" ", 1)[1])

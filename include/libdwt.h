@@ -148,6 +148,14 @@ int dwt_util_compare_i(void *ptr1, void *ptr2, int stride_x, int stride_y, int s
 /* log-magnitude view of a transform, src/libdwt.c:21075, 21020 */
 void dwt_util_conv_show_s(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
 void dwt_util_conv_show_i(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+/* double-precision twins (examples/simple-double): pattern with 0-based x, y
+ * (src/libdwt.c:1112-1125), copy, compare within 1e-6 absolute, view, PGM writer */
+void dwt_util_test_image_fill_d(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand);
+void dwt_util_copy_d(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+int dwt_util_compare_d(void *ptr1, void *ptr2, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+void dwt_util_conv_show_d(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
+int dwt_util_save_to_pgm_d(const char *filename, double max_value, const void *ptr, int stride_x, int stride_y,
+	int size_i_big_x, int size_i_big_y);
 /* ASCII PGM writers, src/libdwt.h:1755, 1783; return 0 on success */
 int dwt_util_save_to_pgm_s(const char *filename, float max_value, const void *ptr, int stride_x, int stride_y,
 	int size_i_big_x, int size_i_big_y);
@@ -203,6 +211,16 @@ int dwt_util_test_cdf97_2_s2(int stride_x, int stride_y, int size_o_big_x, int s
 	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding);
 int dwt_util_test2_cdf97_2_s(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one);
 int dwt_util_test2_cdf97_2_s2(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one);
+/* the same self-tests for the double and the fixed-point int 9/7 drivers (src/libdwt.h:2688,
+ * 2703, 2727, 2739; examples/test/test.c:61-73) */
+void dwt_util_get_sizes_d(enum dwt_array array_type, int size_x, int size_y, int opt_stride,
+	int *stride_x, int *stride_y, int *size_o_big_x, int *size_o_big_y, int *size_i_big_x, int *size_i_big_y);
+int dwt_util_test_cdf97_2_d(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding);
+int dwt_util_test_cdf97_2_i(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding);
+int dwt_util_test2_cdf97_2_d(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one);
+int dwt_util_test2_cdf97_2_i(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one);
 
 /* ---- timers (src/libdwt.h:1589-1658) --------------------------------------------- */
 enum dwt_timer_types {

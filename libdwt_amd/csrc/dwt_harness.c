@@ -53,6 +53,13 @@ void dwt_util_get_sizes_i(enum dwt_array array_type, int size_x, int size_y, int
 		size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y);
 }
 
+void dwt_util_get_sizes_d(enum dwt_array array_type, int size_x, int size_y, int opt_stride,
+	int *stride_x, int *stride_y, int *size_o_big_x, int *size_o_big_y, int *size_i_big_x, int *size_i_big_y)
+{
+	get_sizes(sizeof(double), array_type, size_x, size_y, opt_stride, stride_x, stride_y,
+		size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y);
+}
+
 typedef void (*fwd_fn)(void *, int, int, int, int, int, int, int *, int, int);
 typedef void (*inv_fn)(void *, int, int, int, int, int, int, int, int, int);
 
@@ -205,6 +212,56 @@ int dwt_util_test_cdf97_2_s2(int stride_x, int stride_y, int size_o_big_x, int s
 }
 
 /* src/libdwt.c:24163-24201 */
+/* the same self-test for the double and the fixed-point int 9/7 drivers
+ * (src/libdwt.c:23877-23960 double, :23962-24045 int; examples/test/test.c:61-73) */
+int dwt_util_test_cdf97_2_d(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding)
+{
+	int j = j_max;
+	void *data, *copy;
+	dwt_util_alloc_image(&data, stride_x, stride_y, size_o_big_x, size_o_big_y);
+	dwt_util_alloc_image(&copy, stride_x, stride_y, size_o_big_x, size_o_big_y);
+	dwt_util_test_image_fill_d(data, stride_x, stride_y, size_i_big_x, size_i_big_y, 0);
+	dwt_util_copy_d(data, copy, stride_x, stride_y, size_i_big_x, size_i_big_y);
+	dwt_cdf97_2f_d(data, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y, &j, decompose_one, zero_padding);
+	dwt_cdf97_2i_d(data, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y, j, decompose_one, zero_padding);
+	const int ret = dwt_util_compare_d(data, copy, stride_x, stride_y, size_i_big_x, size_i_big_y) ? 1 : 0;
+	dwt_util_free_image(&data);
+	dwt_util_free_image(&copy);
+	return ret;
+}
+
+int dwt_util_test_cdf97_2_i(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding)
+{
+	int j = j_max;
+	void *data, *copy;
+	dwt_util_alloc_image(&data, stride_x, stride_y, size_o_big_x, size_o_big_y);
+	dwt_util_alloc_image(&copy, stride_x, stride_y, size_o_big_x, size_o_big_y);
+	dwt_util_test_image_fill_i(data, stride_x, stride_y, size_i_big_x, size_i_big_y, 0);
+	dwt_util_copy_i(data, copy, stride_x, stride_y, size_i_big_x, size_i_big_y);
+	dwt_cdf97_2f_i(data, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y, &j, decompose_one, zero_padding);
+	dwt_cdf97_2i_i(data, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y, j, decompose_one, zero_padding);
+	const int ret = dwt_util_compare_i(data, copy, stride_x, stride_y, size_i_big_x, size_i_big_y) ? 1 : 0;
+	dwt_util_free_image(&data);
+	dwt_util_free_image(&copy);
+	return ret;
+}
+
+int dwt_util_test2_cdf97_2_d(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one)
+{
+	int stride_x, stride_y, sox, soy, six, siy;
+	dwt_util_get_sizes_d(array_type, size_x, size_y, opt_stride, &stride_x, &stride_y, &sox, &soy, &six, &siy);
+	return dwt_util_test_cdf97_2_d(stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, 0);
+}
+
+int dwt_util_test2_cdf97_2_i(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one)
+{
+	int stride_x, stride_y, sox, soy, six, siy;
+	dwt_util_get_sizes_i(array_type, size_x, size_y, opt_stride, &stride_x, &stride_y, &sox, &soy, &six, &siy);
+	return dwt_util_test_cdf97_2_i(stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, 0);
+}
+
 int dwt_util_test2_cdf97_2_s(enum dwt_array array_type, int size_x, int size_y, int opt_stride, int j_max, int decompose_one)
 {
 	int stride_x, stride_y, sox, soy, six, siy;

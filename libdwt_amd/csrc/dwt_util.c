@@ -229,6 +229,83 @@ void dwt_util_copy_i(const void *src, void *dst, int stride_x, int stride_y, int
 	dwt_util_copy_s(src, dst, stride_x, stride_y, size_i_big_x, size_i_big_y);
 }
 
+/* double-precision twins used by examples/simple-double and the self-test
+ * (src/libdwt.c:1112-1125 + 1246-1266 pattern with 0-based x, y; copy :1426; compare 1e-6
+ * absolute; view; PGM writer) */
+void dwt_util_test_image_fill_d(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand)
+{
+	for (int y = 0; y < size_i_big_y; y++)
+		for (int x = 0; x < size_i_big_x; x++) {
+			const int xx = x >> rand;
+			const double v = 2 * xx * y / (double)(xx * xx + y * y + 1);
+			memcpy(px(ptr, y, x, stride_x, stride_y), &v, sizeof v);
+		}
+}
+
+void dwt_util_copy_d(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y)
+{
+	for (int y = 0; y < size_i_big_y; y++)
+		for (int x = 0; x < size_i_big_x; x++)
+			memcpy(px(dst, y, x, stride_x, stride_y), px(src, y, x, stride_x, stride_y), 8);
+}
+
+int dwt_util_compare_d(void *ptr1, void *ptr2, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y)
+{
+	for (int y = 0; y < size_i_big_y; y++)
+		for (int x = 0; x < size_i_big_x; x++) {
+			double a, b;
+			memcpy(&a, px(ptr1, y, x, stride_x, stride_y), 8);
+			memcpy(&b, px(ptr2, y, x, stride_x, stride_y), 8);
+			if (!isfinite(a) || !isfinite(b) || fabs(a - b) > 1e-6)
+				return 1;
+		}
+	return 0;
+}
+
+void dwt_util_conv_show_d(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y)
+{
+	for (int y = 0; y < size_i_big_y; y++)
+		for (int x = 0; x < size_i_big_x; x++) {
+			double c;
+			memcpy(&c, px(src, y, x, stride_x, stride_y), 8);
+			const double t = log(1. + fabs(c) * 100.) / 10.;
+			memcpy(px(dst, y, x, stride_x, stride_y), &t, 8);
+		}
+}
+
+int dwt_util_save_to_pgm_d(const char *filename, double max_value, const void *ptr, int stride_x, int stride_y,
+	int size_i_big_x, int size_i_big_y)
+{
+	FILE *f = fopen(filename, "w");
+	if (!f)
+		return 1;
+	fprintf(f, "P2\n%i %i\n%i\n", size_i_big_x, size_i_big_y, 255);
+	int incidents = 0;
+	for (int y = 0; y < size_i_big_y; y++)
+		for (int x = 0; x < size_i_big_x; x++) {
+			double p;
+			memcpy(&p, px(ptr, y, x, stride_x, stride_y), 8);
+			int val = (int)(255 * p / max_value);
+			if (p - 1e-6 > max_value && !incidents++)
+				dwt_util_log(LOG_WARN, "%s: Maximum pixel intensity exceeded (%f > %f) at (y=%i, x=%i). Such an incident will be reported only once.\n", __func__, p, max_value, y, x);
+			if (p > max_value)
+				val = 255;
+			if (p + 1e-6 < 0.0 && !incidents++)
+				dwt_util_log(LOG_WARN, "%s: Minimum pixel intensity exceeded (%f < %f) at (y=%i, x=%i). Such an incident will be reported only once.\n", __func__, p, 0.0f, y, x);
+			if (p < 0.0)
+				val = 0;
+			if (fprintf(f, "%i\n", val) < 0) {
+				dwt_util_log(LOG_WARN, "%s: error writing into file.\n", __func__);
+				fclose(f);
+				return 1;
+			}
+		}
+	fclose(f);
+	if (incidents)
+		dwt_util_log(LOG_WARN, "%s: %i errors ocurred while saving a file.\n", __func__, incidents);
+	return 0;
+}
+
 /* ---- comparison (src/libdwt.c:1593-1620, 1531-1558) ---- */
 int dwt_util_compare_s(void *ptr1, void *ptr2, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y)
 {

@@ -126,7 +126,7 @@ def test_conv_show_copy_pgm(dwt, tmp_path):
 
 def test_reference_examples_link_unchanged(dwt, tmp_path):
     """The reference's own programs around the path -- examples/simple, simple-int,
-    simple-perf, subbands, perf-plot, simple-newapi -- compile against include/*.h and link against
+    simple-perf, subbands, perf-plot, simple-newapi, simple-double and the self-test `test` -- compile against include/*.h and link against
     libdwt_hip.so without modification."""
     ref = "/root/reference/examples"
     if not os.path.isdir(ref):
@@ -134,7 +134,7 @@ def test_reference_examples_link_unchanged(dwt, tmp_path):
     libdir = os.path.join(ROOT, "libdwt_amd")
     import glob
 
-    for ex in ("simple", "simple-int", "simple-perf", "subbands", "perf-plot", "simple-newapi"):
+    for ex in ("simple", "simple-int", "simple-perf", "subbands", "perf-plot", "simple-newapi", "simple-double", "test"):
         exe = tmp_path / (ex + ".bin")
         src = sorted(glob.glob(os.path.join(ref, ex, "*.c")))[0]
         subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", INCLUDE, src,

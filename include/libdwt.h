@@ -107,6 +107,17 @@ void dwt_cdf53_2f_inplace_s(void *ptr, int stride_x, int stride_y,
 void dwt_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
 	int j_max, int decompose_one, int zero_padding);
+/* the reference's other CPU schedules of the same forward transform (identical bits):
+ * src/libdwt.h:612, 625, 649 */
+void dwt_cdf97_2f_inplace_sep_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void dwt_cdf97_2f_inplace_sep_sdl_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void dwt_cdf97_2f_inplace_sdl_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
 
 /* ---- lifecycle and backend knobs (src/libdwt.h:1667-1745, 1974-1986) -------------- */
 void dwt_util_init(void);   /* brings the device up (the reference loads BCE firmware here) */
@@ -257,6 +268,32 @@ const char *dwt_util_appname(void);
 
 /* size sweep writing "pixels<TAB>seconds per pixel" rows (src/libdwt.c:22559) */
 void dwt_util_measure_perf_cdf97_2_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
+	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
+	FILE *fwd_plot_data, FILE *inv_plot_data);
+/* the same protocols for the interleaved-layout entries (src/libdwt.h:2520, 2537, 2554, 2576,
+ * 2744, 2764, 2784, 2804) */
+void dwt_util_perf_cdf97_2_inplace_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding,
+	int M, int N, int clock_type, float *fwd_secs, float *inv_secs);
+void dwt_util_measure_perf_cdf97_2_inplace_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
+	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
+	FILE *fwd_plot_data, FILE *inv_plot_data);
+void dwt_util_perf_cdf97_2_inplace_sep_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding,
+	int M, int N, int clock_type, float *fwd_secs, float *inv_secs);
+void dwt_util_measure_perf_cdf97_2_inplace_sep_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
+	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
+	FILE *fwd_plot_data, FILE *inv_plot_data);
+void dwt_util_perf_cdf97_2_inplace_sep_sdl_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding,
+	int M, int N, int clock_type, float *fwd_secs, float *inv_secs);
+void dwt_util_measure_perf_cdf97_2_inplace_sep_sdl_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
+	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
+	FILE *fwd_plot_data, FILE *inv_plot_data);
+void dwt_util_perf_cdf97_2_inplace_sdl_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int j_max, int decompose_one, int zero_padding,
+	int M, int N, int clock_type, float *fwd_secs, float *inv_secs);
+void dwt_util_measure_perf_cdf97_2_inplace_sdl_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
 	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
 	FILE *fwd_plot_data, FILE *inv_plot_data);
 

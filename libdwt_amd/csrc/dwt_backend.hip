@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -47,6 +48,8 @@ struct Ctx {
 	size_t ll_bytes[2] = {0, 0};
 	void *host_a = nullptr, *host_b = nullptr; // device images for host-pointer calls
 	size_t host_a_bytes = 0, host_b_bytes = 0;
+	void *pin = nullptr; // pinned host staging for host-pointer calls with awkward strides
+	size_t pin_bytes = 0;
 	// pipeline lanes for batches: image k runs all its levels on lane k % lanes, so the
 	// small tail levels of one image overlap the big levels of the next
 	struct Lane {
@@ -150,6 +153,107 @@ int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, l
 		return 0;
 	HIP_TRY(hipMemcpy2DAsync(dst.p + dy * dst.sx + dx * dst.es, dst.sx, src.p + sy_ * src.sx + sx_ * src.es, src.sx, w * dst.es, h,
 		hipMemcpyDeviceToDevice, st));
+	return 0;
+}
+
+// ---- host images <-> dense device images (host-pointer entries) ----
+// hipMemcpy2D from pageable memory falls to a row-by-row path when the host pitch is not
+// nicely aligned -- and libdwt's "optimal" strides are primes (2053 B for 512 floats,
+// src/libdwt.c:20655-20658): 7.7 ms instead of 0.16 ms for 512^2.  Such images are packed
+// into a pinned buffer with the device pitch (parallel row memcpy) and moved by ONE copy.
+static int grow_pinned(size_t need)
+{
+	if (g.pin_bytes >= need)
+		return 0;
+	if (g.pin) {
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		HIP_TRY(hipHostFree(g.pin));
+		g.pin = nullptr;
+		g.pin_bytes = 0;
+	}
+	HIP_TRY(hipHostMalloc(&g.pin, need, hipHostMallocDefault));
+	g.pin_bytes = need;
+	return 0;
+}
+
+template <class F>
+static void for_rows_parallel(int rows, size_t bytes_total, F f)
+{
+	unsigned nt = bytes_total >= (8u << 20) ? std::thread::hardware_concurrency() : 1;
+	if (nt > 16)
+		nt = 16;
+	if (nt <= 1 || rows < 64) {
+		f(0, rows);
+		return;
+	}
+	std::vector<std::thread> th;
+	const int chunk = (rows + (int)nt - 1) / (int)nt;
+	for (unsigned t = 0; t < nt; t++) {
+		const int a = (int)t * chunk, b = a + chunk < rows ? a + chunk : rows;
+		if (a < b)
+			th.emplace_back(f, a, b);
+	}
+	for (auto &x : th)
+		x.join();
+}
+
+static bool host_pitch_is_fast(const void *hp, int stride_x, int stride_y, int es)
+{
+	return stride_y == es && stride_x % 64 == 0 && (uintptr_t)hp % 16 == 0;
+}
+
+// w x h elements of `es` bytes at hp (byte strides) -> device image dp with `pitch`
+static int host_upload(const void *hp, int stride_x, int stride_y, int es, int w, int h, void *dp, long pitch)
+{
+	if (host_pitch_is_fast(hp, stride_x, stride_y, es)) {
+		HIP_TRY(hipMemcpy2DAsync(dp, pitch, hp, stride_x, (size_t)w * es, h, hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		return 0;
+	}
+	if (grow_pinned((size_t)pitch * h))
+		return 1;
+	char *pin = (char *)g.pin;
+	for_rows_parallel(h, (size_t)pitch * h, [=](int y0, int y1) {
+		for (int y = y0; y < y1; y++) {
+			const char *row = (const char *)hp + (long)y * stride_x;
+			char *out = pin + (long)y * pitch;
+			if (stride_y == es) {
+				memcpy(out, row, (size_t)w * es);
+			} else {
+				for (int x = 0; x < w; x++)
+					memcpy(out + (long)x * es, row + (long)x * stride_y, es);
+			}
+		}
+	});
+	HIP_TRY(hipMemcpyAsync(dp, pin, (size_t)pitch * h, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+static int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, const void *dp, long pitch)
+{
+	if (host_pitch_is_fast(hp, stride_x, stride_y, es)) {
+		HIP_TRY(hipMemcpy2DAsync(hp, stride_x, dp, pitch, (size_t)w * es, h, hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		return 0;
+	}
+	if (grow_pinned((size_t)pitch * h))
+		return 1;
+	char *pin = (char *)g.pin;
+	HIP_TRY(hipMemcpyAsync(pin, dp, (size_t)pitch * h, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	for_rows_parallel(h, (size_t)pitch * h, [=](int y0, int y1) {
+		for (int y = y0; y < y1; y++) {
+			char *row = (char *)hp + (long)y * stride_x;
+			const char *in = pin + (long)y * pitch;
+			if (stride_y == es) {
+				memcpy(row, in, (size_t)w * es);
+			} else {
+				for (int x = 0; x < w; x++)
+					memcpy(row + (long)x * stride_y, in + (long)x * es, es);
+			}
+		}
+	});
 	return 0;
 }
 
@@ -663,6 +767,10 @@ void dwt_hip_finish(void)
 		*b = nullptr;
 	}
 	g.stage_bytes = g.ll_bytes[0] = g.ll_bytes[1] = g.host_a_bytes = g.host_b_bytes = 0;
+	if (g.pin)
+		hipHostFree(g.pin);
+	g.pin = nullptr;
+	g.pin_bytes = 0;
 	for (auto &l : g.lanes) {
 		void **lb[] = {&l.ll[0], &l.ll[1], &l.stage_img};
 		for (void **p : lb) {
@@ -893,36 +1001,8 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	if (grow(&g.host_a, &g.host_a_bytes, bytes) || grow(&g.host_b, &g.host_b_bytes, bytes))
 		return 1;
 	const bool s2 = (src != dst);
-	// dense element stride: one 2-D copy; otherwise gather on the host first
-	std::vector<char> packed;
-	auto upload = [&](const void *hp, void *dp) -> int {
-		if (stride_y == es) {
-			HIP_TRY(hipMemcpy2DAsync(dp, pitch, hp, stride_x, (size_t)sox * es, soy, hipMemcpyHostToDevice, g.stream));
-			HIP_TRY(hipStreamSynchronize(g.stream));
-		} else {
-			packed.resize((size_t)sox * soy * es);
-			for (int y = 0; y < soy; y++)
-				for (int x = 0; x < sox; x++)
-					memcpy(&packed[((size_t)y * sox + x) * es], (const char *)hp + (long)y * stride_x + (long)x * stride_y, es);
-			HIP_TRY(hipMemcpy2DAsync(dp, pitch, packed.data(), (size_t)sox * es, (size_t)sox * es, soy, hipMemcpyHostToDevice, g.stream));
-			HIP_TRY(hipStreamSynchronize(g.stream));
-		}
-		return 0;
-	};
-	auto download = [&](void *hp, const void *dp) -> int {
-		if (stride_y == es) {
-			HIP_TRY(hipMemcpy2DAsync(hp, stride_x, dp, pitch, (size_t)sox * es, soy, hipMemcpyDeviceToHost, g.stream));
-			HIP_TRY(hipStreamSynchronize(g.stream));
-		} else {
-			packed.resize((size_t)sox * soy * es);
-			HIP_TRY(hipMemcpy2DAsync(packed.data(), (size_t)sox * es, dp, pitch, (size_t)sox * es, soy, hipMemcpyDeviceToHost, g.stream));
-			HIP_TRY(hipStreamSynchronize(g.stream));
-			for (int y = 0; y < soy; y++)
-				for (int x = 0; x < sox; x++)
-					memcpy((char *)hp + (long)y * stride_x + (long)x * stride_y, &packed[((size_t)y * sox + x) * es], es);
-		}
-		return 0;
-	};
+	auto upload = [&](const void *hp, void *dp) -> int { return host_upload(hp, stride_x, stride_y, es, sox, soy, dp, pitch); };
+	auto download = [&](void *hp, const void *dp) -> int { return host_download(hp, stride_x, stride_y, es, sox, soy, dp, pitch); };
 	Img A{(char *)g.host_a, pitch, es}, B{(char *)g.host_b, pitch, es};
 	if (upload(src, A.p))
 		return 1;
@@ -1181,31 +1261,12 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 	const long pitch = align_up((long)sox * 4, 256);
 	if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * soy))
 		return 1;
-	std::vector<char> packed;
-	if (stride_y == 4) {
-		HIP_TRY(hipMemcpy2DAsync(g.host_a, pitch, src, stride_x, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
-	} else {
-		packed.resize((size_t)sox * soy * 4);
-		for (int y = 0; y < soy; y++)
-			for (int x = 0; x < sox; x++)
-				memcpy(&packed[((size_t)y * sox + x) * 4], (const char *)src + (long)y * stride_x + (long)x * stride_y, 4);
-		HIP_TRY(hipMemcpy2DAsync(g.host_a, pitch, packed.data(), (size_t)sox * 4, (size_t)sox * 4, soy, hipMemcpyHostToDevice, g.stream));
-	}
-	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (host_upload(src, stride_x, stride_y, 4, sox, soy, g.host_a, pitch))
+		return 1;
 	Img A{(char *)g.host_a, pitch, 4};
 	if (interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one))
 		return 1;
-	if (stride_y == 4) {
-		HIP_TRY(hipMemcpy2DAsync(dst, stride_x, g.host_a, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
-		HIP_TRY(hipStreamSynchronize(g.stream));
-	} else {
-		HIP_TRY(hipMemcpy2DAsync(packed.data(), (size_t)sox * 4, g.host_a, pitch, (size_t)sox * 4, soy, hipMemcpyDeviceToHost, g.stream));
-		HIP_TRY(hipStreamSynchronize(g.stream));
-		for (int y = 0; y < soy; y++)
-			for (int x = 0; x < sox; x++)
-				memcpy((char *)dst + (long)y * stride_x + (long)x * stride_y, &packed[((size_t)y * sox + x) * 4], 4);
-	}
-	return 0;
+	return host_download(dst, stride_x, stride_y, 4, sox, soy, g.host_a, pitch);
 }
 
 int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *dst, size_t batch_stride, int batch,

@@ -149,9 +149,11 @@ void dwt_hip_perf_cdf97_2_s(int stride_x, int stride_y, int size_o_big_x, int si
 		size_i_big_x, size_i_big_y, j_max, decompose_one, zero_padding, M, N, clock_type, fwd_secs, inv_secs);
 }
 
+typedef void (*perf_fn)(int, int, int, int, int, int, int, int, int, int, int, int, float *, float *);
+
 /* src/libdwt.c:22559-22645: size sweep x = min_x, ceil(x*1.13), ... writing
  * "pixels <TAB> seconds per pixel" (MEASURE_PER_PIXEL is defined at :8) */
-void dwt_util_measure_perf_cdf97_2_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
+static void measure_perf(perf_fn perf, enum dwt_array array_type, int min_x, int max_x, int opt_stride,
 	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
 	FILE *fwd_plot_data, FILE *inv_plot_data)
 {
@@ -163,13 +165,55 @@ void dwt_util_measure_perf_cdf97_2_s(enum dwt_array array_type, int min_x, int m
 		dwt_util_log(LOG_DBG, "performance test for [%ix%i] in [%ix%i] with strides (%i, %i)...\n",
 			six, siy, sox, soy, stride_x, stride_y);
 		float fwd_secs, inv_secs;
-		dwt_util_perf_cdf97_2_s(stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding,
+		perf(stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, zero_padding,
 			M, N, clock_type, &fwd_secs, &inv_secs);
 		const int denominator = x * y;
 		fprintf(fwd_plot_data, "%i\t%.10f\n", x * y, fwd_secs / denominator);
 		fprintf(inv_plot_data, "%i\t%.10f\n", x * y, inv_secs / denominator);
 	}
 }
+
+void dwt_util_measure_perf_cdf97_2_s(enum dwt_array array_type, int min_x, int max_x, int opt_stride,
+	int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type,
+	FILE *fwd_plot_data, FILE *inv_plot_data)
+{
+	measure_perf(dwt_util_perf_cdf97_2_s, array_type, min_x, max_x, opt_stride, j_max, decompose_one, zero_padding,
+		M, N, clock_type, fwd_plot_data, inv_plot_data);
+}
+
+/* Interleaved (in-place lifting) layout: the reference's four CPU schedules of the forward
+ * transform (src/libdwt.c:12926 plain, :13485 _sep_, :13641 _sep_sdl_, :14847 _sdl_) give
+ * identical bits; one device path serves them.  Perf helpers: src/libdwt.c:21519-21920,
+ * size sweeps :22647-22990. */
+#define DWT_INPLACE_VARIANT(suffix)                                                                              \
+	void dwt_cdf97_2f_inplace_##suffix(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,  \
+		int *j_max_ptr, int decompose_one, int zero_padding)                                                      \
+	{                                                                                                            \
+		dwt_cdf97_2f_inplace_s(ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, zero_padding); \
+	}
+DWT_INPLACE_VARIANT(sep_s)
+DWT_INPLACE_VARIANT(sep_sdl_s)
+DWT_INPLACE_VARIANT(sdl_s)
+#undef DWT_INPLACE_VARIANT
+
+#define DWT_INPLACE_PERF(suffix)                                                                                 \
+	void dwt_util_perf_cdf97_2_inplace_##suffix(int stride_x, int stride_y, int sox, int soy, int six, int siy,   \
+		int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type, float *fwd_secs, float *inv_secs) \
+	{                                                                                                            \
+		perf_2d(dwt_cdf97_2f_inplace_s, dwt_cdf97_2i_inplace_s, 0, 0, stride_x, stride_y, sox, soy, six, siy,       \
+			j_max, decompose_one, zero_padding, M, N, clock_type, fwd_secs, inv_secs);                               \
+	}                                                                                                            \
+	void dwt_util_measure_perf_cdf97_2_inplace_##suffix(enum dwt_array array_type, int min_x, int max_x, int opt_stride, \
+		int j_max, int decompose_one, int zero_padding, int M, int N, int clock_type, FILE *fwd_plot_data, FILE *inv_plot_data) \
+	{                                                                                                            \
+		measure_perf(dwt_util_perf_cdf97_2_inplace_##suffix, array_type, min_x, max_x, opt_stride, j_max,          \
+			decompose_one, zero_padding, M, N, clock_type, fwd_plot_data, inv_plot_data);                            \
+	}
+DWT_INPLACE_PERF(s)
+DWT_INPLACE_PERF(sep_s)
+DWT_INPLACE_PERF(sep_sdl_s)
+DWT_INPLACE_PERF(sdl_s)
+#undef DWT_INPLACE_PERF
 
 /* src/libdwt.c:23788-23875: fill, forward, inverse, compare; 0 = success */
 int dwt_util_test_cdf97_2_s(int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,

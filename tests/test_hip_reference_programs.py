@@ -53,6 +53,7 @@ def test_reference_example_programs_write_the_reference_bytes(tmp_path, name):
     assert got == want["files"]
 
 
-def test_reference_perf_program(tmp_path):
-    text = run("simple-perf", tmp_path, timeout=600)
-    assert "rror" not in text, text[-2000:]
+@pytest.mark.parametrize("name", ["simple-perf", "simple-perf-single", "simple-perf-single-sdl"])
+def test_reference_perf_programs(tmp_path, name):
+    text = run(name, tmp_path, timeout=600)
+    assert "rror" not in text and "differs" not in text, text[-2000:]

@@ -8,7 +8,8 @@
  * schedules ("vectorisations") that give identical bits; here they are one device path.
  * Results equal the reference's within fp32 rounding (<= 1e-5 relative): the reference
  * interleaves row and column work in phases, the device finishes the rows first, which
- * changes the rounding in the 8-sample border bands only.
+ * changes the rounding in the 8-sample border bands only; after dwt_util_set_accel(1) the
+ * device follows the reference's phase order and the results are bit-identical.
  *
  * `ptr` may be a host pointer (staged through HBM) or a device pointer (stride_y == 4).
  * Element (y, x) lives at ptr + y*stride_x + x*stride_y (bytes).  `*j_max_ptr` < 0 or

@@ -1047,6 +1047,88 @@ struct IlLevel {
 	int lx = 0, ly = 0;
 };
 
+// The reference's 9/7 in-place drivers and fdwt2_* cut every line transform into phases --
+// SHORT (whole line, lines shorter than `min_phased`), PROLOG, CORE, EPILOG -- and run each
+// phase over all rows, then all columns, before the next (src/dwt-simple.c:2266-2350,
+// src/libdwt.c:12970-13480, 17517-17594).  This is that order, phase by phase, for
+// dwt_util_set_accel(1): bit-identical to the reference, eight passes per level instead of one.
+// Index ranges per lifting step: prolog src/dwt-simple.c:580-611, core :981-1029, epilog
+// :1469-1528, short :424-510; inverse src/libdwt.c:9591-9668, 7661-7740, 9929-10010.
+static void il_phase_ranges(int N, int K, bool inverse, int phase, IlPhase *ph)
+{
+	// phase: 0 short, 1 prolog, 2 core, 3 epilog
+	for (int s = 0; s < 4; s++) {
+		ph->lo[s] = 1;
+		ph->hi[s] = 0;
+	}
+	if (phase == 0) {
+		for (int s = 0; s < K; s++) {
+			ph->lo[s] = 0;
+			ph->hi[s] = N - 1;
+		}
+		ph->sc_lo = 0;
+		ph->sc_hi = N - 1;
+	} else if (!inverse) {
+		const int M = (((N - 1) & ~1) - K) / 2; // core pairs, counted from index 1
+		for (int s = 0; s < K; s++) {
+			if (phase == 1) { ph->lo[s] = 0; ph->hi[s] = K - 1 - s; }
+			else if (phase == 2) { ph->lo[s] = K + 1 - s; ph->hi[s] = K - 1 - s + 2 * M; }
+			else { ph->lo[s] = K + 1 - s + 2 * M; ph->hi[s] = N - 1; }
+		}
+		if (phase == 1) { ph->sc_lo = 0; ph->sc_hi = 0; }
+		else if (phase == 2) { ph->sc_lo = 1; ph->sc_hi = 2 * M; }
+		else { ph->sc_lo = 2 * M + 1; ph->sc_hi = N - 1; }
+	} else {
+		const int M = ((N & ~1) - K) / 2; // core pairs, counted from index 0
+		for (int s = 0; s < K; s++) {
+			if (phase == 1) { ph->lo[s] = 0; ph->hi[s] = K - 2 - s; }
+			else if (phase == 2) { ph->lo[s] = K - s; ph->hi[s] = K - 2 - s + 2 * M; }
+			else { ph->lo[s] = K - s + 2 * M; ph->hi[s] = N - 1; }
+		}
+		if (phase == 1) { ph->sc_lo = 0; ph->sc_hi = K - 1; }
+		else if (phase == 2) { ph->sc_lo = K; ph->sc_hi = K - 1 + 2 * M; }
+		else { ph->sc_lo = K + 2 * M; ph->sc_hi = N - 1; }
+	}
+}
+
+static bool il_is_phased(Wavelet w) { return w == kCdf97S || w == kCdf97SFma || w == kCdf53SNew; }
+
+static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int ly)
+{
+	if (in.sx != out.sx)
+		return fail("interleaved phased level: pitches differ");
+	const int K = w == kCdf53SNew ? 2 : 4;
+	const int min_phased = w == kCdf53SNew ? 3 : (inverse ? 4 : 5);
+	struct Pass { bool rows; int phase; };
+	Pass seq[8];
+	int n = 0;
+	for (int phase = 0; phase < 4; phase++) {
+		if (lx > 1 && (phase == 0) == (lx < min_phased))
+			seq[n++] = {true, phase};
+		if (ly > 1 && (phase == 0) == (ly < min_phased))
+			seq[n++] = {false, phase};
+	}
+	if (n == 0)
+		return copy_rect(out, 0, 0, in, 0, 0, lx, ly);
+	if (grow(&g.host_b, &g.host_b_bytes, (size_t)in.sx * ly))
+		return 1;
+	Img tmp{(char *)g.host_b, in.sx, 4};
+	// ping-pong so that the last pass writes `out`
+	Img cur = in;
+	for (int i = 0; i < n; i++) {
+		const Img nxt = ((n - 1 - i) % 2 == 0) ? out : tmp;
+		IlPhase ph;
+		const int N = seq[i].rows ? lx : ly;
+		il_phase_ranges(N, K, inverse, seq[i].phase, &ph);
+		hipError_t e = launch_il_phase(w == kCdf97SFma ? kCdf97S : w, inverse, cur.p, nxt.p, seq[i].rows ? cur.sx : 4, seq[i].rows ? 4 : cur.sx,
+			seq[i].rows ? ly : lx, N, !seq[i].rows, ph, g.stream);
+		if (e != hipSuccess)
+			return fail("interleaved phase launch failed: %s", hipGetErrorString(e));
+		cur = nxt;
+	}
+	return 0;
+}
+
 // one level on dense images with a common pitch: rows completely, then columns
 static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
 	const Img *even_rows = nullptr)
@@ -1076,7 +1158,19 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 			return fail("interleaved sweep launch failed: %s", hipGetErrorString(e));
 		return 0;
 	}
-	// generic: two exact line passes through a temporary with the same pitch
+	// generic.  The phase-ordered entries reproduce the reference's order exactly when the
+	// generic path was asked for (accel 1); tiny levels of the fused path and the 5/3 _inplace_
+	// pair (rows, then columns in the reference too) take two exact line passes.
+	if (g.force_generic && il_is_phased(w) && !scale_single) {
+		if (il_level_phased(w, inverse, in, out, lx, ly))
+			return 1;
+		if (ll && !inverse) {
+			hipError_t e = launch_lattice_copy((const float *)out.p, 2, out.sx / 4 * 2, 0, ll, 1, ll_pitch, 0, (lx + 1) / 2, (ly + 1) / 2, 1, g.stream);
+			if (e != hipSuccess)
+				return fail("lattice gather failed: %s", hipGetErrorString(e));
+		}
+		return 0;
+	}
 	if (in.sx != out.sx)
 		return fail("interleaved generic level: pitches differ");
 	if (grow(&g.host_b, &g.host_b_bytes, (size_t)in.sx * ly))

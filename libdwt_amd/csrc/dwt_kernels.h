@@ -106,6 +106,17 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
 	int nx, int ny, int nz, hipStream_t s);
 
+// One PHASE of the reference's phase-ordered in-place lifting (src/dwt-simple.c:2266-2350,
+// src/libdwt.c:17517-17594): lifting step s updates the coefficients lo[s]..hi[s] of its
+// parity only, the scaling touches sc_lo..sc_hi only; everything else is copied.  Out of
+// place, one thread per coefficient pair, interleaved layout on both sides.
+struct IlPhase {
+	int lo[4], hi[4];
+	int sc_lo, sc_hi;
+};
+hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
+	int n_lines, int N, bool lanes_along_lines, const IlPhase &ph, hipStream_t s);
+
 // Interleaved (in-place lifting) layout, multi-level: the dense per-level images of the
 // levels 1..J-1 (level j has ceil(W/2^j) x ceil(H/2^j) samples and lives on the stride-2^j
 // lattice of the W x H image).  Pitches in ELEMENTS.

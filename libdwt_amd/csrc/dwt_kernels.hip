@@ -1692,6 +1692,84 @@ hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz
 	return hipGetLastError();
 }
 
+// ---- interleaved layout: one phase of the reference's phase-ordered lifting, exact ----
+// Same windowed evaluation as k_line_pass, with every step masked to the index range the
+// phase gives it.  Mirrored window entries (symmetric extension) carry the index they
+// mirror, so they receive the same masked updates as their originals.
+template <class W, bool INV>
+__global__ __launch_bounds__(256) void k_il_phase(const char *__restrict__ src, char *__restrict__ dst,
+	long line_stride, long elem_stride, int n_lines, int N, int lanes_along_lines, IlPhase ph)
+{
+	using T = typename W::T;
+	constexpr int K = W::K, NW = 2 * K + 1;
+	const int fast = blockIdx.x * blockDim.x + threadIdx.x;
+	const int slow = blockIdx.y;
+	const int line = lanes_along_lines ? fast : slow;
+	const int k = lanes_along_lines ? slow : fast;
+	if (line >= n_lines || k >= ((N + 1) >> 1))
+		return;
+	const char *s = src + (long)line * line_stride;
+	char *d = dst + (long)line * line_stride;
+	// forward: w[0] is the even sample 2k-K; inverse: the odd sample 2k-K+1
+	const int first = 2 * k - K + (INV ? 1 : 0);
+	T w[NW];
+	int idx[NW];
+#pragma unroll
+	for (int j = 0; j < NW; j++) {
+		idx[j] = reflect(first + j, N);
+		w[j] = *(const T *)(s + (long)idx[j] * elem_stride);
+		if (INV && idx[j] >= ph.sc_lo && idx[j] <= ph.sc_hi)
+			w[j] = W::inv_scale(idx[j] & 1, w[j]);
+	}
+#pragma unroll
+	for (int st = 0; st < K; st++) {
+#pragma unroll
+		for (int j = st + 1; j <= NW - 2 - st; j += 2)
+			if (idx[j] >= ph.lo[st] && idx[j] <= ph.hi[st])
+				w[j] = INV ? W::inv_step(st, w[j], w[j - 1], w[j + 1]) : W::fwd_step(st, w[j], w[j - 1], w[j + 1]);
+	}
+	const int c0 = INV ? K - 1 : K; // window position of sample 2k
+#pragma unroll
+	for (int e = 0; e < 2; e++) {
+		const int i = 2 * k + e;
+		if (i < N) {
+			T v = w[c0 + e];
+			if (!INV && i >= ph.sc_lo && i <= ph.sc_hi)
+				v = W::fwd_scale(e, v);
+			*(T *)(d + (long)i * elem_stride) = v;
+		}
+	}
+}
+
+template <class W>
+static hipError_t il_phase_t(bool inverse, const void *src, void *dst, long line_stride, long elem_stride, int n_lines, int N,
+	bool lanes_along_lines, const IlPhase &ph, hipStream_t s)
+{
+	if (n_lines <= 0 || N < 2)
+		return hipErrorInvalidValue;
+	const int npairs = (N + 1) >> 1;
+	const int fast = lanes_along_lines ? n_lines : npairs;
+	const int slow = lanes_along_lines ? npairs : n_lines;
+	const int bs = fast >= 256 ? 256 : 64;
+	dim3 grid((fast + bs - 1) / bs, slow);
+	if (inverse)
+		k_il_phase<W, true><<<grid, bs, 0, s>>>((const char *)src, (char *)dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph);
+	else
+		k_il_phase<W, false><<<grid, bs, 0, s>>>((const char *)src, (char *)dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph);
+	return hipGetLastError();
+}
+
+hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
+	int n_lines, int N, bool lanes_along_lines, const IlPhase &ph, hipStream_t s)
+{
+	switch (w) {
+	case kCdf97S: return il_phase_t<Cdf97S>(inverse, src, dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph, s);
+	case kCdf53SNew: return il_phase_t<Cdf53SNew>(inverse, src, dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph, s);
+	default: break;
+	}
+	return hipErrorInvalidValue;
+}
+
 // ---- interleaved layout: all levels' lattices in one pass over the even rows ----
 // A lattice-1 point (p, q) (image column 2p, row 2q) belongs to level
 // j = 1 + min(ctz(p), ctz(q)) capped at J-1; its sample sits at (p >> (j-1), q >> (j-1))

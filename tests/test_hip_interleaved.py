@@ -4,9 +4,11 @@ C-ABI: libdwt.h dwt_cdf{97,53}_2{f,i}_inplace_s and dwt-simple.h fdwt2_cdf{97,53
 Bars (written here on purpose):
  * 5/3 `_inplace_` pair: the reference finishes rows before columns -> BIT-EXACT.
  * 9/7 pair and fdwt2_*: the reference interleaves row and column work in phases; the
-   device finishes the rows first.  Same arithmetic, different fp32 rounding order in
-   the 8-sample border bands: |diff| <= 1e-5 * max|coefficient| (the north star's float
-   tolerance), and the interior is still bit-identical."""
+   fused device path finishes the rows first.  Same arithmetic, different fp32 rounding
+   order in the 8-sample border bands: |diff| <= 1e-5 * max|coefficient| (the north
+   star's float tolerance), and the interior is still bit-identical.
+ * dwt_util_set_accel(1) runs the reference's phase order pass by pass: BIT-EXACT for
+   every entry."""
 import numpy as np
 import pytest
 
@@ -55,7 +57,8 @@ def test_golden_inplace_entries_host(dwt, case, wv, accel):
         inv = getattr(dwt, f"dwt_{wv}_2i_inplace_s")
         j = fwd(buf, buf.strides[0], 4, sox, soy, six, siy, m["j_in"], m["decompose_one"])
         assert j == m[f"{wv}.j_out"]
-        exact = wv == "cdf53"
+        # accel 1 follows the reference's phase order pass by pass: bit-exact for every entry
+        exact = wv == "cdf53" or accel == 1
         check(buf, z[f"{wv}.fwd"], exact, "forward")
         # the inverse is checked on the reference's own coefficients
         buf = z[f"{wv}.fwd"].copy()
@@ -65,16 +68,21 @@ def test_golden_inplace_entries_host(dwt, case, wv, accel):
         dwt.dwt_util_set_accel(0)
 
 
+@pytest.mark.parametrize("accel", [0, 1])
 @pytest.mark.parametrize("sched", ["horizontal", "vertical", "diagonal"])
 @pytest.mark.parametrize("wv", ["cdf97", "cdf53"])
 @pytest.mark.parametrize("case", [c for c in CASES if "cdf97.fdwt2" in c[1]], ids=[m["name"] for m, z in CASES if "cdf97.fdwt2" in z])
-def test_golden_fdwt2_host(dwt, case, wv, sched):
+def test_golden_fdwt2_host(dwt, case, wv, sched, accel):
     m, z = case
     buf = z["in"].copy()
     w, h = m["size_o"]
-    j = getattr(dwt, f"fdwt2_{wv}_{sched}_s")(buf, w, h, buf.strides[0], 4, m["j_in"], m["decompose_one"])
+    dwt.dwt_util_set_accel(accel)
+    try:
+        j = getattr(dwt, f"fdwt2_{wv}_{sched}_s")(buf, w, h, buf.strides[0], 4, m["j_in"], m["decompose_one"])
+    finally:
+        dwt.dwt_util_set_accel(0)
     assert j == m[f"{wv}.j_out"]
-    close(buf, z[f"{wv}.fdwt2"], "fdwt2")
+    check(buf, z[f"{wv}.fdwt2"], accel == 1, "fdwt2")
     # pitch padding untouched
     assert np.array_equal(bits(buf[:, w:]), bits(z["in"][:, w:]))
 
@@ -163,6 +171,17 @@ def test_sparse_frame_and_levels(dwt, oracle, wv):
         got = want.copy()
         getattr(dwt, f"dwt_{wv}_2i_inplace_s")(got, got.strides[0], 4, 300, 200, six, siy, jw, d1)
         check(got, rec, wv == "cdf53", f"sparse inverse {six}x{siy}")
+        # the exact phase-ordered path
+        dwt.dwt_util_set_accel(1)
+        try:
+            got = a.copy()
+            getattr(dwt, f"dwt_{wv}_2f_inplace_s")(got, got.strides[0], 4, 300, 200, six, siy, j, d1)
+            check(got, want, True, f"sparse forward {six}x{siy}, accel 1")
+            got = want.copy()
+            getattr(dwt, f"dwt_{wv}_2i_inplace_s")(got, got.strides[0], 4, 300, 200, six, siy, jw, d1)
+            check(got, rec, True, f"sparse inverse {six}x{siy}, accel 1")
+        finally:
+            dwt.dwt_util_set_accel(0)
 
 
 def test_full_size_round_trip_and_linearity(dwt):

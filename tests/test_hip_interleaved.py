@@ -184,6 +184,32 @@ def test_sparse_frame_and_levels(dwt, oracle, wv):
             dwt.dwt_util_set_accel(0)
 
 
+@pytest.mark.parametrize("wv", ["cdf97", "cdf53"])
+@pytest.mark.parametrize("inplace", [True, False], ids=["inplace", "outofplace"])
+def test_device_sparse_frame(dwt, oracle, wv, inplace):
+    """size_i < size_o on device-resident images: only the inner region is transformed, the rest
+    of the outer frame keeps (in place) or receives (out of place) the source's values."""
+    h, w, six, siy = 700, 900, 650, 333
+    rng = np.random.default_rng(5)
+    a = rng.random((h, w), dtype=np.float32)
+    want = a.copy()
+    jw = oracle.fwd(f"{wv}_2f_inplace_s", want, 4, size_o=(w, h), size_i=(six, siy))
+    pitch = 3840
+    src = to_device(dwt, a, pitch)
+    dst = src if inplace else to_device(dwt, np.full_like(a, -3.0), pitch)
+    j = dwt.transform2d_interleaved(f"{wv}_s", 0, 0, src.ptr, dst.ptr, pitch, 4, w, h, six, siy, 4)
+    assert j == jw
+    check(from_device(dst), want, wv == "cdf53", "sparse device forward")
+    rec = want.copy()
+    oracle.inv(f"{wv}_2i_inplace_s", rec, jw, size_o=(w, h), size_i=(six, siy))
+    src2 = to_device(dwt, want, pitch)
+    dst2 = src2 if inplace else to_device(dwt, np.full_like(a, -3.0), pitch)
+    dwt.transform2d_interleaved(f"{wv}_s", 1, 0, src2.ptr, dst2.ptr, pitch, 4, w, h, six, siy, jw)
+    check(from_device(dst2), rec, wv == "cdf53", "sparse device inverse")
+    for d in {src, dst, src2, dst2}:
+        d.free()
+
+
 def test_full_size_round_trip_and_linearity(dwt):
     """8192^2, 5 levels, device resident: properties that need no CPU transform of the image."""
     n, J = 8192, 5

@@ -94,6 +94,13 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z,
 	int size_x, int size_y, int size_z, int levels);
 
+/* The same forward transform OUT OF PLACE (src != dst, both device pointers, same strides):
+ * cdf97_3f_op_sep_horizontal_s (src/volume-dwt.c:727-785), the entry the reference's 3-D
+ * perf test drives.  Each level is one fused x+y+z pass where the fused kernel applies
+ * (x size a multiple of 256), two passes otherwise. */
+int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z,
+	int size_x, int size_y, int size_z, int levels);
+
 /* Device-side twins of dwt_util_conv_show_{s,i} (src/libdwt.c:21075, 21020) and
  * dwt_util_compare_{s,i} (:1593, :1531) for images that stay in HBM between a forward and
  * an inverse transform.  compare returns 0 equal / 1 differ (float: 1e-3 absolute, NaN or

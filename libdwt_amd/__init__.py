@@ -74,6 +74,8 @@ lib.dwt_hip_transform2d_interleaved.argtypes = [_I, _I, _I, _P, _P, _I, _I, _I, 
 lib.dwt_hip_transform2d_interleaved.restype = _I
 lib.dwt_hip_transform3d.argtypes = [_I, _P, _S, _S, _I, _I, _I, _I]
 lib.dwt_hip_transform3d.restype = _I
+lib.dwt_hip_transform3d_op.argtypes = [_P, _P, _S, _S, _I, _I, _I, _I]
+lib.dwt_hip_transform3d_op.restype = _I
 lib.dwt_hip_malloc.argtypes = [_S]
 lib.dwt_hip_malloc.restype = _P
 lib.dwt_hip_free.argtypes = [_P]
@@ -368,6 +370,12 @@ def transform2d_batch(wavelet, inverse, src, dst, batch_stride, batch, stride_x,
 def transform3d(inverse, vol, stride_y, stride_z, size_x, size_y, size_z, levels=1):
     _check(lib.dwt_hip_transform3d(int(inverse), _addr(vol), stride_y, stride_z, size_x, size_y, size_z, levels),
            "dwt_hip_transform3d")
+
+
+def transform3d_op(src, dst, stride_y, stride_z, size_x, size_y, size_z, levels=1):
+    """Forward 3-D transform out of place (cdf97_3f_op_sep_horizontal_s, src/volume-dwt.c:727)."""
+    _check(lib.dwt_hip_transform3d_op(_addr(src), _addr(dst), stride_y, stride_z, size_x, size_y, size_z, levels),
+           "dwt_hip_transform3d_op")
 
 
 # ---- device memory without torch -------------------------------------------------------

@@ -838,6 +838,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.vol.tile_pairs = value;
 	else if (!strcmp(name, "vol_nt"))
 		g.vol.nt = value;
+	else if (!strcmp(name, "vol_fused"))
+		g.vol.fused = value;
 	else if (!strcmp(name, "pipeline"))
 		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else
@@ -877,6 +879,8 @@ int dwt_hip_get_option(const char *name)
 		return g.vol.tile_pairs;
 	if (!strcmp(name, "vol_nt"))
 		return g.vol.nt;
+	if (!strcmp(name, "vol_fused"))
+		return g.vol.fused;
 	return -1;
 }
 
@@ -1458,6 +1462,100 @@ int dwt_hip_compare(int is_int, const void *ptr1, const void *ptr2, int stride_x
 		return -1;
 	}
 	return host ? 1 : 0;
+}
+
+// Forward 3-D transform, OUT OF PLACE: the layout and arithmetic of cdf97_3f_op_sep_horizontal_s
+// (src/volume-dwt.c:727-785: copy each x line to the destination, then lift x, y, z there), the
+// entry the reference's own 3-D perf test drives (volume_perftest_fwd97op_s, src/volume.c).
+// Level j reads a dense volume and writes a dense volume, so each level is ONE fused pass
+// (k_vol_fwd_fused) where that kernel applies and the two-pass path (xy sweep, z sweep through
+// the scratch volume) elsewhere; the even-even-even samples go to the next level densely, and the
+// results of the levels >= 1 are scattered into their lattices at the end (deepest first).
+int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
+{
+	if (check_inited())
+		return 1;
+	if (!src || !dst || !dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
+		return fail("dwt_hip_transform3d_op takes device pointers");
+	if (src == dst)
+		return fail("dwt_hip_transform3d_op is out of place; use dwt_hip_transform3d for in-place volumes");
+	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
+		return fail("bad volume strides");
+	constexpr int kMaxLevels = 24;
+	if (levels > kMaxLevels)
+		return fail("too many levels");
+	if (levels >= 1 && (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2))
+		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
+	const long vsy = (long)stride_y / 4, vsz = (long)stride_z / 4;
+	if (levels < 1) {
+		// no levels: the reference's copy stage alone
+		hipError_t e = launch_lattice_copy((const float *)src, 1, vsy, vsz, (float *)dst, 1, vsy, vsz, nx, ny, nz, g.stream);
+		return e == hipSuccess ? 0 : fail("volume copy failed: %s", hipGetErrorString(e));
+	}
+	struct Lvl { const float *in; float *out; long sy, sz; int lx, ly, lz; } L[kMaxLevels];
+	L[0] = {(const float *)src, (float *)dst, vsy, vsz, nx, ny, nz};
+	size_t pool = 0;
+	for (int j = 1; j < levels; j++) {
+		L[j].lx = ceil_div_pow2(nx, j); L[j].ly = ceil_div_pow2(ny, j); L[j].lz = ceil_div_pow2(nz, j);
+		L[j].sy = align_up(L[j].lx, 4);
+		L[j].sz = L[j].sy * L[j].ly;
+		pool += (size_t)L[j].sz * L[j].lz;
+	}
+	if (levels > 1) {
+		if (grow(&g.host_a, &g.host_a_bytes, pool * 4) || grow(&g.host_b, &g.host_b_bytes, pool * 4))
+			return 1;
+		float *pa = (float *)g.host_a, *pb = (float *)g.host_b;
+		for (int j = 1; j < levels; j++) {
+			L[j].in = pa; L[j].out = pb;
+			pa += (size_t)L[j].sz * L[j].lz;
+			pb += (size_t)L[j].sz * L[j].lz;
+		}
+	}
+	for (int j = 0; j < levels; j++)
+		if (L[j].lz > 65535 || L[j].ly > 65535)
+			return fail("volume too large for the launch grid");
+	float *S = nullptr;
+	long s_sy = 0, s_sz = 0;
+	for (int j = 0; j < levels; j++) {
+		const Lvl &b = L[j];
+		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;
+		const long lsy = j + 1 < levels ? L[j + 1].sy : 0, lsz = j + 1 < levels ? L[j + 1].sz : 0;
+		VolFusedArgs fa{b.in, b.sy, b.sz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
+		if (g.vol.fused && !g.force_generic && vol_fused_applies(fa)) {
+			prof_before(j);
+			hipError_t e = launch_vol_fwd_fused(fa, g.vol, g.stream);
+			prof_after(j);
+			if (e != hipSuccess)
+				return fail("fused 3-D level launch failed: %s", hipGetErrorString(e));
+			continue;
+		}
+		// two passes through the scratch volume
+		if (!S) {
+			s_sy = align_up(nx, 4);
+			s_sz = s_sy * ny;
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
+				return 1;
+			S = (float *)g.stage_img;
+		}
+		FwdLevelArgs a;
+		a.in = b.in; a.in_pitch = b.sy; a.in_bstride = b.sz;
+		a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
+		a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
+		a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
+		hipError_t e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
+		if (e != hipSuccess)
+			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
+		e = launch_vol_z(false, S, s_sy, s_sz, b.out, b.sy, b.sz, b.lx, b.ly, b.lz, g.vol, g.stream, lll, lsy, lsz);
+		if (e != hipSuccess)
+			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
+	}
+	for (int j = levels - 1; j >= 1; j--) {
+		const Lvl &c = L[j], &par = L[j - 1];
+		hipError_t e = launch_lattice_copy(c.out, 1, c.sy, c.sz, par.out, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice scatter failed: %s", hipGetErrorString(e));
+	}
+	return 0;
 }
 
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)

@@ -92,7 +92,9 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 struct VolTuning {
 	int cpt = 8;        // columns per lane: 4 or 8 (two groups of 4, 256 columns apart; +4 % at 1024^3)
 	int tile_pairs = 0; // slice pairs per wave; 0 = choose from the volume depth
-	int nt = 0;         // bit 0 non-temporal stores, bit 1 non-temporal loads
+	int nt = -1;        // bit 0 non-temporal stores, bit 1 non-temporal loads; -1 = measured default
+	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
+	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it applies, 0 = two passes
 };
 
 // z pass of the 3-D path: CDF 9/7 float along the slice axis of an interleaved volume,
@@ -100,6 +102,21 @@ struct VolTuning {
 // even-x/even-y/even-z samples (the next level's input) are also written densely there.
 hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
 	int nx, int ny, int nz, const VolTuning &vt, hipStream_t s, float *lll = nullptr, long lll_sy = 0, long lll_sz = 0);
+
+// One forward 3-D level in ONE pass, out of place (in != out): x, y and z lifting fused.  A
+// workgroup owns 256 x 32 voxel columns and marches along z; see k_vol_fwd_fused.  Applies
+// when nx is a multiple of 256 and everything is 16 B aligned (vol_fused_applies).
+struct VolFusedArgs {
+	const float *in;
+	long in_sy, in_sz;
+	float *out;
+	long out_sy, out_sz;
+	float *lll; // optional dense copy of the even-even-even samples (next level's input)
+	long lll_sy, lll_sz;
+	int nx, ny, nz;
+};
+bool vol_fused_applies(const VolFusedArgs &a);
+hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s);
 
 // Strided 3-D copy (lattice pack/unpack for the levels >= 1 of the 3-D path);
 // strides in ELEMENTS, including the x strides.

@@ -1629,7 +1629,7 @@ template <bool INV, int CPT>
 static void vol_z_nt(int nt, dim3 grid, int threads, hipStream_t s, const float *in, long in_sy, long in_sz, float *out,
 	long out_sy, long out_sz, int nx, int ny, int nz, int tp, int vec_ok, float *lll, long lll_sy, long lll_sz)
 {
-	switch (nt & 3) {
+	switch ((nt < 0 ? 0 : nt) & 3) {
 	case 0: k_vol_z<INV, CPT, 0><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
 	case 1: k_vol_z<INV, CPT, 1><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
 	case 2: k_vol_z<INV, CPT, 2><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
@@ -1667,6 +1667,209 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 			vol_z_nt<false, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
 		else
 			vol_z_nt<false, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+	}
+	return hipGetLastError();
+}
+
+// ---- 3-D, one pass: x, y and z lifting of a level fused (forward, out of place) ----
+// "Slab-tiled z pass": a workgroup (4 waves) owns 256 x 32 voxel columns and marches along
+// z.  Per slice: each wave DMAs 10 of the tile's 40 input rows (32 + 4 halo rows each side,
+// row and column reflection in the source address) into its own LDS ring, one slice ahead;
+// lifts them horizontally in registers; parks the x-lifted rows in a workgroup-shared LDS
+// slab; after a barrier reads the 16 rows around its 8 output rows back, lifts them
+// vertically in registers; and feeds the 8 x 4 samples per lane into the streaming z
+// recurrence whose state (4 partial slices x 32 columns) stays in registers for the whole
+// march.  The intermediate volume of the two-pass path never exists: 8 B per voxel (+ 25 %
+// halo rows, + z warm-up) instead of 16.  Same arithmetic and operand order as
+// k_fwd_sweep / k_vol_z, hence the same bits.
+static __device__ __forceinline__ void wg_barrier_lds()
+{
+	// LDS traffic of this wave done, then the barrier; outstanding LDS-DMA keeps flying
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z)
+{
+	using W = Cdf97S;
+	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, TY = 32, NR = TY + 2 * K, RPW = NR / 4;
+	constexpr int kDmaPerSlice = 2 * RPW;
+	constexpr int kLdAux = (NT & 2) ? 2 : 0;
+	constexpr bool kNtStore = (NT & 1) != 0;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int c0 = blockIdx.x * TW, c = c0 + lane * CPT;
+	const int y0 = blockIdx.y * TY;
+	const int Zd = (a.nz + 1) >> 1;
+	const int A = blockIdx.z * tile_pairs_z;
+	if (A >= Zd)
+		return; // the whole workgroup leaves together
+	const int B = min(A + tile_pairs_z, Zd);
+	const int n_iter = (B - A) + K, q0 = A - K / 2;
+	const int n_slices = 2 * n_iter;
+
+	char *ring = smem + (size_t)wv * 2 * RPW * RS * 4;      // [2 slices][RPW rows][RS floats], wave-private
+	char *slab = smem + (size_t)4 * 2 * RPW * RS * 4;       // [NR rows][TW floats], shared
+	const unsigned ring_off = lds_offset(ring), slab_off = lds_offset(slab);
+	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
+
+	auto issue = [&](int t) {
+		const float *sl = a.in + (long)reflect(2 * q0 - 1 + t, a.nz) * a.in_sz;
+		char *buf = ring + (size_t)(t & 1) * RPW * RS * 4;
+#pragma unroll
+		for (int i = 0; i < RPW; i++) {
+			const int r = reflect(y0 - K + wv + 4 * i, a.ny);
+			const float *grow = sl + (long)r * a.in_sy;
+			char *lrow = buf + (size_t)i * RS * 4;
+			dma16<kLdAux>(grow + c, lrow); // the DMA places lane i's 16 B at lrow + 16 i
+			if (lane < 8)
+				dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
+		}
+	};
+
+	float st[K][8][CPT], ra[8][CPT];
+#pragma unroll
+	for (int s = 0; s < K; s++)
+#pragma unroll
+		for (int r = 0; r < 8; r++)
+#pragma unroll
+			for (int e = 0; e < CPT; e++)
+				st[s][r][e] = 0.f;
+
+	issue(0);
+	for (int t = 0; t < n_slices; t++) {
+		if (t + 1 < n_slices) {
+			issue(t + 1);
+			DWT_WAIT_VMCNT(kDmaPerSlice);
+		} else {
+			DWT_WAIT_VMCNT(0);
+		}
+		// horizontal lift of this wave's rows, parked in the shared slab
+		const unsigned buf = ring_off + (unsigned)(t & 1) * RPW * RS * 4;
+#pragma unroll
+		for (int i = 0; i < RPW; i++) {
+			const unsigned base = buf + (unsigned)i * RS * 4;
+			const unsigned own = base + lane * CPT * 4;
+			const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
+			const unsigned ra_ = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
+			u4 L4, O0, R4;
+			lds_read3(la, own, ra_, L4, O0, R4);
+			float x[CPT + 2 * K];
+#pragma unroll
+			for (int e = 0; e < K; e++) {
+				x[e] = from_bits<float>(L4[e]);
+				x[K + e] = from_bits<float>(O0[e]);
+				x[K + CPT + e] = from_bits<float>(R4[e]);
+			}
+			lift_fwd_regs<W, CPT + 2 * K>(x);
+			const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
+				to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
+			lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
+		}
+		wg_barrier_lds(); // the slab is complete
+
+		// vertical lift: slab rows 8 wv .. 8 wv + 15 give this wave's 8 output rows
+		u4 v[16];
+		{
+			const unsigned vb = slab_off + (unsigned)(8 * wv) * TW * 4 + lane * 16;
+			asm volatile(
+				"ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:1024\n\tds_read_b128 %2, %16 offset:2048\n\tds_read_b128 %3, %16 offset:3072\n\t"
+				"ds_read_b128 %4, %16 offset:4096\n\tds_read_b128 %5, %16 offset:5120\n\tds_read_b128 %6, %16 offset:6144\n\tds_read_b128 %7, %16 offset:7168\n\t"
+				"ds_read_b128 %8, %16 offset:8192\n\tds_read_b128 %9, %16 offset:9216\n\tds_read_b128 %10, %16 offset:10240\n\tds_read_b128 %11, %16 offset:11264\n\t"
+				"ds_read_b128 %12, %16 offset:12288\n\tds_read_b128 %13, %16 offset:13312\n\tds_read_b128 %14, %16 offset:14336\n\tds_read_b128 %15, %16 offset:15360\n\t"
+				"s_waitcnt lgkmcnt(0)\n\ts_barrier"
+				: "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+				  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+				: "v"(vb)
+				: "memory"); // the barrier: every wave has read the slab, the next slice may overwrite it
+		}
+		float cur[8][CPT];
+#pragma unroll
+		for (int e = 0; e < CPT; e++) {
+			float col[16];
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				col[j] = from_bits<float>(v[j][e]);
+			lift_fwd_regs<W, 16>(col);
+#pragma unroll
+			for (int r = 0; r < 8; r++)
+				cur[r][e] = W::fwd_scale(r & 1, col[K + r]);
+		}
+
+		// z: slices arrive as (2q-1, 2q); the odd one waits in registers for its partner
+		if (!(t & 1)) {
+#pragma unroll
+			for (int r = 0; r < 8; r++)
+#pragma unroll
+				for (int e = 0; e < CPT; e++)
+					ra[r][e] = cur[r][e];
+			continue;
+		}
+		const int it = t >> 1;
+		const int k = A + it - K;
+#pragma unroll
+		for (int r = 0; r < 8; r++) {
+			float o0[CPT], o1[CPT];
+#pragma unroll
+			for (int e = 0; e < CPT; e++) {
+				const float d1n = W::fwd_step(0, ra[r][e], st[0][r][e], cur[r][e]);
+				const float s1n = W::fwd_step(1, st[0][r][e], st[1][r][e], d1n);
+				const float d2n = W::fwd_step(2, st[1][r][e], st[2][r][e], s1n);
+				const float s2n = W::fwd_step(3, st[2][r][e], st[3][r][e], d2n);
+				o0[e] = W::fwd_scale(0, s2n);
+				o1[e] = W::fwd_scale(1, d2n);
+				st[0][r][e] = cur[r][e];
+				st[1][r][e] = d1n;
+				st[2][r][e] = s1n;
+				st[3][r][e] = d2n;
+			}
+			const int y = y0 + 8 * wv + r;
+			if (it >= K && y < a.ny) {
+				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + c;
+				store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
+				if (2 * k + 1 < a.nz)
+					store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
+				if (a.lll && !(r & 1))
+					*(u2 *)(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1)) = u2{to_bits(o0[0]), to_bits(o0[2])};
+			}
+		}
+	}
+}
+
+bool vol_fused_applies(const VolFusedArgs &a)
+{
+	return a.in != a.out && a.nx >= 256 && a.nx % 256 == 0 && a.ny >= 2 && a.nz >= 2 && aligned16(a.in) && aligned16(a.out) &&
+		a.in_sy % 4 == 0 && a.in_sz % 4 == 0 && a.out_sy % 4 == 0 && a.out_sz % 4 == 0 &&
+		(!a.lll || (((uintptr_t)a.lll & 7) == 0 && a.lll_sy % 2 == 0 && a.lll_sz % 2 == 0));
+}
+
+hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s)
+{
+	if (!vol_fused_applies(a))
+		return hipErrorInvalidValue;
+	const int Zd = (a.nz + 1) / 2;
+	const int ntx = a.nx / 256, nty = (a.ny + 31) / 32;
+	// z lines are split so that at least two rounds of workgroups exist (one workgroup per
+	// CU); longer marches amortise the 8-slice warm-up (1024^3: 128 pairs 2.13 ms, 64 pairs 2.25)
+	int tp = 128;
+	while (tp > 8 && (long)ntx * nty * ((Zd + tp - 1) / tp) < 512)
+		tp >>= 1;
+	if (vt.tile_pairs >= 4)
+		tp = vt.tile_pairs;
+	const int nzt = (Zd + tp - 1) / tp;
+	if (nty > 65535 || nzt > 65535)
+		return hipErrorInvalidValue;
+	const size_t lds = (size_t)4 * 2 * 10 * (256 + 8) * 4 + (size_t)40 * 256 * 4;
+	dim3 grid(ntx, nty, nzt);
+	if (vt.nt < 0 || (vt.nt & 1)) {
+		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<3>, lds))
+			return e;
+		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp);
+	} else {
+		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<2>, lds))
+			return e;
+		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp);
 	}
 	return hipGetLastError();
 }

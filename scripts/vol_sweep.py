@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 lv = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dwt.dwt_util_init(); dwt.use_torch_stream()
 V = torch.rand((n, n, n), device="cuda")
-DEFAULTS = dict(cpt=0, tile_pairs=0, waves=4, ring=0, wave_horiz=-1, xcd_swizzle=1, vol_cpt=8, vol_tile_pairs=0, vol_nt=0)
+DEFAULTS = dict(cpt=0, tile_pairs=0, waves=4, ring=0, wave_horiz=-1, xcd_swizzle=1, vol_cpt=8, vol_tile_pairs=0, vol_nt=-1)
 VARIANTS = [
     "", "vol_nt=1", "vol_nt=2", "vol_nt=3", "vol_cpt=8", "vol_cpt=8,vol_nt=3",
     "vol_tile_pairs=32", "vol_tile_pairs=128", "vol_tile_pairs=256", "vol_tile_pairs=512",

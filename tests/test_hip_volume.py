@@ -78,3 +78,44 @@ def test_volume_vs_oracle(dwt, oracle, shape, levels):
     assert np.array_equal(bits(rec), bits(want_rec))
     assert np.abs(rec - vol).max() < 1e-4
     d.free()
+
+
+@pytest.mark.parametrize("fused", [1, 0], ids=["fused", "two-pass"])
+@pytest.mark.parametrize("shape,levels", [((16, 16, 256), 1), ((37, 50, 256), 1), ((9, 7, 512), 1), ((64, 96, 256), 2),
+                                          ((40, 33, 768), 1), ((128, 128, 512), 3), ((66, 130, 1024), 3), ((33, 65, 129), 2),
+                                          ((2, 2, 256), 1), ((130, 3, 256), 1)],
+                         ids=lambda v: str(v))
+def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
+    """dwt_hip_transform3d_op (cdf97_3f_op_sep_horizontal_s semantics): one fused x+y+z pass per
+    level where the x size is a multiple of 256, two passes elsewhere; the source stays intact;
+    bit-identical either way."""
+    rng = np.random.default_rng(sum(shape) * 3 + levels)
+    vol = rng.random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), levels, False)
+    src = DevVol(dwt, vol)
+    dst = DevVol(dwt, np.full(shape, -5.0, np.float32))
+    nz, ny, nx = shape
+    dwt.set_option("vol_fused", fused)
+    try:
+        dwt.transform3d_op(src.ptr, dst.ptr, nx * 4, nx * ny * 4, nx, ny, nz, levels)
+    finally:
+        dwt.set_option("vol_fused", 1)
+    assert np.array_equal(bits(dst.get()), bits(want))
+    assert np.array_equal(bits(src.get()), bits(vol)), "source volume modified"
+    # the in-place inverse undoes it
+    dst.run(1, levels)
+    assert np.abs(dst.get() - vol).max() < 1e-4
+    src.free()
+    dst.free()
+
+
+def test_out_of_place_zero_levels_and_errors(dwt):
+    vol = np.random.default_rng(1).random((4, 5, 6), dtype=np.float32)
+    src = DevVol(dwt, vol)
+    dst = DevVol(dwt, np.zeros_like(vol))
+    dwt.transform3d_op(src.ptr, dst.ptr, 24, 120, 6, 5, 4, 0)
+    assert np.array_equal(dst.get(), vol)
+    with pytest.raises(dwt.DwtError):
+        dwt.transform3d_op(src.ptr, src.ptr, 24, 120, 6, 5, 4, 1)
+    src.free()
+    dst.free()

@@ -1689,11 +1689,12 @@ static __device__ __forceinline__ void wg_barrier_lds()
 }
 
 template <int NT>
-__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z)
+__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok)
 {
 	using W = Cdf97S;
-	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, TY = 32, NR = TY + 2 * K, RPW = NR / 4;
-	constexpr int kDmaPerSlice = 2 * RPW;
+	// the 8 output rows of a wave need x-lifted rows -4 .. +10 around its first row: the tile's
+	// 32 rows need 39 input rows; wave w stages rows w, w+4, ... (10, 10, 10, 9 of them)
+	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, TY = 32, NR = TY + 2 * K - 1, RPW = (NR + 3) / 4;
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
 	constexpr bool kNtStore = (NT & 1) != 0;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1709,22 +1710,37 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 	const int n_iter = (B - A) + K, q0 = A - K / 2;
 	const int n_slices = 2 * n_iter;
 
-	char *ring = smem + (size_t)wv * 2 * RPW * RS * 4;      // [2 slices][RPW rows][RS floats], wave-private
-	char *slab = smem + (size_t)4 * 2 * RPW * RS * 4;       // [NR rows][TW floats], shared
+	// LDS: [wave-private staging rows, one slice: NR x RS floats] [shared slab: NR x TW floats];
+	// 81 KiB, so that two workgroups share a CU and one computes while the other waits
+	char *ring = smem + (size_t)wv * RPW * RS * 4;
+	char *slab = smem + (size_t)NR * RS * 4;
 	const unsigned ring_off = lds_offset(ring), slab_off = lds_offset(slab);
 	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
+	// tiles that overhang the volume (or unaligned volumes) are staged column by column
+	const bool full = vec_ok && c0 + TW <= a.nx;
+	int colmap[CPT];
+#pragma unroll
+	for (int i = 0; i < CPT; i++)
+		colmap[i] = reflect(c0 + i * 64 + lane, a.nx);
 
 	auto issue = [&](int t) {
 		const float *sl = a.in + (long)reflect(2 * q0 - 1 + t, a.nz) * a.in_sz;
-		char *buf = ring + (size_t)(t & 1) * RPW * RS * 4;
 #pragma unroll
 		for (int i = 0; i < RPW; i++) {
-			const int r = reflect(y0 - K + wv + 4 * i, a.ny);
-			const float *grow = sl + (long)r * a.in_sy;
-			char *lrow = buf + (size_t)i * RS * 4;
-			dma16<kLdAux>(grow + c, lrow); // the DMA places lane i's 16 B at lrow + 16 i
-			if (lane < 8)
-				dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
+			if (wv + 4 * i < NR) {
+				const int r = reflect(y0 - K + wv + 4 * i, a.ny);
+				const float *grow = sl + (long)r * a.in_sy;
+				char *lrow = ring + (size_t)i * RS * 4;
+				if (full) {
+					dma16<kLdAux>(grow + c, lrow); // the DMA places lane i's 16 B at lrow + 16 i
+				} else {
+#pragma unroll
+					for (int e = 0; e < CPT; e++)
+						dma4<kLdAux>(grow + colmap[e], lrow + e * 256);
+				}
+				if (lane < 8)
+					dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
+			}
 		}
 	};
 
@@ -1739,59 +1755,58 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 
 	issue(0);
 	for (int t = 0; t < n_slices; t++) {
-		if (t + 1 < n_slices) {
-			issue(t + 1);
-			DWT_WAIT_VMCNT(kDmaPerSlice);
-		} else {
-			DWT_WAIT_VMCNT(0);
-		}
+		DWT_WAIT_VMCNT(0); // this slice's rows have landed (and the previous stores are out)
 		// horizontal lift of this wave's rows, parked in the shared slab
-		const unsigned buf = ring_off + (unsigned)(t & 1) * RPW * RS * 4;
 #pragma unroll
 		for (int i = 0; i < RPW; i++) {
-			const unsigned base = buf + (unsigned)i * RS * 4;
-			const unsigned own = base + lane * CPT * 4;
-			const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
-			const unsigned ra_ = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
-			u4 L4, O0, R4;
-			lds_read3(la, own, ra_, L4, O0, R4);
-			float x[CPT + 2 * K];
+			if (wv + 4 * i < NR) {
+				const unsigned base = ring_off + (unsigned)i * RS * 4;
+				const unsigned own = base + lane * CPT * 4;
+				const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
+				const unsigned ra_ = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
+				u4 L4, O0, R4;
+				lds_read3(la, own, ra_, L4, O0, R4);
+				float x[CPT + 2 * K];
 #pragma unroll
-			for (int e = 0; e < K; e++) {
-				x[e] = from_bits<float>(L4[e]);
-				x[K + e] = from_bits<float>(O0[e]);
-				x[K + CPT + e] = from_bits<float>(R4[e]);
+				for (int e = 0; e < K; e++) {
+					x[e] = from_bits<float>(L4[e]);
+					x[K + e] = from_bits<float>(O0[e]);
+					x[K + CPT + e] = from_bits<float>(R4[e]);
+				}
+				lift_fwd_regs<W, CPT + 2 * K>(x);
+				const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
+					to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
+				lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
 			}
-			lift_fwd_regs<W, CPT + 2 * K>(x);
-			const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
-				to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
-			lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
 		}
+		// the staging rows are consumed: the next slice's DMA flies during the rest of the iteration
+		if (t + 1 < n_slices)
+			issue(t + 1);
 		wg_barrier_lds(); // the slab is complete
 
-		// vertical lift: slab rows 8 wv .. 8 wv + 15 give this wave's 8 output rows
-		u4 v[16];
+		// vertical lift: slab rows 8 wv .. 8 wv + 14 give this wave's 8 output rows
+		u4 v[15];
 		{
 			const unsigned vb = slab_off + (unsigned)(8 * wv) * TW * 4 + lane * 16;
 			asm volatile(
-				"ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:1024\n\tds_read_b128 %2, %16 offset:2048\n\tds_read_b128 %3, %16 offset:3072\n\t"
-				"ds_read_b128 %4, %16 offset:4096\n\tds_read_b128 %5, %16 offset:5120\n\tds_read_b128 %6, %16 offset:6144\n\tds_read_b128 %7, %16 offset:7168\n\t"
-				"ds_read_b128 %8, %16 offset:8192\n\tds_read_b128 %9, %16 offset:9216\n\tds_read_b128 %10, %16 offset:10240\n\tds_read_b128 %11, %16 offset:11264\n\t"
-				"ds_read_b128 %12, %16 offset:12288\n\tds_read_b128 %13, %16 offset:13312\n\tds_read_b128 %14, %16 offset:14336\n\tds_read_b128 %15, %16 offset:15360\n\t"
+				"ds_read_b128 %0, %15\n\tds_read_b128 %1, %15 offset:1024\n\tds_read_b128 %2, %15 offset:2048\n\tds_read_b128 %3, %15 offset:3072\n\t"
+				"ds_read_b128 %4, %15 offset:4096\n\tds_read_b128 %5, %15 offset:5120\n\tds_read_b128 %6, %15 offset:6144\n\tds_read_b128 %7, %15 offset:7168\n\t"
+				"ds_read_b128 %8, %15 offset:8192\n\tds_read_b128 %9, %15 offset:9216\n\tds_read_b128 %10, %15 offset:10240\n\tds_read_b128 %11, %15 offset:11264\n\t"
+				"ds_read_b128 %12, %15 offset:12288\n\tds_read_b128 %13, %15 offset:13312\n\tds_read_b128 %14, %15 offset:14336\n\t"
 				"s_waitcnt lgkmcnt(0)\n\ts_barrier"
 				: "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-				  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+				  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14])
 				: "v"(vb)
 				: "memory"); // the barrier: every wave has read the slab, the next slice may overwrite it
 		}
 		float cur[8][CPT];
 #pragma unroll
 		for (int e = 0; e < CPT; e++) {
-			float col[16];
+			float col[15];
 #pragma unroll
-			for (int j = 0; j < 16; j++)
+			for (int j = 0; j < 15; j++)
 				col[j] = from_bits<float>(v[j][e]);
-			lift_fwd_regs<W, 16>(col);
+			lift_fwd_regs<W, 15>(col);
 #pragma unroll
 			for (int r = 0; r < 8; r++)
 				cur[r][e] = W::fwd_scale(r & 1, col[K + r]);
@@ -1827,11 +1842,25 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 			const int y = y0 + 8 * wv + r;
 			if (it >= K && y < a.ny) {
 				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + c;
-				store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
-				if (2 * k + 1 < a.nz)
-					store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
-				if (a.lll && !(r & 1))
-					*(u2 *)(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1)) = u2{to_bits(o0[0]), to_bits(o0[2])};
+				const bool hz = 2 * k + 1 < a.nz;
+				float *pl = a.lll && !(r & 1) ? a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1) : nullptr;
+				if (full) {
+					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
+					if (hz)
+						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
+					if (pl)
+						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+				} else {
+#pragma unroll
+					for (int e = 0; e < CPT; e++)
+						if (c + e < a.nx) {
+							p[e] = o0[e];
+							if (hz)
+								p[a.out_sz + e] = o1[e];
+							if (pl && !(e & 1))
+								pl[e >> 1] = o0[e];
+						}
+				}
 			}
 		}
 	}
@@ -1839,8 +1868,13 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 
 bool vol_fused_applies(const VolFusedArgs &a)
 {
-	return a.in != a.out && a.nx >= 256 && a.nx % 256 == 0 && a.ny >= 2 && a.nz >= 2 && aligned16(a.in) && aligned16(a.out) &&
-		a.in_sy % 4 == 0 && a.in_sz % 4 == 0 && a.out_sy % 4 == 0 && a.out_sz % 4 == 0 &&
+	// narrow volumes leave most of a 256-column tile idle: they take the two-pass path
+	return a.in != a.out && a.nx >= 128 && a.ny >= 2 && a.nz >= 2;
+}
+
+static bool vol_fused_vec_ok(const VolFusedArgs &a)
+{
+	return aligned16(a.in) && aligned16(a.out) && a.in_sy % 4 == 0 && a.in_sz % 4 == 0 && a.out_sy % 4 == 0 && a.out_sz % 4 == 0 &&
 		(!a.lll || (((uintptr_t)a.lll & 7) == 0 && a.lll_sy % 2 == 0 && a.lll_sz % 2 == 0));
 }
 
@@ -1849,27 +1883,27 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	if (!vol_fused_applies(a))
 		return hipErrorInvalidValue;
 	const int Zd = (a.nz + 1) / 2;
-	const int ntx = a.nx / 256, nty = (a.ny + 31) / 32;
-	// z lines are split so that at least two rounds of workgroups exist (one workgroup per
-	// CU); longer marches amortise the 8-slice warm-up (1024^3: 128 pairs 2.13 ms, 64 pairs 2.25)
+	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
+	// z lines are split so that at least two rounds of workgroups exist (two workgroups per
+	// CU); longer marches amortise the 8-slice warm-up
 	int tp = 128;
-	while (tp > 8 && (long)ntx * nty * ((Zd + tp - 1) / tp) < 512)
+	while (tp > 8 && (long)ntx * nty * ((Zd + tp - 1) / tp) < 1024)
 		tp >>= 1;
 	if (vt.tile_pairs >= 4)
 		tp = vt.tile_pairs;
 	const int nzt = (Zd + tp - 1) / tp;
 	if (nty > 65535 || nzt > 65535)
 		return hipErrorInvalidValue;
-	const size_t lds = (size_t)4 * 2 * 10 * (256 + 8) * 4 + (size_t)40 * 256 * 4;
+	const size_t lds = (size_t)39 * (256 + 8) * 4 + (size_t)39 * 256 * 4;
 	dim3 grid(ntx, nty, nzt);
 	if (vt.nt < 0 || (vt.nt & 1)) {
 		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<3>, lds))
 			return e;
-		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp);
+		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a));
 	} else {
 		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<2>, lds))
 			return e;
-		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp);
+		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a));
 	}
 	return hipGetLastError();
 }

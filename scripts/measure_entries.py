@@ -62,15 +62,22 @@ def main():
     m = timeit(lambda: dwt.dwt_cdf97_2f_s(h, n*4, 4, n, n, n, n, J), reps=3, warm=1); rep("cdf97 fwd 8192^2 J=5 HOST pointer (H2D + kernels + D2H)", *m, n*n, alg)
     hs = np.random.default_rng(0).random((512, 512), dtype=np.float32)
     m = timeit(lambda: dwt.dwt_cdf97_2f_s(hs, 2048, 4, 512, 512, 512, 512, -1), reps=10, warm=2); rep("cdf97 fwd 512^2 full HOST pointer (examples/simple size)", *m, 512*512, sum(2*4*(512>>j)**2 for j in range(9)))
-    # 3-D
+    # 3-D: in place (two passes per level) and out of place (one fused pass per level)
     for nn, lv in ((512, 3), (1024, 3)):
         try:
-            V = torch.rand((nn, nn, nn), device="cuda")
-            m = timeit(lambda: dwt.transform3d(0, V, nn*4, nn*nn*4, nn, nn, nn, lv), reps=5, warm=2)
+            V = torch.rand((nn, nn, nn), device="cuda"); O = torch.empty_like(V)
             vox = nn**3; algv = sum(8*((nn>>j)**3) for j in range(lv))
-            rep(f"cdf97 3-D fwd {nn}^3 {lv} levels in place", *m, vox, algv)
+            m = timeit(lambda: dwt.transform3d_op(V, O, nn*4, nn*nn*4, nn, nn, nn, lv), reps=5, warm=2)
+            rep(f"cdf97 3-D fwd {nn}^3 {lv} levels OUT OF PLACE (fused x+y+z levels)", *m, vox, algv)
+            m = timeit(lambda: dwt.transform3d_op(V, O, nn*4, nn*nn*4, nn, nn, nn, 1), reps=5, warm=2)
+            rep(f"cdf97 3-D fwd {nn}^3 1 level OUT OF PLACE (fused x+y+z)", *m, vox, 8*vox)
+            del O
+            m = timeit(lambda: dwt.transform3d(0, V, nn*4, nn*nn*4, nn, nn, nn, lv), reps=5, warm=2)
+            rep(f"cdf97 3-D fwd {nn}^3 {lv} levels in place (two passes per level)", *m, vox, algv)
             m = timeit(lambda: dwt.transform3d(0, V, nn*4, nn*nn*4, nn, nn, nn, 1), reps=5, warm=2)
             rep(f"cdf97 3-D fwd {nn}^3 1 level in place", *m, vox, 8*vox)
+            m = timeit(lambda: dwt.transform3d(1, V, nn*4, nn*nn*4, nn, nn, nn, lv), reps=5, warm=2)
+            rep(f"cdf97 3-D inv {nn}^3 {lv} levels in place", *m, vox, algv)
             del V
         except Exception as e:
             print("3-D", nn, "failed:", e)

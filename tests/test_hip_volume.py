@@ -83,11 +83,12 @@ def test_volume_vs_oracle(dwt, oracle, shape, levels):
 @pytest.mark.parametrize("fused", [1, 0], ids=["fused", "two-pass"])
 @pytest.mark.parametrize("shape,levels", [((16, 16, 256), 1), ((37, 50, 256), 1), ((9, 7, 512), 1), ((64, 96, 256), 2),
                                           ((40, 33, 768), 1), ((128, 128, 512), 3), ((66, 130, 1024), 3), ((33, 65, 129), 2),
-                                          ((2, 2, 256), 1), ((130, 3, 256), 1)],
+                                          ((2, 2, 256), 1), ((130, 3, 256), 1), ((20, 40, 300), 1), ((33, 35, 129), 1),
+                                          ((18, 70, 1000), 2), ((24, 24, 515), 1)],
                          ids=lambda v: str(v))
 def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
     """dwt_hip_transform3d_op (cdf97_3f_op_sep_horizontal_s semantics): one fused x+y+z pass per
-    level where the x size is a multiple of 256, two passes elsewhere; the source stays intact;
+    level for volumes at least 128 samples wide (whole or overhanging 256-column tiles), two passes elsewhere; the source stays intact;
     bit-identical either way."""
     rng = np.random.default_rng(sum(shape) * 3 + levels)
     vol = rng.random(shape, dtype=np.float32)

@@ -1521,7 +1521,8 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;
 		const long lsy = j + 1 < levels ? L[j + 1].sy : 0, lsz = j + 1 < levels ? L[j + 1].sz : 0;
 		VolFusedArgs fa{b.in, b.sy, b.sz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
-		if (g.vol.fused && !g.force_generic && vol_fused_applies(fa)) {
+		const bool can_fuse = fa.in != fa.out && fa.nx >= 2 && fa.ny >= 2 && fa.nz >= 2;
+		if (!g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(fa)) || (g.vol.fused >= 2 && can_fuse))) {
 			prof_before(j);
 			hipError_t e = launch_vol_fwd_fused(fa, g.vol, g.stream);
 			prof_after(j);

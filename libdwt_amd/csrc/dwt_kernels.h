@@ -105,8 +105,8 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 
 // One forward 3-D level in ONE pass, out of place (in != out): x, y and z lifting fused.  A
 // workgroup owns 256 x 32 voxel columns and marches along z; see k_vol_fwd_fused.  Applies
-// to volumes at least 128 samples wide (vol_fused_applies); overhanging or unaligned tiles are
-// staged column by column.
+// to volumes at least 128 samples wide with about one workgroup per CU (vol_fused_applies);
+// overhanging or unaligned tiles are staged column by column.
 struct VolFusedArgs {
 	const float *in;
 	long in_sy, in_sz;

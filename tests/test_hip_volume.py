@@ -84,7 +84,7 @@ def test_volume_vs_oracle(dwt, oracle, shape, levels):
 @pytest.mark.parametrize("shape,levels", [((16, 16, 256), 1), ((37, 50, 256), 1), ((9, 7, 512), 1), ((64, 96, 256), 2),
                                           ((40, 33, 768), 1), ((128, 128, 512), 3), ((66, 130, 1024), 3), ((33, 65, 129), 2),
                                           ((2, 2, 256), 1), ((130, 3, 256), 1), ((20, 40, 300), 1), ((33, 35, 129), 1),
-                                          ((18, 70, 1000), 2), ((24, 24, 515), 1)],
+                                          ((18, 70, 1000), 2), ((24, 24, 515), 1), ((200, 520, 600), 2), ((129, 1000, 513), 1)],
                          ids=lambda v: str(v))
 def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
     """dwt_hip_transform3d_op (cdf97_3f_op_sep_horizontal_s semantics): one fused x+y+z pass per
@@ -96,7 +96,8 @@ def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
     src = DevVol(dwt, vol)
     dst = DevVol(dwt, np.full(shape, -5.0, np.float32))
     nz, ny, nx = shape
-    dwt.set_option("vol_fused", fused)
+    # fused: 2 = the one-pass kernel wherever it can run (small test volumes included), 1 = where it pays
+    dwt.set_option("vol_fused", 2 if fused else 0)
     try:
         dwt.transform3d_op(src.ptr, dst.ptr, nx * 4, nx * ny * 4, nx, ny, nz, levels)
     finally:

@@ -599,7 +599,8 @@ def test_finish_releases_and_context_stays_usable(dwt, oracle):
 
 def test_extreme_shapes_fused_equals_line_passes():
     """Maximum sizes (SURVEY s8c edge cases): 32768^2 (4 GiB), 64 x 2^20, 2^20 x 64, odd
-    70001-wide rows, 12 levels: the fused sweeps equal the exact line-pass kernels bit for
+    70001-wide rows, 12 levels, the interleaved layout, and 3-D volumes up to 1024^3 (fused
+    one-pass level vs two passes): the fused kernels equal the exact / two-pass ones bit for
     bit and the round trip closes.  Own process (torch supplies the device tensors)."""
     import os
     import subprocess
@@ -610,7 +611,7 @@ def test_extreme_shapes_fused_equals_line_passes():
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "large_sanity.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if "round-trip" in l]
-    assert len(lines) == 9, out.stdout
+    assert len(lines) == 12, out.stdout
     for l in lines:
         assert "fused == line passes: True" in l, l
         err = float(l.rsplit(" ", 1)[1])

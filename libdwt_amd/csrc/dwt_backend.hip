@@ -840,6 +840,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.vol.nt = value;
 	else if (!strcmp(name, "vol_fused"))
 		g.vol.fused = value;
+	else if (!strcmp(name, "vol_swizzle"))
+		g.vol.swizzle = value;
 	else if (!strcmp(name, "pipeline"))
 		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else

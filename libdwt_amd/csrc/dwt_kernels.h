@@ -94,7 +94,8 @@ struct VolTuning {
 	int tile_pairs = 0; // slice pairs per wave; 0 = choose from the volume depth
 	int nt = -1;        // bit 0 non-temporal stores, bit 1 non-temporal loads; -1 = measured default
 	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
-	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it applies, 0 = two passes
+	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes
+	int swizzle = 1;    // fused level: hand contiguous runs of tiles to one XCD
 };
 
 // z pass of the 3-D path: CDF 9/7 float along the slice axis of an interleaved volume,

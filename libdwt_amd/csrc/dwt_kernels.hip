@@ -1689,7 +1689,7 @@ static __device__ __forceinline__ void wg_barrier_lds()
 }
 
 template <int NT>
-__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok)
+__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
 {
 	using W = Cdf97S;
 	// the 8 output rows of a wave need x-lifted rows -4 .. +10 around its first row: the tile's
@@ -1700,10 +1700,14 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int c0 = blockIdx.x * TW, c = c0 + lane * CPT;
-	const int y0 = blockIdx.y * TY;
+	// workgroup -> tile: x tiles fastest, then y tiles, then z tiles; with the XCD swizzle an
+	// XCD (workgroups id % 8) owns a contiguous run of tiles, so the halo rows and columns that
+	// neighbouring tiles share are hits in that XCD's L2
+	const int bid = tile_block_id(swz);
+	const int c0 = (bid % ntx) * TW, c = c0 + lane * CPT;
+	const int y0 = ((bid / ntx) % nty) * TY;
 	const int Zd = (a.nz + 1) >> 1;
-	const int A = blockIdx.z * tile_pairs_z;
+	const int A = (bid / (ntx * nty)) * tile_pairs_z;
 	if (A >= Zd)
 		return; // the whole workgroup leaves together
 	const int B = min(A + tile_pairs_z, Zd);
@@ -1899,18 +1903,19 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	if (vt.tile_pairs >= 4)
 		tp = vt.tile_pairs;
 	const int nzt = (Zd + tp - 1) / tp;
-	if (nty > 65535 || nzt > 65535)
+	if ((long)ntx * nty * nzt > 0x7fffffffL)
 		return hipErrorInvalidValue;
 	const size_t lds = (size_t)39 * (256 + 8) * 4 + (size_t)39 * 256 * 4;
-	dim3 grid(ntx, nty, nzt);
+	dim3 grid(ntx * nty * nzt);
+	const int swz = vt.swizzle;
 	if (vt.nt < 0 || (vt.nt & 1)) {
 		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<3>, lds))
 			return e;
-		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a));
+		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
 	} else {
 		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<2>, lds))
 			return e;
-		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a));
+		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
 	}
 	return hipGetLastError();
 }

@@ -37,7 +37,7 @@ out = [f"# Round {tag[1:].lstrip('0') or '0'} — fused 3-D level (`k_vol_fwd_fu
        "    VARIANTS=vol_fused=1 rocprofv3 --kernel-trace [--stats | --pmc ...] -- python3 scripts/vol_op_bench.py 1024 3", "",
        f"- level-0 launches: {len(dur)}, average {avg_us:.1f} us (min {min(dur)/1e3:.1f}, max {max(dur)/1e3:.1f}) under the profiler; grid {grid_l0} threads = {grid_l0//256} workgroups of 4 waves",
        f"- algorithmic bytes per launch (8 B per voxel): {alg/1e6:.0f} MB -> {alg/avg_us/1e3:.0f} GB/s = {alg/avg_us/1e3/8000:.3f} of the 8 TB/s HBM3E peak",
-       f"- HBM fetch (FETCH_SIZE x 2, gfx950 correction): {fetch/1e6:.0f} MB = {fetch/(alg/2):.3f} x the input volume (the 22 % halo rows and the z warm-up are mostly L2 hits)",
+       f"- HBM fetch (FETCH_SIZE x 2, gfx950 correction): {fetch/1e6:.0f} MB = {fetch/(alg/2):.3f} x the input volume (halo rows 7/32, halo columns fetched as 4 B DMAs out of neighbouring lines, 8-slice z warm-up per march)",
        f"- HBM write (WRITE_SIZE): {write/1e6:.0f} MB (output volume {alg/2/1e6:.0f} MB + dense next-level copy on multi-level calls; non-temporal stores)",
        f"- L2: hit {pmc.get('TCC_HIT_sum',0):.4g}, miss {pmc.get('TCC_MISS_sum',0):.4g} -> hit rate {pmc.get('TCC_HIT_sum',0)/max(1,pmc.get('TCC_HIT_sum',0)+pmc.get('TCC_MISS_sum',0)):.3f}",
        f"- waves {waves:.0f}; wave cycles {pmc.get('SQ_WAVE_CYCLES',0):.4g}; issuing {pmc.get('SQ_ACTIVE_INST_ANY',0)/max(1,pmc.get('SQ_WAVE_CYCLES',1)):.2f} of wave cycles; "

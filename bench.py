@@ -99,6 +99,80 @@ def cpu_baseline(size, levels):
                       f"pitch {pitch_elems * 4} B; {detail}"}
 
 
+def other_workload(args, dwt, torch, dist, world, rank, local_rank):
+    """The other BASELINE.json configs through the same contract (one JSON line, whole-job rate,
+    barrier + synchronize on both sides, max over ranks): config3 = int CDF 5/3 4096^2 3 levels
+    forward + inverse; config4 = float 9/7 forward 4096^2 5 levels, 32 images per GPU (256 over 8
+    GPUs); config5 = float 9/7 forward 3-D 1024^3 3 levels, out of place."""
+    dev = torch.device("cuda", local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    w = args.workload
+    if w == "config3":
+        n, J, nb = 4096, 3, 16
+        src = torch.randint(-32768, 32768, (nb, n, n), generator=gen, device=dev, dtype=torch.int32)
+        dst = torch.empty_like(src)
+        back = torch.empty_like(src)
+        def step():
+            dwt.transform2d_batch("cdf53_i", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
+            dwt.transform2d_batch("cdf53_i", 1, dst, back, n * n * 4, nb, n * 4, n, n, J)
+        units, unit, dtype = nb * n * n, "Gsamples/s", "i32"
+        alg = 2 * algorithmic_bytes(n, n, J) * nb
+        metric = "Gsamples/s CDF 5/3 2-D int forward+inverse, 4096^2 3-level"
+        name = f"CDF 5/3 forward + inverse 2-D int32, {n}x{n}, {J} levels, {nb} device-resident images per step per GPU"
+        check = lambda: bool(torch.equal(back, src))
+    elif w == "config4":
+        n, J, nb = 4096, 5, 32
+        src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
+        dst = torch.empty_like(src)
+        def step():
+            dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
+        units, unit, dtype = nb * n * n, "Gsamples/s", "f32"
+        alg = algorithmic_bytes(n, n, J) * nb
+        metric = "Gsamples/s CDF 9/7 2-D fwd float, batch of 4096^2 5-level"
+        name = f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, {nb} device-resident images per step per GPU (256 over 8 GPUs)"
+        check = lambda: True
+    else:
+        n, J = 1024, 3
+        src = torch.rand((n, n, n), generator=gen, device=dev, dtype=torch.float32)
+        dst = torch.empty_like(src)
+        def step():
+            dwt.transform3d_op(src, dst, n * 4, n * n * 4, n, n, n, J)
+        units, unit, dtype = n ** 3, "Gvoxels/s", "f32"
+        alg = sum(8 * ((n >> j) ** 3) for j in range(J))
+        metric = "Gvoxels/s CDF 9/7 3-D fwd float, 1024^3 3-level"
+        name = f"CDF 9/7 forward 3-D float, {n}^3, {J} levels, out of place (cdf97_3f_op semantics), one volume per step per GPU"
+        check = lambda: True
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    from libdwt_amd.batch import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device=dev)
+    ok = check()
+    if rank == 0:
+        ach = alg * args.steps / elapsed / 1e9
+        print(json.dumps({
+            "metric": metric, "value": round(world * units * args.steps / elapsed / 1e9, 3), "unit": unit, "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": name, "parallelism": f"batch-sharded x{world}", "round_trip_exact": ok},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "whole step (all levels): algorithmic bytes / step time"},
+        }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +184,8 @@ def main():
     ap.add_argument("--inplace", action="store_true", help="time the in-place entry dwt_cdf97_2f_s instead of _s2")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")
+    ap.add_argument("--workload", default="headline", choices=["headline", "config3", "config4", "config5"],
+                    help="headline = BASELINE.json's metric (default); config3/4/5 = the other BASELINE configs, same JSON contract")
     args = ap.parse_args()
 
     import torch
@@ -136,6 +212,12 @@ def main():
         dwt.set_option(k, int(v))
     stream = torch.cuda.current_stream()
     dwt.set_stream(stream.cuda_stream)
+
+    if args.workload != "headline":
+        other_workload(args, dwt, torch, dist if use_dist else None, world, rank, local_rank)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     n, J, nb = args.size, args.levels, args.images
     dev = torch.device("cuda", local_rank)
@@ -186,7 +268,7 @@ def main():
 
     # HBM traffic of the dominant kernel from the PMC passes of the committed profile
     # (profiles/<tag>_pmc_level0.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE per
-    # launch of 4 images); scaled to this run's images per launch.  None if absent.
+    # launch of 8 images); scaled to this run's images per launch.  None if absent.
     traffic, traffic_src = None, None
     try:
         import glob

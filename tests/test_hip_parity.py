@@ -377,6 +377,14 @@ def test_c_example_program(dwt, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "host round trip: success" in out.stderr and "device round trip: success" in out.stderr
+    # examples/volume3d.c: the out-of-place 3-D entry and the interleaved-layout 2-D entries from C
+    exe = tmp_path / "volume3d"
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "volume3d.c"), "-o", str(exe),
+                           "-L", libdir, "-l:libdwt_hip.so", "-Wl,-rpath," + libdir, "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "volume round trip: success" in out.stderr and "interleaved round trip: success" in out.stderr
 
 
 def test_harness_helpers(dwt):

@@ -302,8 +302,16 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 {
 	if (n_lines <= 0 || N <= 0)
 		return 0;
-	if (N == 1 && (w == kCdf53I || w == kCdf97I))
+	if (N == 1 && (w == kCdf53I || w == kCdf97I)) {
+		// the int kernels leave a lone sample as it is (src/libdwt.c:10961); out of place that
+		// still means the samples have to arrive in the destination
+		if (in.p != out.p) {
+			if (side_join())
+				return 1;
+			return copy_rect(out, 0, 0, in, 0, 0, frame_w, frame_h);
+		}
 		return 0;
+	}
 	if (side_join())
 		return 1;
 	const bool alias = in.p == out.p;

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised self-consistency soak on the device: fused sweeps vs the exact line-pass kernels
+(option generic) on random shapes / levels / wavelets / entries, bit for bit, plus round trips.
+python scripts/stress.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import libdwt_amd as dwt
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+dwt.dwt_util_init(); dwt.use_torch_stream()
+t_end = time.time() + secs
+n_cases = bad = 0
+def rand_dim():
+    r = rng.random()
+    if r < 0.15: return int(rng.integers(1, 12))
+    if r < 0.6: return int(rng.integers(12, 700))
+    return int(rng.integers(700, 3300))
+while time.time() < t_end:
+    kind = rng.choice(["mallat", "mallat", "interleaved", "volume"])
+    if kind == "volume":
+        nz, ny, nx = [int(rng.integers(2, 200)) for _ in range(2)] + [int(rng.integers(2, 900))]
+        lv = int(rng.integers(1, 4))
+        while (min(nx, ny, nz) + (1 << (lv - 1)) - 1) >> (lv - 1) < 2:
+            lv -= 1
+        a = torch.rand((nz, ny, nx), device="cuda"); f = torch.empty_like(a); g = torch.empty_like(a)
+        dwt.set_option("vol_fused", 2); dwt.transform3d_op(a, f, nx * 4, nx * ny * 4, nx, ny, nz, lv)
+        dwt.set_option("vol_fused", 0); dwt.transform3d_op(a, g, nx * 4, nx * ny * 4, nx, ny, nz, lv)
+        dwt.set_option("vol_fused", 1)
+        h = a.clone(); dwt.transform3d(0, h, nx * 4, nx * ny * 4, nx, ny, nz, lv)
+        ok = torch.equal(f, g) and torch.equal(f, h)
+        dwt.transform3d(1, h, nx * 4, nx * ny * 4, nx, ny, nz, lv)
+        ok = ok and (h - a).abs().max().item() < 1e-4
+        desc = f"volume {nz}x{ny}x{nx} J={lv}"
+    else:
+        h_, w_ = rand_dim(), rand_dim()
+        pitch = w_ + int(rng.integers(0, 3)) * 4
+        J = int(rng.integers(-1, 7)); d1 = int(rng.integers(0, 2))
+        if kind == "mallat":
+            wav = str(rng.choice(["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"]))
+            if wav.endswith("_i"):
+                a = torch.randint(-32768, 32768, (h_, pitch), device="cuda", dtype=torch.int32)
+            else:
+                a = torch.rand((h_, pitch), device="cuda")
+            inplace = bool(rng.integers(0, 2))
+            outs = []
+            for generic in (0, 1):
+                dwt.set_option("generic", generic)
+                src = a.clone(); dst = src if inplace else torch.full_like(a, 7)
+                j = dwt._fwd(dwt.WAVELET_ID[wav], src, dst, pitch * 4, 4, w_, h_, w_, h_, J, d1, 0, "f")
+                fwd = dst.clone()
+                dwt._inv(dwt.WAVELET_ID[wav], dst, dst, pitch * 4, 4, w_, h_, w_, h_, j, d1, 0, "i")
+                outs.append((fwd, dst.clone(), j))
+            dwt.set_option("generic", 0)
+            ok = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+            rec = outs[0][1][:, :w_]
+            if outs[0][2] > 0 or inplace:  # zero levels, out of place: the reference writes nothing to dst either
+                ok = ok and (torch.equal(rec, a[:, :w_]) if wav.endswith("_i") else (rec - a[:, :w_]).abs().max().item() < 1e-3)
+            desc = f"{wav} {h_}x{w_} pitch {pitch} J={J} d1={d1} inplace={inplace}"
+        else:
+            wav = str(rng.choice(["cdf97_s", "cdf53_s"])); flav = int(rng.integers(0, 2))
+            a = torch.rand((h_, pitch), device="cuda")
+            inplace = bool(rng.integers(0, 2))
+            outs = []
+            for generic in (0, 1):
+                dwt.set_option("generic", generic)
+                src = a.clone(); dst = src if inplace else torch.full_like(a, 7)
+                j = dwt.transform2d_interleaved(wav, 0, flav, src, dst, pitch * 4, 4, w_, h_, None, None, J, d1)
+                outs.append((dst.clone(), j))
+            dwt.set_option("generic", 0)
+            f0, f1 = outs[0][0][:, :w_], outs[1][0][:, :w_]
+            exact = wav == "cdf53_s" and flav == 0
+            ok = outs[0][1] == outs[1][1] and (torch.equal(f0, f1) if exact else (f0 - f1).abs().max().item() <= 1e-5 * max(1e-30, f1.abs().max().item()))
+            if flav == 0 and (outs[0][1] > 0 or inplace or True):
+                r = outs[0][0].clone()
+                dwt.transform2d_interleaved(wav, 1, 0, r, r, pitch * 4, 4, w_, h_, None, None, outs[0][1], d1)
+                ok = ok and (r[:, :w_] - a[:, :w_]).abs().max().item() < 1e-3
+            desc = f"interleaved {wav} flavour {flav} {h_}x{w_} pitch {pitch} J={J} d1={d1} inplace={inplace}"
+    n_cases += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH:", desc, flush=True)
+torch.cuda.synchronize()
+print(f"stress: {n_cases} cases, {bad} mismatches, seed {seed}", flush=True)
+sys.exit(1 if bad else 0)

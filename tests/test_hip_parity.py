@@ -624,3 +624,40 @@ def test_extreme_shapes_fused_equals_line_passes():
         assert "fused == line passes: True" in l, l
         err = float(l.rsplit(" ", 1)[1])
         assert err == 0.0 if "cdf53_i" in l else err < 1e-5, l
+
+
+@pytest.mark.parametrize("wname", ["cdf53_i", "cdf97_i"])
+@pytest.mark.parametrize("shape", [(280, 1), (1, 300), (4, 1), (1, 2)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_int_single_sample_lines_out_of_place(dwt, oracle, wname, shape):
+    """The int kernels leave a lone sample as it is (src/libdwt.c:10961); with distinct source and
+    destination the samples still have to arrive in the destination (found by scripts/stress.py)."""
+    ff, fi, dt = NAMES[wname]
+    h, w = shape
+    img = rand_img(np.random.default_rng(h * 31 + w), h, w, dt)
+    want = img.copy()
+    jw = oracle.fwd(ff, want, -1, decompose_one=1)
+    pitch = 64
+    pad = np.zeros((h, pitch // 4), dt)
+    pad[:, :w] = img
+    a = dwt.DeviceImage(h, w, 4, pitch).upload(pad)
+    b = dwt.DeviceImage(h, w, 4, pitch).upload(np.full_like(pad, 77))
+    j = dwt._fwd(dwt.WAVELET_ID[wname], a.ptr, b.ptr, pitch, 4, w, h, w, h, -1, 1, 0, "fwd")
+    assert j == jw
+    assert np.array_equal(b.download(dt)[:, :w], want)
+    dwt._inv(dwt.WAVELET_ID[wname], b.ptr, a.ptr, pitch, 4, w, h, w, h, j, 1, 0, "inv")
+    assert np.array_equal(a.download(dt)[:, :w], img)
+    a.free()
+    b.free()
+
+
+def test_randomised_soak():
+    """scripts/stress.py for 20 s: random shapes, levels, wavelets, entries and layouts; the fused
+    kernels against the exact line-pass / two-pass kernels bit for bit, plus round trips."""
+    import os
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress.py"), "20", "7"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, (out.stdout[-2000:], out.stderr[-1000:])

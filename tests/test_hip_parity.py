@@ -636,7 +636,7 @@ def test_int_single_sample_lines_out_of_place(dwt, oracle, wname, shape):
     img = rand_img(np.random.default_rng(h * 31 + w), h, w, dt)
     want = img.copy()
     jw = oracle.fwd(ff, want, -1, decompose_one=1)
-    pitch = 64
+    pitch = ((w * 4 + 63) // 64) * 64
     pad = np.zeros((h, pitch // 4), dt)
     pad[:, :w] = img
     a = dwt.DeviceImage(h, w, 4, pitch).upload(pad)

@@ -21,7 +21,7 @@ def rand_dim():
     if r < 0.6: return int(rng.integers(12, 700))
     return int(rng.integers(700, 3300))
 while time.time() < t_end:
-    kind = rng.choice(["mallat", "mallat", "interleaved", "volume"])
+    kind = rng.choice(["mallat", "mallat", "interleaved", "volume", "sparse", "batch", "host"])
     if kind == "volume":
         nz, ny, nx = [int(rng.integers(2, 200)) for _ in range(2)] + [int(rng.integers(2, 900))]
         lv = int(rng.integers(1, 4))
@@ -36,6 +36,59 @@ while time.time() < t_end:
         dwt.transform3d(1, h, nx * 4, nx * ny * 4, nx, ny, nz, lv)
         ok = ok and (h - a).abs().max().item() < 1e-4
         desc = f"volume {nz}x{ny}x{nx} J={lv}"
+    elif kind == "sparse":
+        # size_i < size_o with and without zero padding: fused vs generic, in place
+        h_, w_ = rand_dim() + 1, rand_dim() + 1
+        six, siy = int(rng.integers(1, w_ + 1)), int(rng.integers(1, h_ + 1))
+        J = int(rng.integers(-1, 6)); d1 = int(rng.integers(0, 2)); zp = int(rng.integers(0, 2))
+        wav = str(rng.choice(["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"]))
+        a = torch.randint(-32768, 32768, (h_, w_), device="cuda", dtype=torch.int32) if wav.endswith("_i") else torch.rand((h_, w_), device="cuda")
+        outs = []
+        for generic in (0, 1):
+            dwt.set_option("generic", generic)
+            buf = a.clone()
+            j = dwt._fwd(dwt.WAVELET_ID[wav], buf, buf, w_ * 4, 4, w_, h_, six, siy, J, d1, zp, "f")
+            fwd = buf.clone()
+            dwt._inv(dwt.WAVELET_ID[wav], buf, buf, w_ * 4, 4, w_, h_, six, siy, j, d1, zp, "i")
+            outs.append((fwd, buf.clone(), j))
+        dwt.set_option("generic", 0)
+        ok = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+        desc = f"sparse {wav} {h_}x{w_} inner {siy}x{six} J={J} d1={d1} zp={zp}"
+    elif kind == "batch":
+        # one launch per level over a batch vs image by image
+        h_, w_ = int(rng.integers(2, 900)), int(rng.integers(2, 900))
+        nb = int(rng.integers(2, 7)); J = int(rng.integers(-1, 6)); inv = int(rng.integers(0, 2))
+        wav = str(rng.choice(["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"]))
+        a = torch.randint(-32768, 32768, (nb, h_, w_), device="cuda", dtype=torch.int32) if wav.endswith("_i") else torch.rand((nb, h_, w_), device="cuda")
+        b = torch.empty_like(a); c = torch.empty_like(a)
+        ok = True
+        try:
+            j = dwt.transform2d_batch(wav, inv, a, b, h_ * w_ * 4, nb, w_ * 4, w_, h_, J)
+            for k in range(nb):
+                if inv:
+                    dwt._inv(dwt.WAVELET_ID[wav], a[k], c[k], w_ * 4, 4, w_, h_, w_, h_, J, 0, 0, "i")
+                else:
+                    dwt._fwd(dwt.WAVELET_ID[wav], a[k], c[k], w_ * 4, 4, w_, h_, w_, h_, J, 0, 0, "f")
+            ok = torch.equal(b, c) if j > 0 else True
+        except dwt.DwtError as e:
+            ok = "both sides >= 2" in str(e)  # batches refuse levels that shrink to a single line
+        desc = f"batch {wav} {nb}x{h_}x{w_} J={J} inverse={inv}"
+    elif kind == "host":
+        # host image with a byte pitch that is not a multiple of 4 (libdwt's prime strides) vs device result
+        h_, w_ = int(rng.integers(1, 600)), int(rng.integers(1, 600))
+        J = int(rng.integers(-1, 6)); d1 = int(rng.integers(0, 2))
+        wav = str(rng.choice(["cdf97_s", "cdf53_i", "cdf53_s"]))
+        pitch_b = dwt.lib.dwt_util_get_opt_stride(w_ * 4) if rng.integers(0, 2) else w_ * 4 + 4 * int(rng.integers(0, 4))
+        hb = np.zeros(pitch_b * h_ + 8, np.uint8)
+        img = rng.integers(-32768, 32768, (h_, w_)).astype(np.int32) if wav.endswith("_i") else rng.random((h_, w_), dtype=np.float32)
+        for y in range(h_):
+            hb[y * pitch_b:y * pitch_b + w_ * 4] = img[y].view(np.uint8)
+        j = dwt.FORWARD[wav](hb, pitch_b, 4, w_, h_, w_, h_, J, d1)
+        got = np.stack([hb[y * pitch_b:y * pitch_b + w_ * 4].view(img.dtype) for y in range(h_)])
+        d = torch.from_numpy(img.copy()).cuda()
+        j2 = dwt.FORWARD[wav](d, w_ * 4, 4, w_, h_, w_, h_, J, d1)
+        ok = j == j2 and np.array_equal(got.view(np.uint32), d.cpu().numpy().view(np.uint32))
+        desc = f"host {wav} {h_}x{w_} pitch {pitch_b} B J={J} d1={d1}"
     else:
         h_, w_ = rand_dim(), rand_dim()
         pitch = w_ + int(rng.integers(0, 3)) * 4

@@ -1,0 +1,284 @@
+// dwt_interleaved.hip -- kernels of the interleaved (in-place lifting) layout beyond the sweeps:
+// the exact phase-ordered line kernel, the compose / decompose passes over the level lattices,
+// and the device-side view helpers (conv_show, compare).
+#include "dwt_device.h"
+
+namespace dwt {
+
+// ---- interleaved layout: one phase of the reference's phase-ordered lifting, exact ----
+// Same windowed evaluation as k_line_pass, with every step masked to the index range the
+// phase gives it.  Mirrored window entries (symmetric extension) carry the index they
+// mirror, so they receive the same masked updates as their originals.
+template <class W, bool INV>
+__global__ __launch_bounds__(256) void k_il_phase(const char *__restrict__ src, char *__restrict__ dst,
+	long line_stride, long elem_stride, int n_lines, int N, int lanes_along_lines, IlPhase ph)
+{
+	using T = typename W::T;
+	constexpr int K = W::K, NW = 2 * K + 1;
+	const int fast = blockIdx.x * blockDim.x + threadIdx.x;
+	const int slow = blockIdx.y;
+	const int line = lanes_along_lines ? fast : slow;
+	const int k = lanes_along_lines ? slow : fast;
+	if (line >= n_lines || k >= ((N + 1) >> 1))
+		return;
+	const char *s = src + (long)line * line_stride;
+	char *d = dst + (long)line * line_stride;
+	// forward: w[0] is the even sample 2k-K; inverse: the odd sample 2k-K+1
+	const int first = 2 * k - K + (INV ? 1 : 0);
+	T w[NW];
+	int idx[NW];
+#pragma unroll
+	for (int j = 0; j < NW; j++) {
+		idx[j] = reflect(first + j, N);
+		w[j] = *(const T *)(s + (long)idx[j] * elem_stride);
+		if (INV && idx[j] >= ph.sc_lo && idx[j] <= ph.sc_hi)
+			w[j] = W::inv_scale(idx[j] & 1, w[j]);
+	}
+#pragma unroll
+	for (int st = 0; st < K; st++) {
+#pragma unroll
+		for (int j = st + 1; j <= NW - 2 - st; j += 2)
+			if (idx[j] >= ph.lo[st] && idx[j] <= ph.hi[st])
+				w[j] = INV ? W::inv_step(st, w[j], w[j - 1], w[j + 1]) : W::fwd_step(st, w[j], w[j - 1], w[j + 1]);
+	}
+	const int c0 = INV ? K - 1 : K; // window position of sample 2k
+#pragma unroll
+	for (int e = 0; e < 2; e++) {
+		const int i = 2 * k + e;
+		if (i < N) {
+			T v = w[c0 + e];
+			if (!INV && i >= ph.sc_lo && i <= ph.sc_hi)
+				v = W::fwd_scale(e, v);
+			*(T *)(d + (long)i * elem_stride) = v;
+		}
+	}
+}
+
+template <class W>
+static hipError_t il_phase_t(bool inverse, const void *src, void *dst, long line_stride, long elem_stride, int n_lines, int N,
+	bool lanes_along_lines, const IlPhase &ph, hipStream_t s)
+{
+	if (n_lines <= 0 || N < 2)
+		return hipErrorInvalidValue;
+	const int npairs = (N + 1) >> 1;
+	const int fast = lanes_along_lines ? n_lines : npairs;
+	const int slow = lanes_along_lines ? npairs : n_lines;
+	const int bs = fast >= 256 ? 256 : 64;
+	dim3 grid((fast + bs - 1) / bs, slow);
+	if (inverse)
+		k_il_phase<W, true><<<grid, bs, 0, s>>>((const char *)src, (char *)dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph);
+	else
+		k_il_phase<W, false><<<grid, bs, 0, s>>>((const char *)src, (char *)dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph);
+	return hipGetLastError();
+}
+
+hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
+	int n_lines, int N, bool lanes_along_lines, const IlPhase &ph, hipStream_t s)
+{
+	switch (w) {
+	case kCdf97S: return il_phase_t<Cdf97S>(inverse, src, dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph, s);
+	case kCdf53SNew: return il_phase_t<Cdf53SNew>(inverse, src, dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph, s);
+	default: break;
+	}
+	return hipErrorInvalidValue;
+}
+
+// ---- interleaved layout: all levels' lattices in one pass over the even rows ----
+// A lattice-1 point (p, q) (image column 2p, row 2q) belongs to level
+// j = 1 + min(ctz(p), ctz(q)) capped at J-1; its sample sits at (p >> (j-1), q >> (j-1))
+// of that level's dense image.  One thread owns 8 image columns of one even row.
+static __device__ __forceinline__ int il_level_of(int p, int q, int J)
+{
+	const int t = __builtin_ctz((unsigned)(p | q) | (1u << 30)); // ctz(0) -> 30
+	const int j = 1 + t;
+	return j < J ? j : J - 1;
+}
+
+__global__ __launch_bounds__(256) void k_il_compose(const float *__restrict__ base, long base_pitch, float *__restrict__ out,
+	long out_pitch, int W, int H, IlPyramid py, int vec_ok, int out_dense)
+{
+	// grid.x = even rows (may exceed 65535), grid.y = blocks of 2048 columns
+	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
+	const int q = blockIdx.x, y = 2 * q;
+	if (x0 >= W || y >= H)
+		return;
+	const float *b = base + (long)y * base_pitch + x0;
+	float *o = out + (long)(out_dense ? q : y) * out_pitch + x0;
+	const int p0 = x0 >> 1;
+	float v[8];
+	const bool vec = vec_ok && x0 + 8 <= W;
+	if (vec) {
+		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			v[e] = from_bits<float>(t0[e]);
+			v[4 + e] = from_bits<float>(t1[e]);
+		}
+		const u4 l1 = *(const u4 *)(py.p[1] + (long)q * py.pitch[1] + p0);
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			v[2 * i] = from_bits<float>(l1[i]);
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			if (x0 + e < W)
+				v[e] = (e & 1) ? b[e] : py.p[1][(long)q * py.pitch[1] + p0 + (e >> 1)];
+	}
+	if (py.J > 2 && !(q & 1)) {
+		// p0 is a multiple of 4: the points p0 and p0+2 lie on deeper lattices
+#pragma unroll
+		for (int i = 0; i < 4; i += 2)
+			if (x0 + 2 * i < W) {
+				const int p = p0 + i, j = il_level_of(p, q, py.J);
+				v[2 * i] = py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + (p >> (j - 1))];
+			}
+	}
+	if (vec) {
+		*(u4 *)o = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
+		*(u4 *)(o + 4) = u4{to_bits(v[4]), to_bits(v[5]), to_bits(v[6]), to_bits(v[7])};
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			if (x0 + e < W)
+				o[e] = v[e];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_il_decompose(const float *__restrict__ img, long pitch, int W, int H, IlPyramid py, int vec_ok)
+{
+	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
+	const int q = blockIdx.x, y = 2 * q;
+	if (x0 >= W || y >= H)
+		return;
+	const float *b = img + (long)y * pitch + x0;
+	const int p0 = x0 >> 1;
+	float v[4];
+	const bool vec = vec_ok && x0 + 8 <= W;
+	if (vec) {
+		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
+		v[0] = from_bits<float>(t0[0]); v[1] = from_bits<float>(t0[2]);
+		v[2] = from_bits<float>(t1[0]); v[3] = from_bits<float>(t1[2]);
+		*(u4 *)(py.p[1] + (long)q * py.pitch[1] + p0) = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			if (x0 + 2 * i < W) {
+				v[i] = b[2 * i];
+				py.p[1][(long)q * py.pitch[1] + p0 + i] = v[i];
+			}
+	}
+	// deeper lattices: level j takes the points whose p and q are multiples of 2^(j-1)
+	for (int j = 2; j < py.J; j++) {
+		const int m = (1 << (j - 1)) - 1;
+		if (q & m)
+			break;
+#pragma unroll
+		for (int i = 0; i < 4; i += 2)
+			if (!((p0 + i) & m) && x0 + 2 * i < W)
+				py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + ((p0 + i) >> (j - 1))] = v[i];
+	}
+}
+
+static int il_vec_ok(const float *a, long ap, const float *b, long bp, const IlPyramid &py)
+{
+	return aligned16(a) && aligned16(b) && ap % 4 == 0 && bp % 4 == 0 && py.J > 1 && aligned16(py.p[1]) && py.pitch[1] % 4 == 0;
+}
+
+hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H, const IlPyramid &py, hipStream_t s,
+	bool out_dense)
+{
+	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
+		return hipErrorInvalidValue;
+	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
+	k_il_compose<<<grid, 256, 0, s>>>(base, base_pitch, out, out_pitch, W, H, py, il_vec_ok(base, base_pitch, out, out_pitch, py), out_dense);
+	return hipGetLastError();
+}
+
+hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s)
+{
+	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
+		return hipErrorInvalidValue;
+	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
+	k_il_decompose<<<grid, 256, 0, s>>>(img, pitch, W, H, py, il_vec_ok(img, pitch, img, pitch, py));
+	return hipGetLastError();
+}
+
+} // namespace dwt
+
+// ---------------------------------------------------------------------------------
+// 4. device-side view helpers: conv_show and compare on images
+//    that stay in HBM between the forward and the inverse transform
+// ---------------------------------------------------------------------------------
+namespace dwt {
+
+// dwt_util_conv_show_s (src/libdwt.c:21075-21117): log(1 + |c|*100) / 10 with the log
+// taken in double as log_i_s does (:21010); non-finite results become 0.
+__global__ __launch_bounds__(256) void k_conv_show_s(const char *__restrict__ src, char *__restrict__ dst, long pitch, int w, int h)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= w || y >= h)
+		return;
+	const float c = *(const float *)(src + (long)y * pitch + (long)x * 4);
+	float t = (float)log((double)(1.f + fabsf(c) * 100.f));
+	t /= 10.f;
+	if (!isfinite(t))
+		t = 0.f;
+	*(float *)(dst + (long)y * pitch + (long)x * 4) = t;
+}
+
+// dwt_util_conv_show_i (src/libdwt.c:21020-21044): |c|
+__global__ __launch_bounds__(256) void k_conv_show_i(const char *__restrict__ src, char *__restrict__ dst, long pitch, int w, int h)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= w || y >= h)
+		return;
+	const int c = *(const int *)(src + (long)y * pitch + (long)x * 4);
+	*(int *)(dst + (long)y * pitch + (long)x * 4) = c < 0 ? -c : c;
+}
+
+// dwt_util_compare_s / _i (src/libdwt.c:1593-1620, 1531-1558): count of differing
+// elements (float: |a-b| > 1e-3 or any NaN/Inf; int: a != b) accumulated in *result
+template <bool IS_INT>
+__global__ __launch_bounds__(256) void k_compare(const char *__restrict__ p1, const char *__restrict__ p2, long pitch, int w, int h, unsigned *result)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	bool differ = false;
+	if (x < w && y < h) {
+		if (IS_INT) {
+			differ = *(const int *)(p1 + (long)y * pitch + (long)x * 4) != *(const int *)(p2 + (long)y * pitch + (long)x * 4);
+		} else {
+			const float a = *(const float *)(p1 + (long)y * pitch + (long)x * 4);
+			const float b = *(const float *)(p2 + (long)y * pitch + (long)x * 4);
+			differ = isnan(a) || isinf(a) || isnan(b) || isinf(b) || fabsf(a - b) > 1e-3f;
+		}
+	}
+	const unsigned long long m = __ballot(differ);
+	if ((threadIdx.x & 63) == 0 && m)
+		atomicAdd(result, (unsigned)__popcll(m));
+}
+
+hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s)
+{
+	if (w <= 0 || h <= 0)
+		return hipSuccess;
+	dim3 grid((w + 255) / 256, h);
+	if (is_int)
+		k_conv_show_i<<<grid, 256, 0, s>>>((const char *)src, (char *)dst, pitch, w, h);
+	else
+		k_conv_show_s<<<grid, 256, 0, s>>>((const char *)src, (char *)dst, pitch, w, h);
+	return hipGetLastError();
+}
+
+hipError_t launch_compare(bool is_int, const void *p1, const void *p2, long pitch, int w, int h, unsigned *result, hipStream_t s)
+{
+	if (w <= 0 || h <= 0)
+		return hipSuccess;
+	dim3 grid((w + 255) / 256, h);
+	if (is_int)
+		k_compare<true><<<grid, 256, 0, s>>>((const char *)p1, (const char *)p2, pitch, w, h, result);
+	else
+		k_compare<false><<<grid, 256, 0, s>>>((const char *)p1, (const char *)p2, pitch, w, h, result);
+	return hipGetLastError();
+}
+
+} // namespace dwt

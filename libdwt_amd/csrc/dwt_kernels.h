@@ -1,5 +1,5 @@
 // dwt_kernels.h -- launch interface between the backend (dwt_backend.hip) and the
-// HIP kernels (dwt_kernels.hip).  Internal to the shared library.
+// HIP kernels (dwt_sweep2d.hip, dwt_vol3d.hip, dwt_interleaved.hip).  Internal to the shared library.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

@@ -1,4 +1,4 @@
-// dwt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the lifting DWT.
+// dwt_sweep2d.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the 2-D lifting DWT.
 //
 // Two families:
 //
@@ -28,19 +28,9 @@
 // Arithmetic order follows the reference exactly (rows before columns, etc.) and
 // this file is compiled with -ffp-contract=off, so float results are bit-identical
 // to libdwt's CPU path; int results are exact.
-#include "dwt_kernels.h"
-#include "dwt_lift.h"
-
-#include <stdint.h>
-#include <type_traits>
+#include "dwt_device.h"
 
 namespace dwt {
-
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
-
-template <class T> static __device__ __forceinline__ T from_bits(unsigned u) { return __builtin_bit_cast(T, u); }
-template <class T> static __device__ __forceinline__ unsigned to_bits(T v) { return __builtin_bit_cast(unsigned, v); }
 
 // ---------------------------------------------------------------------------------
 // 1. generic exact line pass
@@ -132,112 +122,6 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 // ---------------------------------------------------------------------------------
 // 2. fused tile sweeps
 // ---------------------------------------------------------------------------------
-#define DWT_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
-// AUX selects the cache policy of the LDS-DMA: 0 = default, 2 = non-temporal (the
-// image is read once per level; nt keeps it from displacing reusable lines).
-template <int AUX = 0>
-static __device__ __forceinline__ void dma16(const void *g, void *l)
-{
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-		(__attribute__((address_space(3))) void *)l, 16, 0, AUX);
-}
-
-template <int AUX = 0>
-static __device__ __forceinline__ void dma4(const void *g, void *l)
-{
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-		(__attribute__((address_space(3))) void *)l, 4, 0, AUX);
-}
-
-template <bool NT, class V>
-static __device__ __forceinline__ void store_vec(V *p, V v)
-{
-	if constexpr (NT)
-		__builtin_nontemporal_store(v, p);
-	else
-		*p = v;
-}
-
-// LDS reads go through inline asm: hipcc (ROCm 7.2) otherwise drains every
-// outstanding LDS-DMA with vmcnt(0) before any ds_read, which would serialise the
-// prefetch ring.  The wait for the data is inside the statement, so the outputs
-// cannot be consumed early.
-static __device__ __forceinline__ void lds_read3(unsigned a0, unsigned a1, unsigned a2, u4 &r0, u4 &r1, u4 &r2)
-{
-	asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-		: "=&v"(r0), "=&v"(r1), "=&v"(r2)
-		: "v"(a0), "v"(a1), "v"(a2)
-		: "memory");
-}
-
-static __device__ __forceinline__ void lds_read4(unsigned a0, unsigned a1, unsigned a2, u4 &r0, u4 &r1, u4 &r2, u4 &r3)
-{
-	asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:16\n\tds_read_b128 %3, %6\n\ts_waitcnt lgkmcnt(0)"
-		: "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-		: "v"(a0), "v"(a1), "v"(a2)
-		: "memory");
-}
-
-static __device__ __forceinline__ void lds_read2x3(unsigned a0, unsigned a1, unsigned a2, u2 &r0, u2 &r1, u2 &r2)
-{
-	asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-		: "=&v"(r0), "=&v"(r1), "=&v"(r2)
-		: "v"(a0), "v"(a1), "v"(a2)
-		: "memory");
-}
-
-static __device__ __forceinline__ void lds_read1(unsigned a0, u4 &r0)
-{
-	asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(a0) : "memory");
-}
-
-static __device__ __forceinline__ void lds_read2o(unsigned a0, unsigned a1, u4 &r0, u4 &r1, u4 &r2)
-{
-	asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %4\n\ts_waitcnt lgkmcnt(0)"
-		: "=&v"(r0), "=&v"(r1), "=&v"(r2)
-		: "v"(a0), "v"(a1)
-		: "memory");
-}
-
-static __device__ __forceinline__ void lds_read2(unsigned a0, unsigned a1, u4 &r0, u4 &r1)
-{
-	asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-		: "=&v"(r0), "=&v"(r1)
-		: "v"(a0), "v"(a1)
-		: "memory");
-}
-
-// Wavefront shifts by one lane (DPP, no LDS traffic): lane t receives lane t-1 / t+1;
-// the wave's first / last lane keeps its own value (replaced by the caller).
-static __device__ __forceinline__ unsigned from_left_lane(unsigned v)
-{
-	return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
-
-static __device__ __forceinline__ unsigned from_right_lane(unsigned v)
-{
-	return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-}
-
-static __device__ __forceinline__ unsigned lds_offset(const void *p)
-{
-	return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const void *)p);
-}
-
-
-// Workgroup -> tile mapping shared by both sweeps.  Each XCD has its own L2 and
-// workgroups are dealt round-robin over the 8 XCDs, so with `swz` consecutive
-// tiles are handed to the same XCD (neighbouring tiles share halo lines).
-static __device__ __forceinline__ int tile_block_id(int swz)
-{
-	int b = blockIdx.x;
-	const int nb = gridDim.x;
-	if (swz && (nb & 7) == 0)
-		b = (b & 7) * (nb >> 3) + (b >> 3);
-	return b;
-}
-
 struct SweepGeom {
 	int tile_pairs, ntx, swz, in_vec_ok, out_vec_ok;
 	int ll_vec_ok = 0; // interleaved layout with a dense LL copy: that copy takes 8 B stores
@@ -898,17 +782,6 @@ static int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batc
 	return tp;
 }
 
-static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
-
-// Dynamic LDS above 64 KiB per workgroup has to be granted per kernel (gfx950 has
-// 160 KiB per CU).
-static hipError_t allow_lds(const void *kernel, size_t bytes)
-{
-	if (bytes <= 48 * 1024)
-		return hipSuccess;
-	return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 template <class W, int CPT, int RING, int NT, bool IL = false>
 static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, hipStream_t s)
 {
@@ -1076,18 +949,6 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 struct Fwd2Geom {
 	int tile_pairs1, ntx, swz, in_vec_ok, out_vec_ok;
 };
-
-static __device__ __forceinline__ void lds_write4(unsigned addr, u4 v)
-{
-	asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-
-static __device__ __forceinline__ unsigned lds_read_dword(unsigned addr)
-{
-	unsigned r;
-	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
-	return r;
-}
 
 template <class W, int RING, int NT>
 __global__ __launch_bounds__(256) void k_fwd2_sweep(Fwd2LevelArgs a, Fwd2Geom g)
@@ -1470,753 +1331,7 @@ hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning 
 	return hipErrorInvalidValue;
 }
 
-// ---------------------------------------------------------------------------------
-// 3. z pass of the 3-D path and the lattice copy
-// ---------------------------------------------------------------------------------
-// One wave owns 256 contiguous x columns of one row y and marches along z with the
-// lifting state in registers (the z neighbours of a sample are whole slices apart, but
-// each access is a contiguous 1 KiB row segment).  Same streaming recurrences as the
-// vertical pass of the 2-D sweeps; out of place, because the symmetric extension at
-// the far end re-reads slices the sweep has already produced.
-template <bool INV, int CPT, int NT>
-__global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, long in_sy, long in_sz,
-	float *__restrict__ out, long out_sy, long out_sz, int nx, int ny, int nz, int tile_pairs, int vec_ok,
-	float *__restrict__ lll, long lll_sy, long lll_sz)
-{
-	using W = Cdf97S;
-	constexpr int K = 4, NV = CPT / 4;
-	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
-	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	// a lane owns NV groups of 4 columns, 256 columns apart: every load/store instruction
-	// of the wave is one contiguous 1 KiB segment
-	const int c = (blockIdx.x * nwv + wv) * 64 * CPT + lane * 4;
-	const int y = blockIdx.y;
-	const int Zd = (nz + 1) >> 1;
-	const int A = blockIdx.z * tile_pairs;
-	if (A >= Zd || (blockIdx.x * nwv + wv) * 64 * CPT >= nx)
-		return;
-	const int B = min(A + tile_pairs, Zd);
-	const int n_iter = (B - A) + K;
-	const int q0 = A - K / 2;
-	const bool vec = vec_ok && (c + 256 * (NV - 1) + 4 <= nx);
-	const float *src = in + (long)y * in_sy + c;
-	float *dst = out + (long)y * out_sy + c;
-
-	auto load = [&](int slice, float (&v)[CPT]) {
-		const float *p = src + (long)reflect(slice, nz) * in_sz;
-		if (vec) {
-#pragma unroll
-			for (int g = 0; g < NV; g++) {
-				const u4 t = (NT & 2) ? __builtin_nontemporal_load((const u4 *)(p + 256 * g)) : *(const u4 *)(p + 256 * g);
-#pragma unroll
-				for (int e = 0; e < 4; e++)
-					v[4 * g + e] = from_bits<float>(t[e]);
-			}
-		} else {
-#pragma unroll
-			for (int e = 0; e < CPT; e++) {
-				const int x = c + 256 * (e >> 2) + (e & 3);
-				v[e] = (x < nx) ? p[256 * (e >> 2) + (e & 3)] : 0.f;
-			}
-		}
-	};
-	auto store = [&](int slice, const float (&v)[CPT]) {
-		float *p = dst + (long)slice * out_sz;
-		if (vec) {
-#pragma unroll
-			for (int g = 0; g < NV; g++) {
-				const u4 t = u4{to_bits(v[4 * g]), to_bits(v[4 * g + 1]), to_bits(v[4 * g + 2]), to_bits(v[4 * g + 3])};
-				if (NT & 1)
-					__builtin_nontemporal_store(t, (u4 *)(p + 256 * g));
-				else
-					*(u4 *)(p + 256 * g) = t;
-			}
-		} else {
-#pragma unroll
-			for (int e = 0; e < CPT; e++)
-				if (c + 256 * (e >> 2) + (e & 3) < nx)
-					p[256 * (e >> 2) + (e & 3)] = v[e];
-		}
-	};
-
-	float st[K][CPT];
-#pragma unroll
-	for (int s = 0; s < K; s++)
-#pragma unroll
-		for (int e = 0; e < CPT; e++)
-			st[s][e] = 0.f;
-
-	float na[CPT], nb[CPT];
-	load(2 * q0 - (INV ? 0 : 1), na);
-	load(2 * q0 + (INV ? 1 : 0), nb);
-	for (int it = 0; it < n_iter; it++) {
-		const int q = q0 + it;
-		float ra[CPT], rb[CPT];
-#pragma unroll
-		for (int e = 0; e < CPT; e++) {
-			ra[e] = na[e];
-			rb[e] = nb[e];
-		}
-		if (it + 1 < n_iter) { // software prefetch of the next pair of slices
-			load(2 * (q + 1) - (INV ? 0 : 1), na);
-			load(2 * (q + 1) + (INV ? 1 : 0), nb);
-		}
-		float o0[CPT], o1[CPT];
-#pragma unroll
-		for (int e = 0; e < CPT; e++) {
-			if constexpr (!INV) {
-				// ra = slice 2q-1 (odd), rb = slice 2q (even)
-				const float d1n = W::fwd_step(0, ra[e], st[0][e], rb[e]);
-				const float s1n = W::fwd_step(1, st[0][e], st[1][e], d1n);
-				const float d2n = W::fwd_step(2, st[1][e], st[2][e], s1n);
-				const float s2n = W::fwd_step(3, st[2][e], st[3][e], d2n);
-				o0[e] = W::fwd_scale(0, s2n);
-				o1[e] = W::fwd_scale(1, d2n);
-				st[0][e] = rb[e];
-				st[1][e] = d1n;
-				st[2][e] = s1n;
-				st[3][e] = d2n;
-			} else {
-				// ra = slice 2q (even, s2'), rb = slice 2q+1 (odd, d2')
-				const float s2 = W::inv_scale(0, ra[e]), d2 = W::inv_scale(1, rb[e]);
-				const float s1n = W::inv_step(0, s2, st[0][e], d2);
-				const float d1n = W::inv_step(1, st[0][e], st[1][e], s1n);
-				const float en = W::inv_step(2, st[1][e], st[2][e], d1n);
-				const float on = W::inv_step(3, st[2][e], st[3][e], en);
-				o0[e] = on; // slice 2q-3
-				o1[e] = en; // slice 2q-2
-				st[0][e] = d2;
-				st[1][e] = s1n;
-				st[2][e] = d1n;
-				st[3][e] = en;
-			}
-		}
-		if constexpr (!INV) {
-			if (it >= K) {
-				const int k = A + it - K;
-				store(2 * k, o0);
-				if (2 * k + 1 < nz)
-					store(2 * k + 1, o1);
-				// forward multi-level: the next level's input (even x, even y, even z = LLL)
-				// also goes out densely, so that no lattice gather is needed
-				if (lll && !(y & 1)) {
-					float *p = lll + (long)k * lll_sz + (long)(y >> 1) * lll_sy + (c >> 1);
-#pragma unroll
-					for (int g = 0; g < NV; g++) {
-						if (vec) {
-							*(u2 *)(p + 128 * g) = u2{to_bits(o0[4 * g]), to_bits(o0[4 * g + 2])};
-						} else {
-							if (c + 256 * g < nx)
-								p[128 * g] = o0[4 * g];
-							if (c + 256 * g + 2 < nx)
-								p[128 * g + 1] = o0[4 * g + 2];
-						}
-					}
-				}
-			}
-		} else {
-			const int pe = q - 1, po = q - 2;
-			if (po >= A && po < B && 2 * po + 1 < nz)
-				store(2 * po + 1, o0);
-			if (pe >= A && pe < B)
-				store(2 * pe, o1);
-		}
-	}
-}
-
-template <bool INV, int CPT>
-static void vol_z_nt(int nt, dim3 grid, int threads, hipStream_t s, const float *in, long in_sy, long in_sz, float *out,
-	long out_sy, long out_sz, int nx, int ny, int nz, int tp, int vec_ok, float *lll, long lll_sy, long lll_sz)
-{
-	switch ((nt < 0 ? 0 : nt) & 3) {
-	case 0: k_vol_z<INV, CPT, 0><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
-	case 1: k_vol_z<INV, CPT, 1><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
-	case 2: k_vol_z<INV, CPT, 2><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
-	default: k_vol_z<INV, CPT, 3><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
-	}
-}
-
-hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
-	int nx, int ny, int nz, const VolTuning &vt, hipStream_t s, float *lll, long lll_sy, long lll_sz)
-{
-	if (nx < 1 || ny < 1 || nz < 2 || ny > 65535 || (lll && (inverse || lll_sy % 2 || lll_sz % 2 || ((uintptr_t)lll & 7))))
-		return hipErrorInvalidValue;
-	const int Zd = (nz + 1) / 2;
-	const int cpt = (vt.cpt == 8 && nx >= 512) ? 8 : 4;
-	const int ntx = (nx + 64 * cpt - 1) / (64 * cpt);
-	// long z lines: split them so that at least ~2048 waves exist
-	int tp = 64;
-	while (tp > 8 && (long)ntx * ny * ((Zd + tp - 1) / tp) < 2048)
-		tp >>= 1;
-	if (vt.tile_pairs >= 4)
-		tp = vt.tile_pairs;
-	const int nzt = (Zd + tp - 1) / tp;
-	if (nzt > 65535)
-		return hipErrorInvalidValue;
-	const int waves = ntx >= 4 ? 4 : ntx;
-	dim3 grid((ntx + waves - 1) / waves, ny, nzt);
-	const int vec_ok = aligned16(in) && aligned16(out) && in_sy % 4 == 0 && in_sz % 4 == 0 && out_sy % 4 == 0 && out_sz % 4 == 0;
-	if (inverse) {
-		if (cpt == 8)
-			vol_z_nt<true, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
-		else
-			vol_z_nt<true, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
-	} else {
-		if (cpt == 8)
-			vol_z_nt<false, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
-		else
-			vol_z_nt<false, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
-	}
-	return hipGetLastError();
-}
-
-// ---- 3-D, one pass: x, y and z lifting of a level fused (forward, out of place) ----
-// "Slab-tiled z pass": a workgroup (4 waves) owns 256 x 32 voxel columns and marches along
-// z.  Per slice: each wave DMAs 10 of the tile's 40 input rows (32 + 4 halo rows each side,
-// row and column reflection in the source address) into its own LDS ring, one slice ahead;
-// lifts them horizontally in registers; parks the x-lifted rows in a workgroup-shared LDS
-// slab; after a barrier reads the 16 rows around its 8 output rows back, lifts them
-// vertically in registers; and feeds the 8 x 4 samples per lane into the streaming z
-// recurrence whose state (4 partial slices x 32 columns) stays in registers for the whole
-// march.  The intermediate volume of the two-pass path never exists: 8 B per voxel (+ 25 %
-// halo rows, + z warm-up) instead of 16.  Same arithmetic and operand order as
-// k_fwd_sweep / k_vol_z, hence the same bits.
-static __device__ __forceinline__ void wg_barrier_lds()
-{
-	// LDS traffic of this wave done, then the barrier; outstanding LDS-DMA keeps flying
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int NT>
-__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
-{
-	using W = Cdf97S;
-	// the 8 output rows of a wave need x-lifted rows -4 .. +10 around its first row: the tile's
-	// 32 rows need 39 input rows; wave w stages rows w, w+4, ... (10, 10, 10, 9 of them)
-	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, TY = 32, NR = TY + 2 * K - 1, RPW = (NR + 3) / 4;
-	constexpr int kLdAux = (NT & 2) ? 2 : 0;
-	constexpr bool kNtStore = (NT & 1) != 0;
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const int lane = threadIdx.x & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	// workgroup -> tile: x tiles fastest, then y tiles, then z tiles; with the XCD swizzle an
-	// XCD (workgroups id % 8) owns a contiguous run of tiles, so the halo rows and columns that
-	// neighbouring tiles share are hits in that XCD's L2
-	const int bid = tile_block_id(swz);
-	const int c0 = (bid % ntx) * TW, c = c0 + lane * CPT;
-	const int y0 = ((bid / ntx) % nty) * TY;
-	const int Zd = (a.nz + 1) >> 1;
-	const int A = (bid / (ntx * nty)) * tile_pairs_z;
-	if (A >= Zd)
-		return; // the whole workgroup leaves together
-	const int B = min(A + tile_pairs_z, Zd);
-	const int n_iter = (B - A) + K, q0 = A - K / 2;
-	const int n_slices = 2 * n_iter;
-
-	// LDS: [wave-private staging rows, one slice: NR x RS floats] [shared slab: NR x TW floats];
-	// 81 KiB, so that two workgroups share a CU and one computes while the other waits
-	char *ring = smem + (size_t)wv * RPW * RS * 4;
-	char *slab = smem + (size_t)NR * RS * 4;
-	const unsigned ring_off = lds_offset(ring), slab_off = lds_offset(slab);
-	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
-	// tiles that overhang the volume (or unaligned volumes) are staged column by column
-	const bool full = vec_ok && c0 + TW <= a.nx;
-	int colmap[CPT];
-#pragma unroll
-	for (int i = 0; i < CPT; i++)
-		colmap[i] = reflect(c0 + i * 64 + lane, a.nx);
-
-	auto issue = [&](int t) {
-		const float *sl = a.in + (long)reflect(2 * q0 - 1 + t, a.nz) * a.in_sz;
-#pragma unroll
-		for (int i = 0; i < RPW; i++) {
-			if (wv + 4 * i < NR) {
-				const int r = reflect(y0 - K + wv + 4 * i, a.ny);
-				const float *grow = sl + (long)r * a.in_sy;
-				char *lrow = ring + (size_t)i * RS * 4;
-				if (full) {
-					dma16<kLdAux>(grow + c, lrow); // the DMA places lane i's 16 B at lrow + 16 i
-				} else {
-#pragma unroll
-					for (int e = 0; e < CPT; e++)
-						dma4<kLdAux>(grow + colmap[e], lrow + e * 256);
-				}
-				if (lane < 8)
-					dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
-			}
-		}
-	};
-
-	float st[K][8][CPT], ra[8][CPT];
-#pragma unroll
-	for (int s = 0; s < K; s++)
-#pragma unroll
-		for (int r = 0; r < 8; r++)
-#pragma unroll
-			for (int e = 0; e < CPT; e++)
-				st[s][r][e] = 0.f;
-
-	issue(0);
-	for (int t = 0; t < n_slices; t++) {
-		DWT_WAIT_VMCNT(0); // this slice's rows have landed (and the previous stores are out)
-		// horizontal lift of this wave's rows, parked in the shared slab
-#pragma unroll
-		for (int i = 0; i < RPW; i++) {
-			if (wv + 4 * i < NR) {
-				const unsigned base = ring_off + (unsigned)i * RS * 4;
-				const unsigned own = base + lane * CPT * 4;
-				const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
-				const unsigned ra_ = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
-				u4 L4, O0, R4;
-				lds_read3(la, own, ra_, L4, O0, R4);
-				float x[CPT + 2 * K];
-#pragma unroll
-				for (int e = 0; e < K; e++) {
-					x[e] = from_bits<float>(L4[e]);
-					x[K + e] = from_bits<float>(O0[e]);
-					x[K + CPT + e] = from_bits<float>(R4[e]);
-				}
-				lift_fwd_regs<W, CPT + 2 * K>(x);
-				const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
-					to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
-				lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
-			}
-		}
-		// the staging rows are consumed: the next slice's DMA flies during the rest of the iteration
-		if (t + 1 < n_slices)
-			issue(t + 1);
-		wg_barrier_lds(); // the slab is complete
-
-		// vertical lift: slab rows 8 wv .. 8 wv + 14 give this wave's 8 output rows
-		u4 v[15];
-		{
-			const unsigned vb = slab_off + (unsigned)(8 * wv) * TW * 4 + lane * 16;
-			asm volatile(
-				"ds_read_b128 %0, %15\n\tds_read_b128 %1, %15 offset:1024\n\tds_read_b128 %2, %15 offset:2048\n\tds_read_b128 %3, %15 offset:3072\n\t"
-				"ds_read_b128 %4, %15 offset:4096\n\tds_read_b128 %5, %15 offset:5120\n\tds_read_b128 %6, %15 offset:6144\n\tds_read_b128 %7, %15 offset:7168\n\t"
-				"ds_read_b128 %8, %15 offset:8192\n\tds_read_b128 %9, %15 offset:9216\n\tds_read_b128 %10, %15 offset:10240\n\tds_read_b128 %11, %15 offset:11264\n\t"
-				"ds_read_b128 %12, %15 offset:12288\n\tds_read_b128 %13, %15 offset:13312\n\tds_read_b128 %14, %15 offset:14336\n\t"
-				"s_waitcnt lgkmcnt(0)\n\ts_barrier"
-				: "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-				  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14])
-				: "v"(vb)
-				: "memory"); // the barrier: every wave has read the slab, the next slice may overwrite it
-		}
-		float cur[8][CPT];
-#pragma unroll
-		for (int e = 0; e < CPT; e++) {
-			float col[15];
-#pragma unroll
-			for (int j = 0; j < 15; j++)
-				col[j] = from_bits<float>(v[j][e]);
-			lift_fwd_regs<W, 15>(col);
-#pragma unroll
-			for (int r = 0; r < 8; r++)
-				cur[r][e] = W::fwd_scale(r & 1, col[K + r]);
-		}
-
-		// z: slices arrive as (2q-1, 2q); the odd one waits in registers for its partner
-		if (!(t & 1)) {
-#pragma unroll
-			for (int r = 0; r < 8; r++)
-#pragma unroll
-				for (int e = 0; e < CPT; e++)
-					ra[r][e] = cur[r][e];
-			continue;
-		}
-		const int it = t >> 1;
-		const int k = A + it - K;
-#pragma unroll
-		for (int r = 0; r < 8; r++) {
-			float o0[CPT], o1[CPT];
-#pragma unroll
-			for (int e = 0; e < CPT; e++) {
-				const float d1n = W::fwd_step(0, ra[r][e], st[0][r][e], cur[r][e]);
-				const float s1n = W::fwd_step(1, st[0][r][e], st[1][r][e], d1n);
-				const float d2n = W::fwd_step(2, st[1][r][e], st[2][r][e], s1n);
-				const float s2n = W::fwd_step(3, st[2][r][e], st[3][r][e], d2n);
-				o0[e] = W::fwd_scale(0, s2n);
-				o1[e] = W::fwd_scale(1, d2n);
-				st[0][r][e] = cur[r][e];
-				st[1][r][e] = d1n;
-				st[2][r][e] = s1n;
-				st[3][r][e] = d2n;
-			}
-			const int y = y0 + 8 * wv + r;
-			if (it >= K && y < a.ny) {
-				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + c;
-				const bool hz = 2 * k + 1 < a.nz;
-				float *pl = a.lll && !(r & 1) ? a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1) : nullptr;
-				if (full) {
-					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
-					if (hz)
-						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
-					if (pl)
-						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
-				} else {
-#pragma unroll
-					for (int e = 0; e < CPT; e++)
-						if (c + e < a.nx) {
-							p[e] = o0[e];
-							if (hz)
-								p[a.out_sz + e] = o1[e];
-							if (pl && !(e & 1))
-								pl[e >> 1] = o0[e];
-						}
-				}
-			}
-		}
-	}
-}
-
-bool vol_fused_applies(const VolFusedArgs &a)
-{
-	// A workgroup's march along z is a serial chain: the fused level pays off once the
-	// volume has about one workgroup per CU at 32 slice pairs per march (512^3: 0.31 ms fused
-	// against 0.43 in two passes; 256^3: 0.11 against 0.07).  Narrow volumes would leave most
-	// of a 256-column tile idle.
-	if (a.in == a.out || a.nx < 128 || a.ny < 2 || a.nz < 2)
-		return false;
-	const long tiles = (long)((a.nx + 255) / 256) * ((a.ny + 31) / 32);
-	return tiles * (((a.nz + 1) / 2 + 31) / 32) >= 192;
-}
-
-static bool vol_fused_vec_ok(const VolFusedArgs &a)
-{
-	return aligned16(a.in) && aligned16(a.out) && a.in_sy % 4 == 0 && a.in_sz % 4 == 0 && a.out_sy % 4 == 0 && a.out_sz % 4 == 0 &&
-		(!a.lll || (((uintptr_t)a.lll & 7) == 0 && a.lll_sy % 2 == 0 && a.lll_sz % 2 == 0));
-}
-
-hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s)
-{
-	if (a.in == a.out || a.nx < 2 || a.ny < 2 || a.nz < 2)
-		return hipErrorInvalidValue;
-	const int Zd = (a.nz + 1) / 2;
-	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
-	// z lines are split until the 512 workgroup slots (two per CU) are filled, but not below 32
-	// slice pairs per march: the 8-slice warm-up is 12 % there (512^3: 32 pairs 0.31 ms, 16
-	// pairs 0.37, 64 pairs -- half the CUs idle -- 0.55)
-	int tp = 128;
-	while (tp > 32 && (long)ntx * nty * ((Zd + tp - 1) / tp) < 512)
-		tp >>= 1;
-	if (vt.tile_pairs >= 4)
-		tp = vt.tile_pairs;
-	const int nzt = (Zd + tp - 1) / tp;
-	if ((long)ntx * nty * nzt > 0x7fffffffL)
-		return hipErrorInvalidValue;
-	const size_t lds = (size_t)39 * (256 + 8) * 4 + (size_t)39 * 256 * 4;
-	dim3 grid(ntx * nty * nzt);
-	const int swz = vt.swizzle;
-	if (vt.nt < 0 || (vt.nt & 1)) {
-		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<3>, lds))
-			return e;
-		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
-	} else {
-		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<2>, lds))
-			return e;
-		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
-	}
-	return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ src, long s_sx, long s_sy, long s_sz,
-	float *__restrict__ dst, long d_sx, long d_sy, long d_sz, int nx, int ny, int nxb)
-{
-	// grid.x = column blocks x rows (rows can exceed the 65535 limit of grid.y), grid.y = slices
-	const int x = (blockIdx.x % nxb) * blockDim.x + threadIdx.x;
-	const int y = blockIdx.x / nxb, z = blockIdx.y;
-	if (x < nx && y < ny)
-		dst[(long)z * d_sz + (long)y * d_sy + (long)x * d_sx] = src[(long)z * s_sz + (long)y * s_sy + (long)x * s_sx];
-}
-
-hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
-	int nx, int ny, int nz, hipStream_t s)
-{
-	const int nxb = (nx + 255) / 256;
-	if (nx < 1 || ny < 1 || nz < 1 || nz > 65535 || (long)nxb * ny > 0x7fffffffL)
-		return hipErrorInvalidValue;
-	dim3 grid(nxb * ny, nz);
-	k_lattice_copy<<<grid, 256, 0, s>>>(src, s_sx, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny, nxb);
-	return hipGetLastError();
-}
-
-// ---- interleaved layout: one phase of the reference's phase-ordered lifting, exact ----
-// Same windowed evaluation as k_line_pass, with every step masked to the index range the
-// phase gives it.  Mirrored window entries (symmetric extension) carry the index they
-// mirror, so they receive the same masked updates as their originals.
-template <class W, bool INV>
-__global__ __launch_bounds__(256) void k_il_phase(const char *__restrict__ src, char *__restrict__ dst,
-	long line_stride, long elem_stride, int n_lines, int N, int lanes_along_lines, IlPhase ph)
-{
-	using T = typename W::T;
-	constexpr int K = W::K, NW = 2 * K + 1;
-	const int fast = blockIdx.x * blockDim.x + threadIdx.x;
-	const int slow = blockIdx.y;
-	const int line = lanes_along_lines ? fast : slow;
-	const int k = lanes_along_lines ? slow : fast;
-	if (line >= n_lines || k >= ((N + 1) >> 1))
-		return;
-	const char *s = src + (long)line * line_stride;
-	char *d = dst + (long)line * line_stride;
-	// forward: w[0] is the even sample 2k-K; inverse: the odd sample 2k-K+1
-	const int first = 2 * k - K + (INV ? 1 : 0);
-	T w[NW];
-	int idx[NW];
-#pragma unroll
-	for (int j = 0; j < NW; j++) {
-		idx[j] = reflect(first + j, N);
-		w[j] = *(const T *)(s + (long)idx[j] * elem_stride);
-		if (INV && idx[j] >= ph.sc_lo && idx[j] <= ph.sc_hi)
-			w[j] = W::inv_scale(idx[j] & 1, w[j]);
-	}
-#pragma unroll
-	for (int st = 0; st < K; st++) {
-#pragma unroll
-		for (int j = st + 1; j <= NW - 2 - st; j += 2)
-			if (idx[j] >= ph.lo[st] && idx[j] <= ph.hi[st])
-				w[j] = INV ? W::inv_step(st, w[j], w[j - 1], w[j + 1]) : W::fwd_step(st, w[j], w[j - 1], w[j + 1]);
-	}
-	const int c0 = INV ? K - 1 : K; // window position of sample 2k
-#pragma unroll
-	for (int e = 0; e < 2; e++) {
-		const int i = 2 * k + e;
-		if (i < N) {
-			T v = w[c0 + e];
-			if (!INV && i >= ph.sc_lo && i <= ph.sc_hi)
-				v = W::fwd_scale(e, v);
-			*(T *)(d + (long)i * elem_stride) = v;
-		}
-	}
-}
-
-template <class W>
-static hipError_t il_phase_t(bool inverse, const void *src, void *dst, long line_stride, long elem_stride, int n_lines, int N,
-	bool lanes_along_lines, const IlPhase &ph, hipStream_t s)
-{
-	if (n_lines <= 0 || N < 2)
-		return hipErrorInvalidValue;
-	const int npairs = (N + 1) >> 1;
-	const int fast = lanes_along_lines ? n_lines : npairs;
-	const int slow = lanes_along_lines ? npairs : n_lines;
-	const int bs = fast >= 256 ? 256 : 64;
-	dim3 grid((fast + bs - 1) / bs, slow);
-	if (inverse)
-		k_il_phase<W, true><<<grid, bs, 0, s>>>((const char *)src, (char *)dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph);
-	else
-		k_il_phase<W, false><<<grid, bs, 0, s>>>((const char *)src, (char *)dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph);
-	return hipGetLastError();
-}
-
-hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
-	int n_lines, int N, bool lanes_along_lines, const IlPhase &ph, hipStream_t s)
-{
-	switch (w) {
-	case kCdf97S: return il_phase_t<Cdf97S>(inverse, src, dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph, s);
-	case kCdf53SNew: return il_phase_t<Cdf53SNew>(inverse, src, dst, line_stride, elem_stride, n_lines, N, lanes_along_lines, ph, s);
-	default: break;
-	}
-	return hipErrorInvalidValue;
-}
-
-// ---- interleaved layout: all levels' lattices in one pass over the even rows ----
-// A lattice-1 point (p, q) (image column 2p, row 2q) belongs to level
-// j = 1 + min(ctz(p), ctz(q)) capped at J-1; its sample sits at (p >> (j-1), q >> (j-1))
-// of that level's dense image.  One thread owns 8 image columns of one even row.
-static __device__ __forceinline__ int il_level_of(int p, int q, int J)
-{
-	const int t = __builtin_ctz((unsigned)(p | q) | (1u << 30)); // ctz(0) -> 30
-	const int j = 1 + t;
-	return j < J ? j : J - 1;
-}
-
-__global__ __launch_bounds__(256) void k_il_compose(const float *__restrict__ base, long base_pitch, float *__restrict__ out,
-	long out_pitch, int W, int H, IlPyramid py, int vec_ok, int out_dense)
-{
-	// grid.x = even rows (may exceed 65535), grid.y = blocks of 2048 columns
-	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
-	const int q = blockIdx.x, y = 2 * q;
-	if (x0 >= W || y >= H)
-		return;
-	const float *b = base + (long)y * base_pitch + x0;
-	float *o = out + (long)(out_dense ? q : y) * out_pitch + x0;
-	const int p0 = x0 >> 1;
-	float v[8];
-	const bool vec = vec_ok && x0 + 8 <= W;
-	if (vec) {
-		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
-#pragma unroll
-		for (int e = 0; e < 4; e++) {
-			v[e] = from_bits<float>(t0[e]);
-			v[4 + e] = from_bits<float>(t1[e]);
-		}
-		const u4 l1 = *(const u4 *)(py.p[1] + (long)q * py.pitch[1] + p0);
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			v[2 * i] = from_bits<float>(l1[i]);
-	} else {
-#pragma unroll
-		for (int e = 0; e < 8; e++)
-			if (x0 + e < W)
-				v[e] = (e & 1) ? b[e] : py.p[1][(long)q * py.pitch[1] + p0 + (e >> 1)];
-	}
-	if (py.J > 2 && !(q & 1)) {
-		// p0 is a multiple of 4: the points p0 and p0+2 lie on deeper lattices
-#pragma unroll
-		for (int i = 0; i < 4; i += 2)
-			if (x0 + 2 * i < W) {
-				const int p = p0 + i, j = il_level_of(p, q, py.J);
-				v[2 * i] = py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + (p >> (j - 1))];
-			}
-	}
-	if (vec) {
-		*(u4 *)o = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
-		*(u4 *)(o + 4) = u4{to_bits(v[4]), to_bits(v[5]), to_bits(v[6]), to_bits(v[7])};
-	} else {
-#pragma unroll
-		for (int e = 0; e < 8; e++)
-			if (x0 + e < W)
-				o[e] = v[e];
-	}
-}
-
-__global__ __launch_bounds__(256) void k_il_decompose(const float *__restrict__ img, long pitch, int W, int H, IlPyramid py, int vec_ok)
-{
-	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
-	const int q = blockIdx.x, y = 2 * q;
-	if (x0 >= W || y >= H)
-		return;
-	const float *b = img + (long)y * pitch + x0;
-	const int p0 = x0 >> 1;
-	float v[4];
-	const bool vec = vec_ok && x0 + 8 <= W;
-	if (vec) {
-		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
-		v[0] = from_bits<float>(t0[0]); v[1] = from_bits<float>(t0[2]);
-		v[2] = from_bits<float>(t1[0]); v[3] = from_bits<float>(t1[2]);
-		*(u4 *)(py.p[1] + (long)q * py.pitch[1] + p0) = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
-	} else {
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			if (x0 + 2 * i < W) {
-				v[i] = b[2 * i];
-				py.p[1][(long)q * py.pitch[1] + p0 + i] = v[i];
-			}
-	}
-	// deeper lattices: level j takes the points whose p and q are multiples of 2^(j-1)
-	for (int j = 2; j < py.J; j++) {
-		const int m = (1 << (j - 1)) - 1;
-		if (q & m)
-			break;
-#pragma unroll
-		for (int i = 0; i < 4; i += 2)
-			if (!((p0 + i) & m) && x0 + 2 * i < W)
-				py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + ((p0 + i) >> (j - 1))] = v[i];
-	}
-}
-
-static int il_vec_ok(const float *a, long ap, const float *b, long bp, const IlPyramid &py)
-{
-	return aligned16(a) && aligned16(b) && ap % 4 == 0 && bp % 4 == 0 && py.J > 1 && aligned16(py.p[1]) && py.pitch[1] % 4 == 0;
-}
-
-hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H, const IlPyramid &py, hipStream_t s,
-	bool out_dense)
-{
-	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
-		return hipErrorInvalidValue;
-	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
-	k_il_compose<<<grid, 256, 0, s>>>(base, base_pitch, out, out_pitch, W, H, py, il_vec_ok(base, base_pitch, out, out_pitch, py), out_dense);
-	return hipGetLastError();
-}
-
-hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s)
-{
-	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
-		return hipErrorInvalidValue;
-	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
-	k_il_decompose<<<grid, 256, 0, s>>>(img, pitch, W, H, py, il_vec_ok(img, pitch, img, pitch, py));
-	return hipGetLastError();
-}
 
 bool have_fused_inverse(Wavelet) { return true; }
-
-} // namespace dwt
-
-// ---------------------------------------------------------------------------------
-// 4. device-side view helpers: conv_show and compare on images
-//    that stay in HBM between the forward and the inverse transform
-// ---------------------------------------------------------------------------------
-namespace dwt {
-
-// dwt_util_conv_show_s (src/libdwt.c:21075-21117): log(1 + |c|*100) / 10 with the log
-// taken in double as log_i_s does (:21010); non-finite results become 0.
-__global__ __launch_bounds__(256) void k_conv_show_s(const char *__restrict__ src, char *__restrict__ dst, long pitch, int w, int h)
-{
-	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-	if (x >= w || y >= h)
-		return;
-	const float c = *(const float *)(src + (long)y * pitch + (long)x * 4);
-	float t = (float)log((double)(1.f + fabsf(c) * 100.f));
-	t /= 10.f;
-	if (!isfinite(t))
-		t = 0.f;
-	*(float *)(dst + (long)y * pitch + (long)x * 4) = t;
-}
-
-// dwt_util_conv_show_i (src/libdwt.c:21020-21044): |c|
-__global__ __launch_bounds__(256) void k_conv_show_i(const char *__restrict__ src, char *__restrict__ dst, long pitch, int w, int h)
-{
-	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-	if (x >= w || y >= h)
-		return;
-	const int c = *(const int *)(src + (long)y * pitch + (long)x * 4);
-	*(int *)(dst + (long)y * pitch + (long)x * 4) = c < 0 ? -c : c;
-}
-
-// dwt_util_compare_s / _i (src/libdwt.c:1593-1620, 1531-1558): count of differing
-// elements (float: |a-b| > 1e-3 or any NaN/Inf; int: a != b) accumulated in *result
-template <bool IS_INT>
-__global__ __launch_bounds__(256) void k_compare(const char *__restrict__ p1, const char *__restrict__ p2, long pitch, int w, int h, unsigned *result)
-{
-	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-	bool differ = false;
-	if (x < w && y < h) {
-		if (IS_INT) {
-			differ = *(const int *)(p1 + (long)y * pitch + (long)x * 4) != *(const int *)(p2 + (long)y * pitch + (long)x * 4);
-		} else {
-			const float a = *(const float *)(p1 + (long)y * pitch + (long)x * 4);
-			const float b = *(const float *)(p2 + (long)y * pitch + (long)x * 4);
-			differ = isnan(a) || isinf(a) || isnan(b) || isinf(b) || fabsf(a - b) > 1e-3f;
-		}
-	}
-	const unsigned long long m = __ballot(differ);
-	if ((threadIdx.x & 63) == 0 && m)
-		atomicAdd(result, (unsigned)__popcll(m));
-}
-
-hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s)
-{
-	if (w <= 0 || h <= 0)
-		return hipSuccess;
-	dim3 grid((w + 255) / 256, h);
-	if (is_int)
-		k_conv_show_i<<<grid, 256, 0, s>>>((const char *)src, (char *)dst, pitch, w, h);
-	else
-		k_conv_show_s<<<grid, 256, 0, s>>>((const char *)src, (char *)dst, pitch, w, h);
-	return hipGetLastError();
-}
-
-hipError_t launch_compare(bool is_int, const void *p1, const void *p2, long pitch, int w, int h, unsigned *result, hipStream_t s)
-{
-	if (w <= 0 || h <= 0)
-		return hipSuccess;
-	dim3 grid((w + 255) / 256, h);
-	if (is_int)
-		k_compare<true><<<grid, 256, 0, s>>>((const char *)p1, (const char *)p2, pitch, w, h, result);
-	else
-		k_compare<false><<<grid, 256, 0, s>>>((const char *)p1, (const char *)p2, pitch, w, h, result);
-	return hipGetLastError();
-}
 
 } // namespace dwt

@@ -1,0 +1,472 @@
+// dwt_vol3d.hip -- the 3-D path (BASELINE config 5): the z pass of the two-pass scheme, the fused
+// one-pass level (x, y and z lifting in one kernel) and the strided lattice copy.
+#include "dwt_device.h"
+
+namespace dwt {
+
+// ---------------------------------------------------------------------------------
+// 3. z pass of the 3-D path and the lattice copy
+// ---------------------------------------------------------------------------------
+// One wave owns 256 contiguous x columns of one row y and marches along z with the
+// lifting state in registers (the z neighbours of a sample are whole slices apart, but
+// each access is a contiguous 1 KiB row segment).  Same streaming recurrences as the
+// vertical pass of the 2-D sweeps; out of place, because the symmetric extension at
+// the far end re-reads slices the sweep has already produced.
+template <bool INV, int CPT, int NT>
+__global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, long in_sy, long in_sz,
+	float *__restrict__ out, long out_sy, long out_sz, int nx, int ny, int nz, int tile_pairs, int vec_ok,
+	float *__restrict__ lll, long lll_sy, long lll_sz)
+{
+	using W = Cdf97S;
+	constexpr int K = 4, NV = CPT / 4;
+	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// a lane owns NV groups of 4 columns, 256 columns apart: every load/store instruction
+	// of the wave is one contiguous 1 KiB segment
+	const int c = (blockIdx.x * nwv + wv) * 64 * CPT + lane * 4;
+	const int y = blockIdx.y;
+	const int Zd = (nz + 1) >> 1;
+	const int A = blockIdx.z * tile_pairs;
+	if (A >= Zd || (blockIdx.x * nwv + wv) * 64 * CPT >= nx)
+		return;
+	const int B = min(A + tile_pairs, Zd);
+	const int n_iter = (B - A) + K;
+	const int q0 = A - K / 2;
+	const bool vec = vec_ok && (c + 256 * (NV - 1) + 4 <= nx);
+	const float *src = in + (long)y * in_sy + c;
+	float *dst = out + (long)y * out_sy + c;
+
+	auto load = [&](int slice, float (&v)[CPT]) {
+		const float *p = src + (long)reflect(slice, nz) * in_sz;
+		if (vec) {
+#pragma unroll
+			for (int g = 0; g < NV; g++) {
+				const u4 t = (NT & 2) ? __builtin_nontemporal_load((const u4 *)(p + 256 * g)) : *(const u4 *)(p + 256 * g);
+#pragma unroll
+				for (int e = 0; e < 4; e++)
+					v[4 * g + e] = from_bits<float>(t[e]);
+			}
+		} else {
+#pragma unroll
+			for (int e = 0; e < CPT; e++) {
+				const int x = c + 256 * (e >> 2) + (e & 3);
+				v[e] = (x < nx) ? p[256 * (e >> 2) + (e & 3)] : 0.f;
+			}
+		}
+	};
+	auto store = [&](int slice, const float (&v)[CPT]) {
+		float *p = dst + (long)slice * out_sz;
+		if (vec) {
+#pragma unroll
+			for (int g = 0; g < NV; g++) {
+				const u4 t = u4{to_bits(v[4 * g]), to_bits(v[4 * g + 1]), to_bits(v[4 * g + 2]), to_bits(v[4 * g + 3])};
+				if (NT & 1)
+					__builtin_nontemporal_store(t, (u4 *)(p + 256 * g));
+				else
+					*(u4 *)(p + 256 * g) = t;
+			}
+		} else {
+#pragma unroll
+			for (int e = 0; e < CPT; e++)
+				if (c + 256 * (e >> 2) + (e & 3) < nx)
+					p[256 * (e >> 2) + (e & 3)] = v[e];
+		}
+	};
+
+	float st[K][CPT];
+#pragma unroll
+	for (int s = 0; s < K; s++)
+#pragma unroll
+		for (int e = 0; e < CPT; e++)
+			st[s][e] = 0.f;
+
+	float na[CPT], nb[CPT];
+	load(2 * q0 - (INV ? 0 : 1), na);
+	load(2 * q0 + (INV ? 1 : 0), nb);
+	for (int it = 0; it < n_iter; it++) {
+		const int q = q0 + it;
+		float ra[CPT], rb[CPT];
+#pragma unroll
+		for (int e = 0; e < CPT; e++) {
+			ra[e] = na[e];
+			rb[e] = nb[e];
+		}
+		if (it + 1 < n_iter) { // software prefetch of the next pair of slices
+			load(2 * (q + 1) - (INV ? 0 : 1), na);
+			load(2 * (q + 1) + (INV ? 1 : 0), nb);
+		}
+		float o0[CPT], o1[CPT];
+#pragma unroll
+		for (int e = 0; e < CPT; e++) {
+			if constexpr (!INV) {
+				// ra = slice 2q-1 (odd), rb = slice 2q (even)
+				const float d1n = W::fwd_step(0, ra[e], st[0][e], rb[e]);
+				const float s1n = W::fwd_step(1, st[0][e], st[1][e], d1n);
+				const float d2n = W::fwd_step(2, st[1][e], st[2][e], s1n);
+				const float s2n = W::fwd_step(3, st[2][e], st[3][e], d2n);
+				o0[e] = W::fwd_scale(0, s2n);
+				o1[e] = W::fwd_scale(1, d2n);
+				st[0][e] = rb[e];
+				st[1][e] = d1n;
+				st[2][e] = s1n;
+				st[3][e] = d2n;
+			} else {
+				// ra = slice 2q (even, s2'), rb = slice 2q+1 (odd, d2')
+				const float s2 = W::inv_scale(0, ra[e]), d2 = W::inv_scale(1, rb[e]);
+				const float s1n = W::inv_step(0, s2, st[0][e], d2);
+				const float d1n = W::inv_step(1, st[0][e], st[1][e], s1n);
+				const float en = W::inv_step(2, st[1][e], st[2][e], d1n);
+				const float on = W::inv_step(3, st[2][e], st[3][e], en);
+				o0[e] = on; // slice 2q-3
+				o1[e] = en; // slice 2q-2
+				st[0][e] = d2;
+				st[1][e] = s1n;
+				st[2][e] = d1n;
+				st[3][e] = en;
+			}
+		}
+		if constexpr (!INV) {
+			if (it >= K) {
+				const int k = A + it - K;
+				store(2 * k, o0);
+				if (2 * k + 1 < nz)
+					store(2 * k + 1, o1);
+				// forward multi-level: the next level's input (even x, even y, even z = LLL)
+				// also goes out densely, so that no lattice gather is needed
+				if (lll && !(y & 1)) {
+					float *p = lll + (long)k * lll_sz + (long)(y >> 1) * lll_sy + (c >> 1);
+#pragma unroll
+					for (int g = 0; g < NV; g++) {
+						if (vec) {
+							*(u2 *)(p + 128 * g) = u2{to_bits(o0[4 * g]), to_bits(o0[4 * g + 2])};
+						} else {
+							if (c + 256 * g < nx)
+								p[128 * g] = o0[4 * g];
+							if (c + 256 * g + 2 < nx)
+								p[128 * g + 1] = o0[4 * g + 2];
+						}
+					}
+				}
+			}
+		} else {
+			const int pe = q - 1, po = q - 2;
+			if (po >= A && po < B && 2 * po + 1 < nz)
+				store(2 * po + 1, o0);
+			if (pe >= A && pe < B)
+				store(2 * pe, o1);
+		}
+	}
+}
+
+template <bool INV, int CPT>
+static void vol_z_nt(int nt, dim3 grid, int threads, hipStream_t s, const float *in, long in_sy, long in_sz, float *out,
+	long out_sy, long out_sz, int nx, int ny, int nz, int tp, int vec_ok, float *lll, long lll_sy, long lll_sz)
+{
+	switch ((nt < 0 ? 0 : nt) & 3) {
+	case 0: k_vol_z<INV, CPT, 0><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	case 1: k_vol_z<INV, CPT, 1><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	case 2: k_vol_z<INV, CPT, 2><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	default: k_vol_z<INV, CPT, 3><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	}
+}
+
+hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, float *out, long out_sy, long out_sz,
+	int nx, int ny, int nz, const VolTuning &vt, hipStream_t s, float *lll, long lll_sy, long lll_sz)
+{
+	if (nx < 1 || ny < 1 || nz < 2 || ny > 65535 || (lll && (inverse || lll_sy % 2 || lll_sz % 2 || ((uintptr_t)lll & 7))))
+		return hipErrorInvalidValue;
+	const int Zd = (nz + 1) / 2;
+	const int cpt = (vt.cpt == 8 && nx >= 512) ? 8 : 4;
+	const int ntx = (nx + 64 * cpt - 1) / (64 * cpt);
+	// long z lines: split them so that at least ~2048 waves exist
+	int tp = 64;
+	while (tp > 8 && (long)ntx * ny * ((Zd + tp - 1) / tp) < 2048)
+		tp >>= 1;
+	if (vt.tile_pairs >= 4)
+		tp = vt.tile_pairs;
+	const int nzt = (Zd + tp - 1) / tp;
+	if (nzt > 65535)
+		return hipErrorInvalidValue;
+	const int waves = ntx >= 4 ? 4 : ntx;
+	dim3 grid((ntx + waves - 1) / waves, ny, nzt);
+	const int vec_ok = aligned16(in) && aligned16(out) && in_sy % 4 == 0 && in_sz % 4 == 0 && out_sy % 4 == 0 && out_sz % 4 == 0;
+	if (inverse) {
+		if (cpt == 8)
+			vol_z_nt<true, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+		else
+			vol_z_nt<true, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+	} else {
+		if (cpt == 8)
+			vol_z_nt<false, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+		else
+			vol_z_nt<false, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+	}
+	return hipGetLastError();
+}
+
+// ---- 3-D, one pass: x, y and z lifting of a level fused (forward, out of place) ----
+// "Slab-tiled z pass": a workgroup (4 waves) owns 256 x 32 voxel columns and marches along
+// z.  Per slice: each wave DMAs 10 of the tile's 40 input rows (32 + 4 halo rows each side,
+// row and column reflection in the source address) into its own LDS ring, one slice ahead;
+// lifts them horizontally in registers; parks the x-lifted rows in a workgroup-shared LDS
+// slab; after a barrier reads the 16 rows around its 8 output rows back, lifts them
+// vertically in registers; and feeds the 8 x 4 samples per lane into the streaming z
+// recurrence whose state (4 partial slices x 32 columns) stays in registers for the whole
+// march.  The intermediate volume of the two-pass path never exists: 8 B per voxel (+ 25 %
+// halo rows, + z warm-up) instead of 16.  Same arithmetic and operand order as
+// k_fwd_sweep / k_vol_z, hence the same bits.
+template <int NT>
+__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
+{
+	using W = Cdf97S;
+	// the 8 output rows of a wave need x-lifted rows -4 .. +10 around its first row: the tile's
+	// 32 rows need 39 input rows; wave w stages rows w, w+4, ... (10, 10, 10, 9 of them)
+	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, TY = 32, NR = TY + 2 * K - 1, RPW = (NR + 3) / 4;
+	constexpr int kLdAux = (NT & 2) ? 2 : 0;
+	constexpr bool kNtStore = (NT & 1) != 0;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// workgroup -> tile: x tiles fastest, then y tiles, then z tiles; with the XCD swizzle an
+	// XCD (workgroups id % 8) owns a contiguous run of tiles, so the halo rows and columns that
+	// neighbouring tiles share are hits in that XCD's L2
+	const int bid = tile_block_id(swz);
+	const int c0 = (bid % ntx) * TW, c = c0 + lane * CPT;
+	const int y0 = ((bid / ntx) % nty) * TY;
+	const int Zd = (a.nz + 1) >> 1;
+	const int A = (bid / (ntx * nty)) * tile_pairs_z;
+	if (A >= Zd)
+		return; // the whole workgroup leaves together
+	const int B = min(A + tile_pairs_z, Zd);
+	const int n_iter = (B - A) + K, q0 = A - K / 2;
+	const int n_slices = 2 * n_iter;
+
+	// LDS: [wave-private staging rows, one slice: NR x RS floats] [shared slab: NR x TW floats];
+	// 81 KiB, so that two workgroups share a CU and one computes while the other waits
+	char *ring = smem + (size_t)wv * RPW * RS * 4;
+	char *slab = smem + (size_t)NR * RS * 4;
+	const unsigned ring_off = lds_offset(ring), slab_off = lds_offset(slab);
+	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
+	// tiles that overhang the volume (or unaligned volumes) are staged column by column
+	const bool full = vec_ok && c0 + TW <= a.nx;
+	int colmap[CPT];
+#pragma unroll
+	for (int i = 0; i < CPT; i++)
+		colmap[i] = reflect(c0 + i * 64 + lane, a.nx);
+
+	auto issue = [&](int t) {
+		const float *sl = a.in + (long)reflect(2 * q0 - 1 + t, a.nz) * a.in_sz;
+#pragma unroll
+		for (int i = 0; i < RPW; i++) {
+			if (wv + 4 * i < NR) {
+				const int r = reflect(y0 - K + wv + 4 * i, a.ny);
+				const float *grow = sl + (long)r * a.in_sy;
+				char *lrow = ring + (size_t)i * RS * 4;
+				if (full) {
+					dma16<kLdAux>(grow + c, lrow); // the DMA places lane i's 16 B at lrow + 16 i
+				} else {
+#pragma unroll
+					for (int e = 0; e < CPT; e++)
+						dma4<kLdAux>(grow + colmap[e], lrow + e * 256);
+				}
+				if (lane < 8)
+					dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
+			}
+		}
+	};
+
+	float st[K][8][CPT], ra[8][CPT];
+#pragma unroll
+	for (int s = 0; s < K; s++)
+#pragma unroll
+		for (int r = 0; r < 8; r++)
+#pragma unroll
+			for (int e = 0; e < CPT; e++)
+				st[s][r][e] = 0.f;
+
+	issue(0);
+	for (int t = 0; t < n_slices; t++) {
+		DWT_WAIT_VMCNT(0); // this slice's rows have landed (and the previous stores are out)
+		// horizontal lift of this wave's rows, parked in the shared slab
+#pragma unroll
+		for (int i = 0; i < RPW; i++) {
+			if (wv + 4 * i < NR) {
+				const unsigned base = ring_off + (unsigned)i * RS * 4;
+				const unsigned own = base + lane * CPT * 4;
+				const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
+				const unsigned ra_ = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
+				u4 L4, O0, R4;
+				lds_read3(la, own, ra_, L4, O0, R4);
+				float x[CPT + 2 * K];
+#pragma unroll
+				for (int e = 0; e < K; e++) {
+					x[e] = from_bits<float>(L4[e]);
+					x[K + e] = from_bits<float>(O0[e]);
+					x[K + CPT + e] = from_bits<float>(R4[e]);
+				}
+				lift_fwd_regs<W, CPT + 2 * K>(x);
+				const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
+					to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
+				lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
+			}
+		}
+		// the staging rows are consumed: the next slice's DMA flies during the rest of the iteration
+		if (t + 1 < n_slices)
+			issue(t + 1);
+		wg_barrier_lds(); // the slab is complete
+
+		// vertical lift: slab rows 8 wv .. 8 wv + 14 give this wave's 8 output rows
+		u4 v[15];
+		{
+			const unsigned vb = slab_off + (unsigned)(8 * wv) * TW * 4 + lane * 16;
+			asm volatile(
+				"ds_read_b128 %0, %15\n\tds_read_b128 %1, %15 offset:1024\n\tds_read_b128 %2, %15 offset:2048\n\tds_read_b128 %3, %15 offset:3072\n\t"
+				"ds_read_b128 %4, %15 offset:4096\n\tds_read_b128 %5, %15 offset:5120\n\tds_read_b128 %6, %15 offset:6144\n\tds_read_b128 %7, %15 offset:7168\n\t"
+				"ds_read_b128 %8, %15 offset:8192\n\tds_read_b128 %9, %15 offset:9216\n\tds_read_b128 %10, %15 offset:10240\n\tds_read_b128 %11, %15 offset:11264\n\t"
+				"ds_read_b128 %12, %15 offset:12288\n\tds_read_b128 %13, %15 offset:13312\n\tds_read_b128 %14, %15 offset:14336\n\t"
+				"s_waitcnt lgkmcnt(0)\n\ts_barrier"
+				: "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+				  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14])
+				: "v"(vb)
+				: "memory"); // the barrier: every wave has read the slab, the next slice may overwrite it
+		}
+		float cur[8][CPT];
+#pragma unroll
+		for (int e = 0; e < CPT; e++) {
+			float col[15];
+#pragma unroll
+			for (int j = 0; j < 15; j++)
+				col[j] = from_bits<float>(v[j][e]);
+			lift_fwd_regs<W, 15>(col);
+#pragma unroll
+			for (int r = 0; r < 8; r++)
+				cur[r][e] = W::fwd_scale(r & 1, col[K + r]);
+		}
+
+		// z: slices arrive as (2q-1, 2q); the odd one waits in registers for its partner
+		if (!(t & 1)) {
+#pragma unroll
+			for (int r = 0; r < 8; r++)
+#pragma unroll
+				for (int e = 0; e < CPT; e++)
+					ra[r][e] = cur[r][e];
+			continue;
+		}
+		const int it = t >> 1;
+		const int k = A + it - K;
+#pragma unroll
+		for (int r = 0; r < 8; r++) {
+			float o0[CPT], o1[CPT];
+#pragma unroll
+			for (int e = 0; e < CPT; e++) {
+				const float d1n = W::fwd_step(0, ra[r][e], st[0][r][e], cur[r][e]);
+				const float s1n = W::fwd_step(1, st[0][r][e], st[1][r][e], d1n);
+				const float d2n = W::fwd_step(2, st[1][r][e], st[2][r][e], s1n);
+				const float s2n = W::fwd_step(3, st[2][r][e], st[3][r][e], d2n);
+				o0[e] = W::fwd_scale(0, s2n);
+				o1[e] = W::fwd_scale(1, d2n);
+				st[0][r][e] = cur[r][e];
+				st[1][r][e] = d1n;
+				st[2][r][e] = s1n;
+				st[3][r][e] = d2n;
+			}
+			const int y = y0 + 8 * wv + r;
+			if (it >= K && y < a.ny) {
+				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + c;
+				const bool hz = 2 * k + 1 < a.nz;
+				float *pl = a.lll && !(r & 1) ? a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1) : nullptr;
+				if (full) {
+					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
+					if (hz)
+						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
+					if (pl)
+						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+				} else {
+#pragma unroll
+					for (int e = 0; e < CPT; e++)
+						if (c + e < a.nx) {
+							p[e] = o0[e];
+							if (hz)
+								p[a.out_sz + e] = o1[e];
+							if (pl && !(e & 1))
+								pl[e >> 1] = o0[e];
+						}
+				}
+			}
+		}
+	}
+}
+
+bool vol_fused_applies(const VolFusedArgs &a)
+{
+	// A workgroup's march along z is a serial chain: the fused level pays off once the
+	// volume has about one workgroup per CU at 32 slice pairs per march (512^3: 0.31 ms fused
+	// against 0.43 in two passes; 256^3: 0.11 against 0.07).  Narrow volumes would leave most
+	// of a 256-column tile idle.
+	if (a.in == a.out || a.nx < 128 || a.ny < 2 || a.nz < 2)
+		return false;
+	const long tiles = (long)((a.nx + 255) / 256) * ((a.ny + 31) / 32);
+	return tiles * (((a.nz + 1) / 2 + 31) / 32) >= 192;
+}
+
+static bool vol_fused_vec_ok(const VolFusedArgs &a)
+{
+	return aligned16(a.in) && aligned16(a.out) && a.in_sy % 4 == 0 && a.in_sz % 4 == 0 && a.out_sy % 4 == 0 && a.out_sz % 4 == 0 &&
+		(!a.lll || (((uintptr_t)a.lll & 7) == 0 && a.lll_sy % 2 == 0 && a.lll_sz % 2 == 0));
+}
+
+hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s)
+{
+	if (a.in == a.out || a.nx < 2 || a.ny < 2 || a.nz < 2)
+		return hipErrorInvalidValue;
+	const int Zd = (a.nz + 1) / 2;
+	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
+	// z lines are split until the 512 workgroup slots (two per CU) are filled, but not below 32
+	// slice pairs per march: the 8-slice warm-up is 12 % there (512^3: 32 pairs 0.31 ms, 16
+	// pairs 0.37, 64 pairs -- half the CUs idle -- 0.55)
+	int tp = 128;
+	while (tp > 32 && (long)ntx * nty * ((Zd + tp - 1) / tp) < 512)
+		tp >>= 1;
+	if (vt.tile_pairs >= 4)
+		tp = vt.tile_pairs;
+	const int nzt = (Zd + tp - 1) / tp;
+	if ((long)ntx * nty * nzt > 0x7fffffffL)
+		return hipErrorInvalidValue;
+	const size_t lds = (size_t)39 * (256 + 8) * 4 + (size_t)39 * 256 * 4;
+	dim3 grid(ntx * nty * nzt);
+	const int swz = vt.swizzle;
+	if (vt.nt < 0 || (vt.nt & 1)) {
+		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<3>, lds))
+			return e;
+		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
+	} else {
+		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<2>, lds))
+			return e;
+		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
+	}
+	return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ src, long s_sx, long s_sy, long s_sz,
+	float *__restrict__ dst, long d_sx, long d_sy, long d_sz, int nx, int ny, int nxb)
+{
+	// grid.x = column blocks x rows (rows can exceed the 65535 limit of grid.y), grid.y = slices
+	const int x = (blockIdx.x % nxb) * blockDim.x + threadIdx.x;
+	const int y = blockIdx.x / nxb, z = blockIdx.y;
+	if (x < nx && y < ny)
+		dst[(long)z * d_sz + (long)y * d_sy + (long)x * d_sx] = src[(long)z * s_sz + (long)y * s_sy + (long)x * s_sx];
+}
+
+hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
+	int nx, int ny, int nz, hipStream_t s)
+{
+	const int nxb = (nx + 255) / 256;
+	if (nx < 1 || ny < 1 || nz < 1 || nz > 65535 || (long)nxb * ny > 0x7fffffffL)
+		return hipErrorInvalidValue;
+	dim3 grid(nxb * ny, nz);
+	k_lattice_copy<<<grid, 256, 0, s>>>(src, s_sx, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny, nxb);
+	return hipGetLastError();
+}
+
+} // namespace dwt

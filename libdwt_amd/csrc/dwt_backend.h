@@ -1,0 +1,121 @@
+// dwt_backend.h -- what the backend's translation units share: the device context, workspace and
+// staging helpers, the level-pass helpers.  Internal to the shared library (hidden visibility).
+#pragma once
+#include "../../include/libdwt_hip.h"
+#include "dwt_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace dwtb {
+using namespace dwt;
+
+struct Ctx {
+	bool inited = false;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	char devname[256] = {0};
+	// workspace
+	void *stage_img = nullptr; // frame-sized staging image (in-place detour, generic passes)
+	size_t stage_bytes = 0;
+	void *ll[2] = {nullptr, nullptr}; // LL ping-pong
+	size_t ll_bytes[2] = {0, 0};
+	void *host_a = nullptr, *host_b = nullptr; // device images for host-pointer calls
+	size_t host_a_bytes = 0, host_b_bytes = 0;
+	void *pin = nullptr; // pinned host staging for host-pointer calls with awkward strides
+	size_t pin_bytes = 0;
+	// pipeline lanes for batches: image k runs all its levels on lane k % lanes, so the
+	// small tail levels of one image overlap the big levels of the next
+	struct Lane {
+		hipStream_t stream = nullptr;
+		void *ll[2] = {nullptr, nullptr};
+		size_t ll_bytes[2] = {0, 0};
+		void *stage_img = nullptr;
+		size_t stage_bytes = 0;
+		hipEvent_t done = nullptr;
+	};
+	static constexpr int kMaxLanes = 4;
+	Lane lanes[kMaxLanes];
+	hipEvent_t fork = nullptr;
+	// side stream: the copy-back of an in-place level 0 (and the copy-aside of an in-place
+	// final inverse level) overlaps the small levels instead of preceding/following them
+	hipStream_t side = nullptr;
+	hipEvent_t side_a = nullptr, side_b = nullptr;
+	bool side_pending = false;
+	int pipeline = 0; // 0: one launch per level for the whole batch; n>=2: n lanes
+	// options
+	SweepTuning tune;
+	VolTuning vol;
+	int force_generic = 0;
+	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
+	// profiling
+	int prof_on = 0;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+	std::vector<int> prof_tag; // level index of each recorded pair
+	size_t prof_used = 0;
+	double prof_ms = 0;
+	int prof_launches = 0;
+	double prof_level_ms[16] = {0};
+	int prof_level_n[16] = {0};
+};
+
+extern Ctx g;
+extern bool g_elems_are_32bit; // set per call: the fused sweeps exist for 4-byte elements only
+
+int fail(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                \
+		if (e_ != hipSuccess)                                                                  \
+			return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+inline int ceil_div_pow2(int i, int j) { return (i + (1 << j) - 1) >> j; } // src/inline.h:455-461
+inline int ceil_log2(int x)                                               // src/inline.h:443-448
+{
+	int n = 0;
+	while (n < 31 && (1 << n) < x)
+		n++;
+	return n;
+}
+inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+// A device image: element (y,x) at p + y*sx + x*es (dense elements of es = 4 or 8 bytes).
+struct Img {
+	char *p;
+	long sx;    // row pitch in bytes
+	int es = 4; // element size in bytes
+};
+
+struct Geom {
+	int sox, soy, six, siy;
+	int Wo(int j) const { return ceil_div_pow2(sox, j); }
+	int Ho(int j) const { return ceil_div_pow2(soy, j); }
+	int Wi(int j) const { return ceil_div_pow2(six, j); }
+	int Hi(int j) const { return ceil_div_pow2(siy, j); }
+	bool dense() const { return sox == six && soy == siy; }
+};
+
+int grow(void **p, size_t *have, size_t need);
+int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
+int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
+int zero_rect(Img img, long x, long y, long w, long h);
+int side_fork();
+int side_join();
+// host images <-> dense device images (any byte strides; awkward pitches go through a pinned buffer)
+int host_upload(const void *hp, int stride_x, int stride_y, int es, int w, int h, void *dp, long pitch);
+int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, const void *dp, long pitch);
+// one exact out-of-place 1-D pass over the lines of a frame (in == out is staged)
+int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_w, int frame_h, int n_lines, int N, int hoff);
+void prof_before(int level = 0);
+void prof_after(int level = 0);
+int check_inited();
+
+} // namespace dwtb

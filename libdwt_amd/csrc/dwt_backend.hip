@@ -20,70 +20,9 @@
 // Frames with size_o != size_i, zero padding, and levels where a direction has a
 // single line follow the reference's exact line-by-line semantics through the
 // generic line-pass kernel, out of place per pass.
-#include "../../include/libdwt_hip.h"
-#include "dwt_kernels.h"
+#include "dwt_backend.h"
 
-#include <hip/hip_runtime.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <thread>
-#include <utility>
-#include <vector>
-
-using namespace dwt;
-
-namespace {
-
-struct Ctx {
-	bool inited = false;
-	int device = 0;
-	hipStream_t stream = nullptr;
-	char devname[256] = {0};
-	// workspace
-	void *stage_img = nullptr; // frame-sized staging image (in-place detour, generic passes)
-	size_t stage_bytes = 0;
-	void *ll[2] = {nullptr, nullptr}; // LL ping-pong
-	size_t ll_bytes[2] = {0, 0};
-	void *host_a = nullptr, *host_b = nullptr; // device images for host-pointer calls
-	size_t host_a_bytes = 0, host_b_bytes = 0;
-	void *pin = nullptr; // pinned host staging for host-pointer calls with awkward strides
-	size_t pin_bytes = 0;
-	// pipeline lanes for batches: image k runs all its levels on lane k % lanes, so the
-	// small tail levels of one image overlap the big levels of the next
-	struct Lane {
-		hipStream_t stream = nullptr;
-		void *ll[2] = {nullptr, nullptr};
-		size_t ll_bytes[2] = {0, 0};
-		void *stage_img = nullptr;
-		size_t stage_bytes = 0;
-		hipEvent_t done = nullptr;
-	};
-	static constexpr int kMaxLanes = 4;
-	Lane lanes[kMaxLanes];
-	hipEvent_t fork = nullptr;
-	// side stream: the copy-back of an in-place level 0 (and the copy-aside of an in-place
-	// final inverse level) overlaps the small levels instead of preceding/following them
-	hipStream_t side = nullptr;
-	hipEvent_t side_a = nullptr, side_b = nullptr;
-	bool side_pending = false;
-	int pipeline = 0; // 0: one launch per level for the whole batch; n>=2: n lanes
-	// options
-	SweepTuning tune;
-	VolTuning vol;
-	int force_generic = 0;
-	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
-	// profiling
-	int prof_on = 0;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-	std::vector<int> prof_tag; // level index of each recorded pair
-	size_t prof_used = 0;
-	double prof_ms = 0;
-	int prof_launches = 0;
-	double prof_level_ms[16] = {0};
-	int prof_level_n[16] = {0};
-};
+namespace dwtb {
 
 Ctx g;
 thread_local char g_err[512] = "";
@@ -96,23 +35,6 @@ int fail(const char *fmt, ...)
 	va_end(ap);
 	return 1;
 }
-
-#define HIP_TRY(expr)                                                                          \
-	do {                                                                                       \
-		hipError_t e_ = (expr);                                                                \
-		if (e_ != hipSuccess)                                                                  \
-			return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-	} while (0)
-
-inline int ceil_div_pow2(int i, int j) { return (i + (1 << j) - 1) >> j; } // src/inline.h:455-461
-inline int ceil_log2(int x)                                               // src/inline.h:443-448
-{
-	int n = 0;
-	while (n < 31 && (1 << n) < x)
-		n++;
-	return n;
-}
-inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
 
 int grow(void **p, size_t *have, size_t need)
 {
@@ -129,21 +51,6 @@ int grow(void **p, size_t *have, size_t need)
 	return 0;
 }
 
-// A device image: element (y,x) at p + y*sx + x*es (dense elements of es = 4 or 8 bytes).
-struct Img {
-	char *p;
-	long sx;    // row pitch in bytes
-	int es = 4; // element size in bytes
-};
-
-struct Geom {
-	int sox, soy, six, siy;
-	int Wo(int j) const { return ceil_div_pow2(sox, j); }
-	int Ho(int j) const { return ceil_div_pow2(soy, j); }
-	int Wi(int j) const { return ceil_div_pow2(six, j); }
-	int Hi(int j) const { return ceil_div_pow2(siy, j); }
-	bool dense() const { return sox == six && soy == siy; }
-};
 
 bool skip_single(Wavelet w) { return w == kCdf97S; } // only the 9/7 drivers guard on lines > 1
 
@@ -203,7 +110,7 @@ static bool host_pitch_is_fast(const void *hp, int stride_x, int stride_y, int e
 }
 
 // w x h elements of `es` bytes at hp (byte strides) -> device image dp with `pitch`
-static int host_upload(const void *hp, int stride_x, int stride_y, int es, int w, int h, void *dp, long pitch)
+int host_upload(const void *hp, int stride_x, int stride_y, int es, int w, int h, void *dp, long pitch)
 {
 	if (host_pitch_is_fast(hp, stride_x, stride_y, es)) {
 		HIP_TRY(hipMemcpy2DAsync(dp, pitch, hp, stride_x, (size_t)w * es, h, hipMemcpyHostToDevice, g.stream));
@@ -230,7 +137,7 @@ static int host_upload(const void *hp, int stride_x, int stride_y, int es, int w
 	return 0;
 }
 
-static int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, const void *dp, long pitch)
+int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, const void *dp, long pitch)
 {
 	if (host_pitch_is_fast(hp, stride_x, stride_y, es)) {
 		HIP_TRY(hipMemcpy2DAsync(hp, stride_x, dp, pitch, (size_t)w * es, h, hipMemcpyDeviceToHost, g.stream));
@@ -334,7 +241,7 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 	return 0;
 }
 
-void prof_before(int level = 0)
+void prof_before(int level)
 {
 	if (!g.prof_on || (g.prof_on == 1 && level != 0))
 		return;
@@ -350,7 +257,7 @@ void prof_before(int level = 0)
 	hipEventRecord(g.prof_events[g.prof_used].first, g.stream);
 }
 
-void prof_after(int level = 0)
+void prof_after(int level)
 {
 	if (!g.prof_on || (g.prof_on == 1 && level != 0))
 		return;
@@ -402,7 +309,7 @@ int ensure_ll(const Geom &ge, int batch)
 	return 0;
 }
 
-bool g_elems_are_32bit = true; // set per call: the fused sweeps exist for 4-byte elements only
+bool g_elems_are_32bit = true;
 
 bool level_fused_ok(const Geom &ge, int j)
 {
@@ -722,7 +629,9 @@ int check_inited()
 	return 0;
 }
 
-} // namespace
+} // namespace dwtb
+
+using namespace dwtb;
 
 // ---- C ABI ------------------------------------------------------------------------
 #pragma GCC visibility push(default)
@@ -1043,340 +952,6 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	return download(dst, B.p);
 }
 
-// ---------------------------------------------------------------------------------
-// Interleaved (in-place lifting) layout: libdwt.h dwt_cdf97_2f_inplace_s (src/libdwt.c:12926),
-// dwt_cdf97_2i_inplace_s (:17474), dwt_cdf53_2f_inplace_s (:16553), dwt_cdf53_2i_inplace_s
-// (:17886) and dwt-simple.h fdwt2_cdf97_* / fdwt2_cdf53_* (src/dwt-simple.c:2224, :2356).
-// Level j transforms the stride-2^j lattice of the image in place.  On the device every
-// level runs on a DENSE image instead: the forward sweep of level j writes its low-pass
-// samples a second time, densely, as the input of level j+1, and the results of the levels
-// >= 1 are scattered into the lattice afterwards (deepest last); the inverse gathers the
-// lattices first.  Rows are finished before columns at every level; the 9/7 entries of the
-// reference interleave the two in phases (prolog / core / epilog), which changes fp32
-// rounding in the 8-sample border bands only (tests/test_oracle_interleaved.py).
-// ---------------------------------------------------------------------------------
-struct IlLevel {
-	float *a = nullptr, *b = nullptr; // dense input / output of the level (levels >= 1)
-	long pitch = 0;                   // elements
-	int lx = 0, ly = 0;
-};
-
-// The reference's 9/7 in-place drivers and fdwt2_* cut every line transform into phases --
-// SHORT (whole line, lines shorter than `min_phased`), PROLOG, CORE, EPILOG -- and run each
-// phase over all rows, then all columns, before the next (src/dwt-simple.c:2266-2350,
-// src/libdwt.c:12970-13480, 17517-17594).  This is that order, phase by phase, for
-// dwt_util_set_accel(1): bit-identical to the reference, eight passes per level instead of one.
-// Index ranges per lifting step: prolog src/dwt-simple.c:580-611, core :981-1029, epilog
-// :1469-1528, short :424-510; inverse src/libdwt.c:9591-9668, 7661-7740, 9929-10010.
-static void il_phase_ranges(int N, int K, bool inverse, int phase, IlPhase *ph)
-{
-	// phase: 0 short, 1 prolog, 2 core, 3 epilog
-	for (int s = 0; s < 4; s++) {
-		ph->lo[s] = 1;
-		ph->hi[s] = 0;
-	}
-	if (phase == 0) {
-		for (int s = 0; s < K; s++) {
-			ph->lo[s] = 0;
-			ph->hi[s] = N - 1;
-		}
-		ph->sc_lo = 0;
-		ph->sc_hi = N - 1;
-	} else if (!inverse) {
-		const int M = (((N - 1) & ~1) - K) / 2; // core pairs, counted from index 1
-		for (int s = 0; s < K; s++) {
-			if (phase == 1) { ph->lo[s] = 0; ph->hi[s] = K - 1 - s; }
-			else if (phase == 2) { ph->lo[s] = K + 1 - s; ph->hi[s] = K - 1 - s + 2 * M; }
-			else { ph->lo[s] = K + 1 - s + 2 * M; ph->hi[s] = N - 1; }
-		}
-		if (phase == 1) { ph->sc_lo = 0; ph->sc_hi = 0; }
-		else if (phase == 2) { ph->sc_lo = 1; ph->sc_hi = 2 * M; }
-		else { ph->sc_lo = 2 * M + 1; ph->sc_hi = N - 1; }
-	} else {
-		const int M = ((N & ~1) - K) / 2; // core pairs, counted from index 0
-		for (int s = 0; s < K; s++) {
-			if (phase == 1) { ph->lo[s] = 0; ph->hi[s] = K - 2 - s; }
-			else if (phase == 2) { ph->lo[s] = K - s; ph->hi[s] = K - 2 - s + 2 * M; }
-			else { ph->lo[s] = K - s + 2 * M; ph->hi[s] = N - 1; }
-		}
-		if (phase == 1) { ph->sc_lo = 0; ph->sc_hi = K - 1; }
-		else if (phase == 2) { ph->sc_lo = K; ph->sc_hi = K - 1 + 2 * M; }
-		else { ph->sc_lo = K + 2 * M; ph->sc_hi = N - 1; }
-	}
-}
-
-static bool il_is_phased(Wavelet w) { return w == kCdf97S || w == kCdf97SFma || w == kCdf53SNew; }
-
-static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int ly)
-{
-	if (in.sx != out.sx)
-		return fail("interleaved phased level: pitches differ");
-	const int K = w == kCdf53SNew ? 2 : 4;
-	const int min_phased = w == kCdf53SNew ? 3 : (inverse ? 4 : 5);
-	struct Pass { bool rows; int phase; };
-	Pass seq[8];
-	int n = 0;
-	for (int phase = 0; phase < 4; phase++) {
-		if (lx > 1 && (phase == 0) == (lx < min_phased))
-			seq[n++] = {true, phase};
-		if (ly > 1 && (phase == 0) == (ly < min_phased))
-			seq[n++] = {false, phase};
-	}
-	if (n == 0)
-		return copy_rect(out, 0, 0, in, 0, 0, lx, ly);
-	if (grow(&g.host_b, &g.host_b_bytes, (size_t)in.sx * ly))
-		return 1;
-	Img tmp{(char *)g.host_b, in.sx, 4};
-	// ping-pong so that the last pass writes `out`
-	Img cur = in;
-	for (int i = 0; i < n; i++) {
-		const Img nxt = ((n - 1 - i) % 2 == 0) ? out : tmp;
-		IlPhase ph;
-		const int N = seq[i].rows ? lx : ly;
-		il_phase_ranges(N, K, inverse, seq[i].phase, &ph);
-		hipError_t e = launch_il_phase(w == kCdf97SFma ? kCdf97S : w, inverse, cur.p, nxt.p, seq[i].rows ? cur.sx : 4, seq[i].rows ? 4 : cur.sx,
-			seq[i].rows ? ly : lx, N, !seq[i].rows, ph, g.stream);
-		if (e != hipSuccess)
-			return fail("interleaved phase launch failed: %s", hipGetErrorString(e));
-		cur = nxt;
-	}
-	return 0;
-}
-
-// one level on dense images with a common pitch: rows completely, then columns
-static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
-	const Img *even_rows = nullptr)
-{
-	const bool fused = !g.force_generic && lx >= 2 && ly >= 2 && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
-	if (even_rows && !fused)
-		return fail("internal: split rows need the fused sweep");
-	if (fused) {
-		hipError_t e;
-		if (!inverse) {
-			FwdLevelArgs a;
-			a.in = in.p; a.in_pitch = in.sx / 4; a.in_bstride = 0;
-			a.out_ll = ll; a.ll_pitch = ll_pitch; a.ll_bstride = 0;
-			a.out_h = out.p; a.h_pitch = out.sx / 4; a.h_bstride = 0;
-			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1; a.il_ll = ll != nullptr;
-			e = launch_fwd_level(w, a, g.tune, g.stream);
-		} else {
-			InvLevelArgs a;
-			// the even rows may live in a buffer of their own (packed), see interleaved2d
-			a.in_ll = even_rows ? even_rows->p : in.p; a.ll_pitch = even_rows ? even_rows->sx / 4 : in.sx / 4 * 2; a.ll_bstride = 0;
-			a.in_h = in.p + in.sx; a.h_pitch = in.sx / 4 * 2; a.h_bstride = 0;
-			a.out = out.p; a.out_pitch = out.sx / 4; a.out_bstride = 0;
-			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1;
-			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream);
-		}
-		if (e != hipSuccess)
-			return fail("interleaved sweep launch failed: %s", hipGetErrorString(e));
-		return 0;
-	}
-	// generic.  The phase-ordered entries reproduce the reference's order exactly when the
-	// generic path was asked for (accel 1); tiny levels of the fused path and the 5/3 _inplace_
-	// pair (rows, then columns in the reference too) take two exact line passes.
-	if (g.force_generic && il_is_phased(w) && !scale_single) {
-		if (il_level_phased(w, inverse, in, out, lx, ly))
-			return 1;
-		if (ll && !inverse) {
-			hipError_t e = launch_lattice_copy((const float *)out.p, 2, out.sx / 4 * 2, 0, ll, 1, ll_pitch, 0, (lx + 1) / 2, (ly + 1) / 2, 1, g.stream);
-			if (e != hipSuccess)
-				return fail("lattice gather failed: %s", hipGetErrorString(e));
-		}
-		return 0;
-	}
-	if (in.sx != out.sx)
-		return fail("interleaved generic level: pitches differ");
-	if (grow(&g.host_b, &g.host_b_bytes, (size_t)in.sx * ly))
-		return 1;
-	Img tmp{(char *)g.host_b, in.sx, 4};
-	auto pass = [&](bool rows, Img from, Img to) -> int {
-		const int N = rows ? lx : ly, lines = rows ? ly : lx;
-		if (N == 1 && !scale_single)
-			return copy_rect(to, 0, 0, from, 0, 0, lx, ly);
-		hipError_t e = launch_line_pass(w, inverse, from.p, to.p, rows ? from.sx : 4, rows ? 4 : from.sx, lines, N, -1, !rows, g.stream);
-		if (e != hipSuccess)
-			return fail("interleaved line pass launch failed: %s", hipGetErrorString(e));
-		return 0;
-	};
-	if (pass(true, in, tmp) || pass(false, tmp, out))
-		return 1;
-	if (ll && !inverse) {
-		hipError_t e = launch_lattice_copy((const float *)out.p, 2, out.sx / 4 * 2, 0, ll, 1, ll_pitch, 0, (lx + 1) / 2, (ly + 1) / 2, 1, g.stream);
-		if (e != hipSuccess)
-			return fail("lattice gather failed: %s", hipGetErrorString(e));
-	}
-	return 0;
-}
-
-static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
-	int *jp, int decompose_one)
-{
-	const int j_limit = ceil_log2(decompose_one ? (sox > soy ? sox : soy) : (sox < soy ? sox : soy));
-	int J = *jp;
-	if (J < 0 || J > j_limit)
-		J = j_limit;
-	if (!inverse)
-		*jp = J;
-	if (side_join())
-		return 1;
-	const bool alias = src.p == dst.p;
-	// everything outside the transformed region keeps the caller's values
-	const bool sparse = six < sox || siy < soy;
-	if (!alias && (J == 0 || sparse) && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))
-		return 1;
-	if (J == 0 || six < 1 || siy < 1)
-		return 0;
-	constexpr int kMax = 32;
-	IlLevel L[kMax];
-	size_t pool = 0;
-	for (int j = 0; j < J; j++) {
-		L[j].lx = ceil_div_pow2(six, j);
-		L[j].ly = ceil_div_pow2(siy, j);
-		L[j].pitch = align_up(L[j].lx, 4);
-		if (j >= 1)
-			pool += (size_t)L[j].pitch * L[j].ly;
-	}
-	if (J > 1) {
-		if (grow(&g.ll[0], &g.ll_bytes[0], pool * 4) || grow(&g.ll[1], &g.ll_bytes[1], pool * 4))
-			return 1;
-		float *pa = (float *)g.ll[0], *pb = (float *)g.ll[1];
-		for (int j = 1; j < J; j++) {
-			L[j].a = pa; L[j].b = pb;
-			pa += (size_t)L[j].pitch * L[j].ly;
-			pb += (size_t)L[j].pitch * L[j].ly;
-		}
-	}
-	auto dense = [&](float *p, const IlLevel &l) { return Img{(char *)p, l.pitch * 4, 4}; };
-	auto scatter = [&](const float *from, long from_pitch, char *to, long to_pitch_bytes, long step, const IlLevel &l) -> int {
-		// dense level -> lattice of stride `step` (elements) of an image
-		hipError_t e = launch_lattice_copy(from, 1, from_pitch, 0, (float *)to, step, to_pitch_bytes / 4 * step, 0, l.lx, l.ly, 1, g.stream);
-		if (e != hipSuccess)
-			return fail("lattice scatter failed: %s", hipGetErrorString(e));
-		return 0;
-	};
-	// level 0 works on the caller's image; in place it detours through the staging image
-	Img stage{nullptr, dst.sx, 4};
-	if (alias || inverse) {
-		if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * siy))
-			return 1;
-		stage.p = (char *)g.stage_img;
-	}
-
-	auto pyramid = [&](bool results, int levels) {
-		IlPyramid py;
-		py.J = levels;
-		for (int j = 1; j < levels; j++) {
-			py.p[j] = results ? L[j].b : L[j].a;
-			py.pitch[j] = L[j].pitch;
-		}
-		return py;
-	};
-	// rows 1, 3, 5, ... of the transformed region from one image to another
-	auto copy_odd_rows = [&](Img to, Img from) -> int {
-		return copy_rect(Img{to.p + to.sx, to.sx * 2, 4}, 0, 0, Img{from.p + from.sx, from.sx * 2, 4}, 0, 0, six, siy / 2);
-	};
-
-	if (!inverse) {
-		for (int j = 0; j < J; j++) {
-			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
-			const Img out = j == 0 ? (alias ? stage : dst) : dense(L[j].b, L[j]);
-			float *ll = j + 1 < J ? L[j + 1].a : nullptr;
-			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0))
-				return 1;
-		}
-		if (J == 1)
-			return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
-		// the even rows receive the samples of the levels >= 1 in ONE pass (in place that pass
-		// also brings them back from the staging image; the odd rows are final after level 0)
-		if (alias && copy_odd_rows(dst, stage))
-			return 1;
-		const Img base = alias ? stage : dst;
-		hipError_t e = launch_il_compose((const float *)base.p, base.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream);
-		if (e != hipSuccess)
-			return fail("interleaved compose failed: %s", hipGetErrorString(e));
-		return 0;
-	}
-	// inverse: the coefficients are read from the source image (never modified before the last
-	// sweep has read it, so out of place needs no copy)
-	const Img cin = src;
-	if (J == 1) {
-		if (!alias)
-			return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0);
-		if (il_level(w, true, scale_single, dst, stage, L[0].lx, L[0].ly, nullptr, 0))
-			return 1;
-		return copy_rect(dst, 0, 0, stage, 0, 0, six, siy);
-	}
-	hipError_t e = launch_il_decompose((const float *)cin.p, cin.sx / 4, six, siy, pyramid(false, J), g.stream);
-	if (e != hipSuccess)
-		return fail("interleaved decompose failed: %s", hipGetErrorString(e));
-	for (int j = J - 1; j >= 1; j--) {
-		if (il_level(w, true, scale_single, dense(L[j].a, L[j]), dense(L[j].b, L[j]), L[j].lx, L[j].ly, nullptr, 0))
-			return 1;
-		// the reconstructed low-pass band is the even-even lattice of the level above
-		if (j >= 2 && scatter(L[j].b, L[j].pitch, (char *)L[j - 1].a, L[j - 1].pitch * 4, 2, L[j]))
-			return 1;
-	}
-	// level 0.  Out of place (fused sweep): odd rows straight from the coefficient image, even
-	// rows from a packed copy that carries the reconstructed LL band (one compose pass).  In
-	// place the sweep must not read what it overwrites: its whole input is built in the staging
-	// image (odd rows copied, even rows composed) and the sweep writes the caller's image.
-	const bool split = !alias && !g.force_generic && L[0].lx >= 2 && L[0].ly >= 2;
-	if (split) {
-		const Img even{stage.p, stage.sx, 4}; // (siy+1)/2 packed rows
-		e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)even.p, even.sx / 4, six, siy, pyramid(true, 2), g.stream, true);
-		if (e != hipSuccess)
-			return fail("interleaved compose failed: %s", hipGetErrorString(e));
-		return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0, &even);
-	}
-	if (copy_odd_rows(stage, cin))
-		return 1;
-	e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)stage.p, stage.sx / 4, six, siy, pyramid(true, 2), g.stream);
-	if (e != hipSuccess)
-		return fail("interleaved compose failed: %s", hipGetErrorString(e));
-	return il_level(w, true, scale_single, stage, dst, L[0].lx, L[0].ly, nullptr, 0);
-}
-
-int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const void *src, void *dst, int stride_x, int stride_y,
-	int sox, int soy, int six, int siy, int *j, int decompose_one)
-{
-	if (check_inited())
-		return 1;
-	if (wavelet != kCdf97S && wavelet != kCdf53S)
-		return fail("the interleaved layout takes the float wavelets (CDF 9/7, CDF 5/3), not %d", wavelet);
-	if (flavour != 0 && flavour != 1)
-		return fail("unknown flavour %d", flavour);
-	if (flavour == 1 && inverse)
-		return fail("dwt-simple.h has forward transforms only; use flavour 0 for the inverse");
-	if (!src || !dst || !j)
-		return fail("null pointer argument");
-	if (sox <= 0 || soy <= 0 || six < 0 || siy < 0 || six > sox || siy > soy)
-		return fail("bad sizes: outer %dx%d inner %dx%d", sox, soy, six, siy);
-	g_elems_are_32bit = true;
-	// single-sample lines: the 9/7 drivers and fdwt2_* leave them (guards `size > 1`,
-	// libdwt.c:12978, dwt-simple.c:2266), the 5/3 _inplace_ drivers scale them (:11041, :11840)
-	const bool scale_single = wavelet == kCdf53S && flavour == 0;
-	const Wavelet w = wavelet == kCdf97S ? ((g.fma && !inverse) ? kCdf97SFma : kCdf97S) : (flavour == 1 ? kCdf53SNew : kCdf53S);
-	const bool dev_src = dwt_hip_is_device_pointer(src), dev_dst = dwt_hip_is_device_pointer(dst);
-	if (dev_src != dev_dst)
-		return fail("src and dst must both be host or both be device pointers");
-	if (dev_dst) {
-		if (stride_y != 4 || (stride_x % 4) || stride_x < sox * 4)
-			return fail("device images need stride_y == 4 and stride_x a multiple of it >= width*4 (got %d, %d)", stride_x, stride_y);
-		return interleaved2d(w, inverse != 0, scale_single, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
-	}
-	// host pointers: stage the outer frame through HBM (any byte strides)
-	const long pitch = align_up((long)sox * 4, 256);
-	if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * soy))
-		return 1;
-	if (host_upload(src, stride_x, stride_y, 4, sox, soy, g.host_a, pitch))
-		return 1;
-	Img A{(char *)g.host_a, pitch, 4};
-	if (interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one))
-		return 1;
-	return host_download(dst, stride_x, stride_y, 4, sox, soy, g.host_a, pitch);
-}
-
 int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *dst, size_t batch_stride, int batch,
 	int stride_x, int size_x, int size_y, int *j)
 {
@@ -1472,204 +1047,6 @@ int dwt_hip_compare(int is_int, const void *ptr1, const void *ptr2, int stride_x
 		return -1;
 	}
 	return host ? 1 : 0;
-}
-
-// Forward 3-D transform, OUT OF PLACE: the layout and arithmetic of cdf97_3f_op_sep_horizontal_s
-// (src/volume-dwt.c:727-785: copy each x line to the destination, then lift x, y, z there), the
-// entry the reference's own 3-D perf test drives (volume_perftest_fwd97op_s, src/volume.c).
-// Level j reads a dense volume and writes a dense volume, so each level is ONE fused pass
-// (k_vol_fwd_fused) where that kernel applies and the two-pass path (xy sweep, z sweep through
-// the scratch volume) elsewhere; the even-even-even samples go to the next level densely, and the
-// results of the levels >= 1 are scattered into their lattices at the end (deepest first).
-int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
-{
-	if (check_inited())
-		return 1;
-	if (!src || !dst || !dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
-		return fail("dwt_hip_transform3d_op takes device pointers");
-	if (src == dst)
-		return fail("dwt_hip_transform3d_op is out of place; use dwt_hip_transform3d for in-place volumes");
-	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
-		return fail("bad volume strides");
-	constexpr int kMaxLevels = 24;
-	if (levels > kMaxLevels)
-		return fail("too many levels");
-	if (levels >= 1 && (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2))
-		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
-	const long vsy = (long)stride_y / 4, vsz = (long)stride_z / 4;
-	if (levels < 1) {
-		// no levels: the reference's copy stage alone
-		hipError_t e = launch_lattice_copy((const float *)src, 1, vsy, vsz, (float *)dst, 1, vsy, vsz, nx, ny, nz, g.stream);
-		return e == hipSuccess ? 0 : fail("volume copy failed: %s", hipGetErrorString(e));
-	}
-	struct Lvl { const float *in; float *out; long sy, sz; int lx, ly, lz; } L[kMaxLevels];
-	L[0] = {(const float *)src, (float *)dst, vsy, vsz, nx, ny, nz};
-	size_t pool = 0;
-	for (int j = 1; j < levels; j++) {
-		L[j].lx = ceil_div_pow2(nx, j); L[j].ly = ceil_div_pow2(ny, j); L[j].lz = ceil_div_pow2(nz, j);
-		L[j].sy = align_up(L[j].lx, 4);
-		L[j].sz = L[j].sy * L[j].ly;
-		pool += (size_t)L[j].sz * L[j].lz;
-	}
-	if (levels > 1) {
-		if (grow(&g.host_a, &g.host_a_bytes, pool * 4) || grow(&g.host_b, &g.host_b_bytes, pool * 4))
-			return 1;
-		float *pa = (float *)g.host_a, *pb = (float *)g.host_b;
-		for (int j = 1; j < levels; j++) {
-			L[j].in = pa; L[j].out = pb;
-			pa += (size_t)L[j].sz * L[j].lz;
-			pb += (size_t)L[j].sz * L[j].lz;
-		}
-	}
-	for (int j = 0; j < levels; j++)
-		if (L[j].lz > 65535 || L[j].ly > 65535)
-			return fail("volume too large for the launch grid");
-	float *S = nullptr;
-	long s_sy = 0, s_sz = 0;
-	for (int j = 0; j < levels; j++) {
-		const Lvl &b = L[j];
-		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;
-		const long lsy = j + 1 < levels ? L[j + 1].sy : 0, lsz = j + 1 < levels ? L[j + 1].sz : 0;
-		VolFusedArgs fa{b.in, b.sy, b.sz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
-		const bool can_fuse = fa.in != fa.out && fa.nx >= 2 && fa.ny >= 2 && fa.nz >= 2;
-		if (!g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(fa)) || (g.vol.fused >= 2 && can_fuse))) {
-			prof_before(j);
-			hipError_t e = launch_vol_fwd_fused(fa, g.vol, g.stream);
-			prof_after(j);
-			if (e != hipSuccess)
-				return fail("fused 3-D level launch failed: %s", hipGetErrorString(e));
-			continue;
-		}
-		// two passes through the scratch volume
-		if (!S) {
-			s_sy = align_up(nx, 4);
-			s_sz = s_sy * ny;
-			if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
-				return 1;
-			S = (float *)g.stage_img;
-		}
-		FwdLevelArgs a;
-		a.in = b.in; a.in_pitch = b.sy; a.in_bstride = b.sz;
-		a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
-		a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
-		a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
-		hipError_t e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
-		if (e != hipSuccess)
-			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
-		e = launch_vol_z(false, S, s_sy, s_sz, b.out, b.sy, b.sz, b.lx, b.ly, b.lz, g.vol, g.stream, lll, lsy, lsz);
-		if (e != hipSuccess)
-			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
-	}
-	for (int j = levels - 1; j >= 1; j--) {
-		const Lvl &c = L[j], &par = L[j - 1];
-		hipError_t e = launch_lattice_copy(c.out, 1, c.sy, c.sz, par.out, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
-		if (e != hipSuccess)
-			return fail("lattice scatter failed: %s", hipGetErrorString(e));
-	}
-	return 0;
-}
-
-int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
-{
-	if (check_inited())
-		return 1;
-	if (!vol || !dwt_hip_is_device_pointer(vol))
-		return fail("dwt_hip_transform3d takes a device pointer");
-	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
-		return fail("bad volume strides");
-	if (levels < 1)
-		return 0;
-	// every level needs at least 2 samples per axis (the reference asserts >= 5, dwt-simple.c:2172)
-	if (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2)
-		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
-	// scratch: S (pass-to-pass buffer) and, for levels >= 1, dense copies P[j] of the
-	// level-j lattice (even-even-even samples of level j-1), all carved from one buffer
-	const long s_sy = align_up(nx, 4), s_sz = s_sy * ny;
-	if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
-		return 1;
-	float *S = (float *)g.stage_img;
-	constexpr int kMaxLevels = 24;
-	if (levels > kMaxLevels)
-		return fail("too many levels");
-	struct Lvl { float *p; long sy, sz; int lx, ly, lz; } L[kMaxLevels];
-	L[0] = {(float *)vol, (long)stride_y / 4, (long)stride_z / 4, nx, ny, nz};
-	size_t p_total = 0;
-	for (int j = 1; j < levels; j++) {
-		L[j].lx = ceil_div_pow2(nx, j); L[j].ly = ceil_div_pow2(ny, j); L[j].lz = ceil_div_pow2(nz, j);
-		L[j].sy = align_up(L[j].lx, 4);
-		L[j].sz = L[j].sy * L[j].ly;
-		p_total += (size_t)L[j].sz * L[j].lz;
-	}
-	if (levels > 1) {
-		if (grow(&g.host_a, &g.host_a_bytes, p_total * 4))
-			return 1;
-		float *p = (float *)g.host_a;
-		for (int j = 1; j < levels; j++) {
-			L[j].p = p;
-			p += (size_t)L[j].sz * L[j].lz;
-		}
-	}
-	for (int j = 0; j < levels; j++)
-		if (L[j].lz > 65535 || L[j].ly > 65535)
-			return fail("volume too large for the launch grid");
-
-	auto one_level = [&](const Lvl &b, const Lvl *next) -> int {
-		// x then y fused per slice, then z (src/volume-dwt.c:677-725; inverse :1115-1163)
-		hipError_t e;
-		if (!inverse) {
-			FwdLevelArgs a;
-			a.in = b.p; a.in_pitch = b.sy; a.in_bstride = b.sz;
-			a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
-			a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
-			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
-			e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
-		} else {
-			InvLevelArgs a;
-			a.in_ll = b.p; a.ll_pitch = 2 * b.sy; a.ll_bstride = b.sz;
-			a.in_h = b.p + b.sy; a.h_pitch = 2 * b.sy; a.h_bstride = b.sz;
-			a.out = S; a.out_pitch = s_sy; a.out_bstride = s_sz;
-			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
-			e = launch_inv_level(kCdf97S, a, g.tune, g.stream);
-		}
-		if (e != hipSuccess)
-			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
-		// forward: the z pass also writes the next level's input densely (no lattice gather)
-		e = launch_vol_z(inverse != 0, S, s_sy, s_sz, b.p, b.sy, b.sz, b.lx, b.ly, b.lz, g.vol, g.stream,
-			next ? next->p : nullptr, next ? next->sy : 0, next ? next->sz : 0);
-		if (e != hipSuccess)
-			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
-		return 0;
-	};
-	// level j lives on the stride-2 lattice (even-even-even samples) of level j-1
-	auto lattice = [&](int j, bool pack) -> int {
-		const Lvl &c = L[j], &par = L[j - 1];
-		hipError_t e = pack
-			? launch_lattice_copy(par.p, 2, par.sy * 2, par.sz * 2, c.p, 1, c.sy, c.sz, c.lx, c.ly, c.lz, g.stream)
-			: launch_lattice_copy(c.p, 1, c.sy, c.sz, par.p, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
-		if (e != hipSuccess)
-			return fail("lattice %s failed: %s", pack ? "pack" : "unpack", hipGetErrorString(e));
-		return 0;
-	};
-
-	if (!inverse) {
-		for (int j = 0; j < levels; j++)
-			if (one_level(L[j], j + 1 < levels ? &L[j + 1] : nullptr))
-				return 1;
-		for (int j = levels - 1; j >= 1; j--)
-			if (lattice(j, false))
-				return 1;
-	} else {
-		for (int j = 1; j < levels; j++)
-			if (lattice(j, true))
-				return 1;
-		for (int j = levels - 1; j >= 0; j--) {
-			if (one_level(L[j], nullptr))
-				return 1;
-			if (j >= 1 && lattice(j, false))
-				return 1;
-		}
-	}
-	return 0;
 }
 
 } // extern "C"

@@ -1,0 +1,346 @@
+// dwt_backend_il.hip -- the interleaved (in-place lifting) layout: level chain on dense images,
+// compose / decompose of the lattices, the exact phase-ordered path, and the C-ABI entry.
+#include "dwt_backend.h"
+
+using namespace dwtb;
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+
+// ---------------------------------------------------------------------------------
+// Interleaved (in-place lifting) layout: libdwt.h dwt_cdf97_2f_inplace_s (src/libdwt.c:12926),
+// dwt_cdf97_2i_inplace_s (:17474), dwt_cdf53_2f_inplace_s (:16553), dwt_cdf53_2i_inplace_s
+// (:17886) and dwt-simple.h fdwt2_cdf97_* / fdwt2_cdf53_* (src/dwt-simple.c:2224, :2356).
+// Level j transforms the stride-2^j lattice of the image in place.  On the device every
+// level runs on a DENSE image instead: the forward sweep of level j writes its low-pass
+// samples a second time, densely, as the input of level j+1, and the results of the levels
+// >= 1 are scattered into the lattice afterwards (deepest last); the inverse gathers the
+// lattices first.  Rows are finished before columns at every level; the 9/7 entries of the
+// reference interleave the two in phases (prolog / core / epilog), which changes fp32
+// rounding in the 8-sample border bands only (tests/test_oracle_interleaved.py).
+// ---------------------------------------------------------------------------------
+struct IlLevel {
+	float *a = nullptr, *b = nullptr; // dense input / output of the level (levels >= 1)
+	long pitch = 0;                   // elements
+	int lx = 0, ly = 0;
+};
+
+// The reference's 9/7 in-place drivers and fdwt2_* cut every line transform into phases --
+// SHORT (whole line, lines shorter than `min_phased`), PROLOG, CORE, EPILOG -- and run each
+// phase over all rows, then all columns, before the next (src/dwt-simple.c:2266-2350,
+// src/libdwt.c:12970-13480, 17517-17594).  This is that order, phase by phase, for
+// dwt_util_set_accel(1): bit-identical to the reference, eight passes per level instead of one.
+// Index ranges per lifting step: prolog src/dwt-simple.c:580-611, core :981-1029, epilog
+// :1469-1528, short :424-510; inverse src/libdwt.c:9591-9668, 7661-7740, 9929-10010.
+static void il_phase_ranges(int N, int K, bool inverse, int phase, IlPhase *ph)
+{
+	// phase: 0 short, 1 prolog, 2 core, 3 epilog
+	for (int s = 0; s < 4; s++) {
+		ph->lo[s] = 1;
+		ph->hi[s] = 0;
+	}
+	if (phase == 0) {
+		for (int s = 0; s < K; s++) {
+			ph->lo[s] = 0;
+			ph->hi[s] = N - 1;
+		}
+		ph->sc_lo = 0;
+		ph->sc_hi = N - 1;
+	} else if (!inverse) {
+		const int M = (((N - 1) & ~1) - K) / 2; // core pairs, counted from index 1
+		for (int s = 0; s < K; s++) {
+			if (phase == 1) { ph->lo[s] = 0; ph->hi[s] = K - 1 - s; }
+			else if (phase == 2) { ph->lo[s] = K + 1 - s; ph->hi[s] = K - 1 - s + 2 * M; }
+			else { ph->lo[s] = K + 1 - s + 2 * M; ph->hi[s] = N - 1; }
+		}
+		if (phase == 1) { ph->sc_lo = 0; ph->sc_hi = 0; }
+		else if (phase == 2) { ph->sc_lo = 1; ph->sc_hi = 2 * M; }
+		else { ph->sc_lo = 2 * M + 1; ph->sc_hi = N - 1; }
+	} else {
+		const int M = ((N & ~1) - K) / 2; // core pairs, counted from index 0
+		for (int s = 0; s < K; s++) {
+			if (phase == 1) { ph->lo[s] = 0; ph->hi[s] = K - 2 - s; }
+			else if (phase == 2) { ph->lo[s] = K - s; ph->hi[s] = K - 2 - s + 2 * M; }
+			else { ph->lo[s] = K - s + 2 * M; ph->hi[s] = N - 1; }
+		}
+		if (phase == 1) { ph->sc_lo = 0; ph->sc_hi = K - 1; }
+		else if (phase == 2) { ph->sc_lo = K; ph->sc_hi = K - 1 + 2 * M; }
+		else { ph->sc_lo = K + 2 * M; ph->sc_hi = N - 1; }
+	}
+}
+
+static bool il_is_phased(Wavelet w) { return w == kCdf97S || w == kCdf97SFma || w == kCdf53SNew; }
+
+static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int ly)
+{
+	if (in.sx != out.sx)
+		return fail("interleaved phased level: pitches differ");
+	const int K = w == kCdf53SNew ? 2 : 4;
+	const int min_phased = w == kCdf53SNew ? 3 : (inverse ? 4 : 5);
+	struct Pass { bool rows; int phase; };
+	Pass seq[8];
+	int n = 0;
+	for (int phase = 0; phase < 4; phase++) {
+		if (lx > 1 && (phase == 0) == (lx < min_phased))
+			seq[n++] = {true, phase};
+		if (ly > 1 && (phase == 0) == (ly < min_phased))
+			seq[n++] = {false, phase};
+	}
+	if (n == 0)
+		return copy_rect(out, 0, 0, in, 0, 0, lx, ly);
+	if (grow(&g.host_b, &g.host_b_bytes, (size_t)in.sx * ly))
+		return 1;
+	Img tmp{(char *)g.host_b, in.sx, 4};
+	// ping-pong so that the last pass writes `out`
+	Img cur = in;
+	for (int i = 0; i < n; i++) {
+		const Img nxt = ((n - 1 - i) % 2 == 0) ? out : tmp;
+		IlPhase ph;
+		const int N = seq[i].rows ? lx : ly;
+		il_phase_ranges(N, K, inverse, seq[i].phase, &ph);
+		hipError_t e = launch_il_phase(w == kCdf97SFma ? kCdf97S : w, inverse, cur.p, nxt.p, seq[i].rows ? cur.sx : 4, seq[i].rows ? 4 : cur.sx,
+			seq[i].rows ? ly : lx, N, !seq[i].rows, ph, g.stream);
+		if (e != hipSuccess)
+			return fail("interleaved phase launch failed: %s", hipGetErrorString(e));
+		cur = nxt;
+	}
+	return 0;
+}
+
+// one level on dense images with a common pitch: rows completely, then columns
+static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
+	const Img *even_rows = nullptr)
+{
+	const bool fused = !g.force_generic && lx >= 2 && ly >= 2 && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
+	if (even_rows && !fused)
+		return fail("internal: split rows need the fused sweep");
+	if (fused) {
+		hipError_t e;
+		if (!inverse) {
+			FwdLevelArgs a;
+			a.in = in.p; a.in_pitch = in.sx / 4; a.in_bstride = 0;
+			a.out_ll = ll; a.ll_pitch = ll_pitch; a.ll_bstride = 0;
+			a.out_h = out.p; a.h_pitch = out.sx / 4; a.h_bstride = 0;
+			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1; a.il_ll = ll != nullptr;
+			e = launch_fwd_level(w, a, g.tune, g.stream);
+		} else {
+			InvLevelArgs a;
+			// the even rows may live in a buffer of their own (packed), see interleaved2d
+			a.in_ll = even_rows ? even_rows->p : in.p; a.ll_pitch = even_rows ? even_rows->sx / 4 : in.sx / 4 * 2; a.ll_bstride = 0;
+			a.in_h = in.p + in.sx; a.h_pitch = in.sx / 4 * 2; a.h_bstride = 0;
+			a.out = out.p; a.out_pitch = out.sx / 4; a.out_bstride = 0;
+			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1;
+			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream);
+		}
+		if (e != hipSuccess)
+			return fail("interleaved sweep launch failed: %s", hipGetErrorString(e));
+		return 0;
+	}
+	// generic.  The phase-ordered entries reproduce the reference's order exactly when the
+	// generic path was asked for (accel 1); tiny levels of the fused path and the 5/3 _inplace_
+	// pair (rows, then columns in the reference too) take two exact line passes.
+	if (g.force_generic && il_is_phased(w) && !scale_single) {
+		if (il_level_phased(w, inverse, in, out, lx, ly))
+			return 1;
+		if (ll && !inverse) {
+			hipError_t e = launch_lattice_copy((const float *)out.p, 2, out.sx / 4 * 2, 0, ll, 1, ll_pitch, 0, (lx + 1) / 2, (ly + 1) / 2, 1, g.stream);
+			if (e != hipSuccess)
+				return fail("lattice gather failed: %s", hipGetErrorString(e));
+		}
+		return 0;
+	}
+	if (in.sx != out.sx)
+		return fail("interleaved generic level: pitches differ");
+	if (grow(&g.host_b, &g.host_b_bytes, (size_t)in.sx * ly))
+		return 1;
+	Img tmp{(char *)g.host_b, in.sx, 4};
+	auto pass = [&](bool rows, Img from, Img to) -> int {
+		const int N = rows ? lx : ly, lines = rows ? ly : lx;
+		if (N == 1 && !scale_single)
+			return copy_rect(to, 0, 0, from, 0, 0, lx, ly);
+		hipError_t e = launch_line_pass(w, inverse, from.p, to.p, rows ? from.sx : 4, rows ? 4 : from.sx, lines, N, -1, !rows, g.stream);
+		if (e != hipSuccess)
+			return fail("interleaved line pass launch failed: %s", hipGetErrorString(e));
+		return 0;
+	};
+	if (pass(true, in, tmp) || pass(false, tmp, out))
+		return 1;
+	if (ll && !inverse) {
+		hipError_t e = launch_lattice_copy((const float *)out.p, 2, out.sx / 4 * 2, 0, ll, 1, ll_pitch, 0, (lx + 1) / 2, (ly + 1) / 2, 1, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice gather failed: %s", hipGetErrorString(e));
+	}
+	return 0;
+}
+
+static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
+	int *jp, int decompose_one)
+{
+	const int j_limit = ceil_log2(decompose_one ? (sox > soy ? sox : soy) : (sox < soy ? sox : soy));
+	int J = *jp;
+	if (J < 0 || J > j_limit)
+		J = j_limit;
+	if (!inverse)
+		*jp = J;
+	if (side_join())
+		return 1;
+	const bool alias = src.p == dst.p;
+	// everything outside the transformed region keeps the caller's values
+	const bool sparse = six < sox || siy < soy;
+	if (!alias && (J == 0 || sparse) && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))
+		return 1;
+	if (J == 0 || six < 1 || siy < 1)
+		return 0;
+	constexpr int kMax = 32;
+	IlLevel L[kMax];
+	size_t pool = 0;
+	for (int j = 0; j < J; j++) {
+		L[j].lx = ceil_div_pow2(six, j);
+		L[j].ly = ceil_div_pow2(siy, j);
+		L[j].pitch = align_up(L[j].lx, 4);
+		if (j >= 1)
+			pool += (size_t)L[j].pitch * L[j].ly;
+	}
+	if (J > 1) {
+		if (grow(&g.ll[0], &g.ll_bytes[0], pool * 4) || grow(&g.ll[1], &g.ll_bytes[1], pool * 4))
+			return 1;
+		float *pa = (float *)g.ll[0], *pb = (float *)g.ll[1];
+		for (int j = 1; j < J; j++) {
+			L[j].a = pa; L[j].b = pb;
+			pa += (size_t)L[j].pitch * L[j].ly;
+			pb += (size_t)L[j].pitch * L[j].ly;
+		}
+	}
+	auto dense = [&](float *p, const IlLevel &l) { return Img{(char *)p, l.pitch * 4, 4}; };
+	auto scatter = [&](const float *from, long from_pitch, char *to, long to_pitch_bytes, long step, const IlLevel &l) -> int {
+		// dense level -> lattice of stride `step` (elements) of an image
+		hipError_t e = launch_lattice_copy(from, 1, from_pitch, 0, (float *)to, step, to_pitch_bytes / 4 * step, 0, l.lx, l.ly, 1, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice scatter failed: %s", hipGetErrorString(e));
+		return 0;
+	};
+	// level 0 works on the caller's image; in place it detours through the staging image
+	Img stage{nullptr, dst.sx, 4};
+	if (alias || inverse) {
+		if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * siy))
+			return 1;
+		stage.p = (char *)g.stage_img;
+	}
+
+	auto pyramid = [&](bool results, int levels) {
+		IlPyramid py;
+		py.J = levels;
+		for (int j = 1; j < levels; j++) {
+			py.p[j] = results ? L[j].b : L[j].a;
+			py.pitch[j] = L[j].pitch;
+		}
+		return py;
+	};
+	// rows 1, 3, 5, ... of the transformed region from one image to another
+	auto copy_odd_rows = [&](Img to, Img from) -> int {
+		return copy_rect(Img{to.p + to.sx, to.sx * 2, 4}, 0, 0, Img{from.p + from.sx, from.sx * 2, 4}, 0, 0, six, siy / 2);
+	};
+
+	if (!inverse) {
+		for (int j = 0; j < J; j++) {
+			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
+			const Img out = j == 0 ? (alias ? stage : dst) : dense(L[j].b, L[j]);
+			float *ll = j + 1 < J ? L[j + 1].a : nullptr;
+			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0))
+				return 1;
+		}
+		if (J == 1)
+			return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
+		// the even rows receive the samples of the levels >= 1 in ONE pass (in place that pass
+		// also brings them back from the staging image; the odd rows are final after level 0)
+		if (alias && copy_odd_rows(dst, stage))
+			return 1;
+		const Img base = alias ? stage : dst;
+		hipError_t e = launch_il_compose((const float *)base.p, base.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream);
+		if (e != hipSuccess)
+			return fail("interleaved compose failed: %s", hipGetErrorString(e));
+		return 0;
+	}
+	// inverse: the coefficients are read from the source image (never modified before the last
+	// sweep has read it, so out of place needs no copy)
+	const Img cin = src;
+	if (J == 1) {
+		if (!alias)
+			return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0);
+		if (il_level(w, true, scale_single, dst, stage, L[0].lx, L[0].ly, nullptr, 0))
+			return 1;
+		return copy_rect(dst, 0, 0, stage, 0, 0, six, siy);
+	}
+	hipError_t e = launch_il_decompose((const float *)cin.p, cin.sx / 4, six, siy, pyramid(false, J), g.stream);
+	if (e != hipSuccess)
+		return fail("interleaved decompose failed: %s", hipGetErrorString(e));
+	for (int j = J - 1; j >= 1; j--) {
+		if (il_level(w, true, scale_single, dense(L[j].a, L[j]), dense(L[j].b, L[j]), L[j].lx, L[j].ly, nullptr, 0))
+			return 1;
+		// the reconstructed low-pass band is the even-even lattice of the level above
+		if (j >= 2 && scatter(L[j].b, L[j].pitch, (char *)L[j - 1].a, L[j - 1].pitch * 4, 2, L[j]))
+			return 1;
+	}
+	// level 0.  Out of place (fused sweep): odd rows straight from the coefficient image, even
+	// rows from a packed copy that carries the reconstructed LL band (one compose pass).  In
+	// place the sweep must not read what it overwrites: its whole input is built in the staging
+	// image (odd rows copied, even rows composed) and the sweep writes the caller's image.
+	const bool split = !alias && !g.force_generic && L[0].lx >= 2 && L[0].ly >= 2;
+	if (split) {
+		const Img even{stage.p, stage.sx, 4}; // (siy+1)/2 packed rows
+		e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)even.p, even.sx / 4, six, siy, pyramid(true, 2), g.stream, true);
+		if (e != hipSuccess)
+			return fail("interleaved compose failed: %s", hipGetErrorString(e));
+		return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0, &even);
+	}
+	if (copy_odd_rows(stage, cin))
+		return 1;
+	e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)stage.p, stage.sx / 4, six, siy, pyramid(true, 2), g.stream);
+	if (e != hipSuccess)
+		return fail("interleaved compose failed: %s", hipGetErrorString(e));
+	return il_level(w, true, scale_single, stage, dst, L[0].lx, L[0].ly, nullptr, 0);
+}
+
+int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const void *src, void *dst, int stride_x, int stride_y,
+	int sox, int soy, int six, int siy, int *j, int decompose_one)
+{
+	if (check_inited())
+		return 1;
+	if (wavelet != kCdf97S && wavelet != kCdf53S)
+		return fail("the interleaved layout takes the float wavelets (CDF 9/7, CDF 5/3), not %d", wavelet);
+	if (flavour != 0 && flavour != 1)
+		return fail("unknown flavour %d", flavour);
+	if (flavour == 1 && inverse)
+		return fail("dwt-simple.h has forward transforms only; use flavour 0 for the inverse");
+	if (!src || !dst || !j)
+		return fail("null pointer argument");
+	if (sox <= 0 || soy <= 0 || six < 0 || siy < 0 || six > sox || siy > soy)
+		return fail("bad sizes: outer %dx%d inner %dx%d", sox, soy, six, siy);
+	g_elems_are_32bit = true;
+	// single-sample lines: the 9/7 drivers and fdwt2_* leave them (guards `size > 1`,
+	// libdwt.c:12978, dwt-simple.c:2266), the 5/3 _inplace_ drivers scale them (:11041, :11840)
+	const bool scale_single = wavelet == kCdf53S && flavour == 0;
+	const Wavelet w = wavelet == kCdf97S ? ((g.fma && !inverse) ? kCdf97SFma : kCdf97S) : (flavour == 1 ? kCdf53SNew : kCdf53S);
+	const bool dev_src = dwt_hip_is_device_pointer(src), dev_dst = dwt_hip_is_device_pointer(dst);
+	if (dev_src != dev_dst)
+		return fail("src and dst must both be host or both be device pointers");
+	if (dev_dst) {
+		if (stride_y != 4 || (stride_x % 4) || stride_x < sox * 4)
+			return fail("device images need stride_y == 4 and stride_x a multiple of it >= width*4 (got %d, %d)", stride_x, stride_y);
+		return interleaved2d(w, inverse != 0, scale_single, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
+	}
+	// host pointers: stage the outer frame through HBM (any byte strides)
+	const long pitch = align_up((long)sox * 4, 256);
+	if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * soy))
+		return 1;
+	if (host_upload(src, stride_x, stride_y, 4, sox, soy, g.host_a, pitch))
+		return 1;
+	Img A{(char *)g.host_a, pitch, 4};
+	if (interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one))
+		return 1;
+	return host_download(dst, stride_x, stride_y, 4, sox, soy, g.host_a, pitch);
+}
+
+} // extern "C"
+#pragma GCC visibility pop

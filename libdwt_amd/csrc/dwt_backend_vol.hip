@@ -1,0 +1,210 @@
+// dwt_backend_vol.hip -- the 3-D entries: out of place (fused one-pass levels) and in place
+// (two passes per level), multi-level over dense per-level volumes.
+#include "dwt_backend.h"
+
+using namespace dwtb;
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+
+// Forward 3-D transform, OUT OF PLACE: the layout and arithmetic of cdf97_3f_op_sep_horizontal_s
+// (src/volume-dwt.c:727-785: copy each x line to the destination, then lift x, y, z there), the
+// entry the reference's own 3-D perf test drives (volume_perftest_fwd97op_s, src/volume.c).
+// Level j reads a dense volume and writes a dense volume, so each level is ONE fused pass
+// (k_vol_fwd_fused) where that kernel applies and the two-pass path (xy sweep, z sweep through
+// the scratch volume) elsewhere; the even-even-even samples go to the next level densely, and the
+// results of the levels >= 1 are scattered into their lattices at the end (deepest first).
+int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
+{
+	if (check_inited())
+		return 1;
+	if (!src || !dst || !dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
+		return fail("dwt_hip_transform3d_op takes device pointers");
+	if (src == dst)
+		return fail("dwt_hip_transform3d_op is out of place; use dwt_hip_transform3d for in-place volumes");
+	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
+		return fail("bad volume strides");
+	constexpr int kMaxLevels = 24;
+	if (levels > kMaxLevels)
+		return fail("too many levels");
+	if (levels >= 1 && (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2))
+		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
+	const long vsy = (long)stride_y / 4, vsz = (long)stride_z / 4;
+	if (levels < 1) {
+		// no levels: the reference's copy stage alone
+		hipError_t e = launch_lattice_copy((const float *)src, 1, vsy, vsz, (float *)dst, 1, vsy, vsz, nx, ny, nz, g.stream);
+		return e == hipSuccess ? 0 : fail("volume copy failed: %s", hipGetErrorString(e));
+	}
+	struct Lvl { const float *in; float *out; long sy, sz; int lx, ly, lz; } L[kMaxLevels];
+	L[0] = {(const float *)src, (float *)dst, vsy, vsz, nx, ny, nz};
+	size_t pool = 0;
+	for (int j = 1; j < levels; j++) {
+		L[j].lx = ceil_div_pow2(nx, j); L[j].ly = ceil_div_pow2(ny, j); L[j].lz = ceil_div_pow2(nz, j);
+		L[j].sy = align_up(L[j].lx, 4);
+		L[j].sz = L[j].sy * L[j].ly;
+		pool += (size_t)L[j].sz * L[j].lz;
+	}
+	if (levels > 1) {
+		if (grow(&g.host_a, &g.host_a_bytes, pool * 4) || grow(&g.host_b, &g.host_b_bytes, pool * 4))
+			return 1;
+		float *pa = (float *)g.host_a, *pb = (float *)g.host_b;
+		for (int j = 1; j < levels; j++) {
+			L[j].in = pa; L[j].out = pb;
+			pa += (size_t)L[j].sz * L[j].lz;
+			pb += (size_t)L[j].sz * L[j].lz;
+		}
+	}
+	for (int j = 0; j < levels; j++)
+		if (L[j].lz > 65535 || L[j].ly > 65535)
+			return fail("volume too large for the launch grid");
+	float *S = nullptr;
+	long s_sy = 0, s_sz = 0;
+	for (int j = 0; j < levels; j++) {
+		const Lvl &b = L[j];
+		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;
+		const long lsy = j + 1 < levels ? L[j + 1].sy : 0, lsz = j + 1 < levels ? L[j + 1].sz : 0;
+		VolFusedArgs fa{b.in, b.sy, b.sz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
+		const bool can_fuse = fa.in != fa.out && fa.nx >= 2 && fa.ny >= 2 && fa.nz >= 2;
+		if (!g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(fa)) || (g.vol.fused >= 2 && can_fuse))) {
+			prof_before(j);
+			hipError_t e = launch_vol_fwd_fused(fa, g.vol, g.stream);
+			prof_after(j);
+			if (e != hipSuccess)
+				return fail("fused 3-D level launch failed: %s", hipGetErrorString(e));
+			continue;
+		}
+		// two passes through the scratch volume
+		if (!S) {
+			s_sy = align_up(nx, 4);
+			s_sz = s_sy * ny;
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
+				return 1;
+			S = (float *)g.stage_img;
+		}
+		FwdLevelArgs a;
+		a.in = b.in; a.in_pitch = b.sy; a.in_bstride = b.sz;
+		a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
+		a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
+		a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
+		hipError_t e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
+		if (e != hipSuccess)
+			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
+		e = launch_vol_z(false, S, s_sy, s_sz, b.out, b.sy, b.sz, b.lx, b.ly, b.lz, g.vol, g.stream, lll, lsy, lsz);
+		if (e != hipSuccess)
+			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
+	}
+	for (int j = levels - 1; j >= 1; j--) {
+		const Lvl &c = L[j], &par = L[j - 1];
+		hipError_t e = launch_lattice_copy(c.out, 1, c.sy, c.sz, par.out, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice scatter failed: %s", hipGetErrorString(e));
+	}
+	return 0;
+}
+
+int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
+{
+	if (check_inited())
+		return 1;
+	if (!vol || !dwt_hip_is_device_pointer(vol))
+		return fail("dwt_hip_transform3d takes a device pointer");
+	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
+		return fail("bad volume strides");
+	if (levels < 1)
+		return 0;
+	// every level needs at least 2 samples per axis (the reference asserts >= 5, dwt-simple.c:2172)
+	if (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2)
+		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
+	// scratch: S (pass-to-pass buffer) and, for levels >= 1, dense copies P[j] of the
+	// level-j lattice (even-even-even samples of level j-1), all carved from one buffer
+	const long s_sy = align_up(nx, 4), s_sz = s_sy * ny;
+	if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
+		return 1;
+	float *S = (float *)g.stage_img;
+	constexpr int kMaxLevels = 24;
+	if (levels > kMaxLevels)
+		return fail("too many levels");
+	struct Lvl { float *p; long sy, sz; int lx, ly, lz; } L[kMaxLevels];
+	L[0] = {(float *)vol, (long)stride_y / 4, (long)stride_z / 4, nx, ny, nz};
+	size_t p_total = 0;
+	for (int j = 1; j < levels; j++) {
+		L[j].lx = ceil_div_pow2(nx, j); L[j].ly = ceil_div_pow2(ny, j); L[j].lz = ceil_div_pow2(nz, j);
+		L[j].sy = align_up(L[j].lx, 4);
+		L[j].sz = L[j].sy * L[j].ly;
+		p_total += (size_t)L[j].sz * L[j].lz;
+	}
+	if (levels > 1) {
+		if (grow(&g.host_a, &g.host_a_bytes, p_total * 4))
+			return 1;
+		float *p = (float *)g.host_a;
+		for (int j = 1; j < levels; j++) {
+			L[j].p = p;
+			p += (size_t)L[j].sz * L[j].lz;
+		}
+	}
+	for (int j = 0; j < levels; j++)
+		if (L[j].lz > 65535 || L[j].ly > 65535)
+			return fail("volume too large for the launch grid");
+
+	auto one_level = [&](const Lvl &b, const Lvl *next) -> int {
+		// x then y fused per slice, then z (src/volume-dwt.c:677-725; inverse :1115-1163)
+		hipError_t e;
+		if (!inverse) {
+			FwdLevelArgs a;
+			a.in = b.p; a.in_pitch = b.sy; a.in_bstride = b.sz;
+			a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
+			a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
+			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
+			e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
+		} else {
+			InvLevelArgs a;
+			a.in_ll = b.p; a.ll_pitch = 2 * b.sy; a.ll_bstride = b.sz;
+			a.in_h = b.p + b.sy; a.h_pitch = 2 * b.sy; a.h_bstride = b.sz;
+			a.out = S; a.out_pitch = s_sy; a.out_bstride = s_sz;
+			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
+			e = launch_inv_level(kCdf97S, a, g.tune, g.stream);
+		}
+		if (e != hipSuccess)
+			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
+		// forward: the z pass also writes the next level's input densely (no lattice gather)
+		e = launch_vol_z(inverse != 0, S, s_sy, s_sz, b.p, b.sy, b.sz, b.lx, b.ly, b.lz, g.vol, g.stream,
+			next ? next->p : nullptr, next ? next->sy : 0, next ? next->sz : 0);
+		if (e != hipSuccess)
+			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
+		return 0;
+	};
+	// level j lives on the stride-2 lattice (even-even-even samples) of level j-1
+	auto lattice = [&](int j, bool pack) -> int {
+		const Lvl &c = L[j], &par = L[j - 1];
+		hipError_t e = pack
+			? launch_lattice_copy(par.p, 2, par.sy * 2, par.sz * 2, c.p, 1, c.sy, c.sz, c.lx, c.ly, c.lz, g.stream)
+			: launch_lattice_copy(c.p, 1, c.sy, c.sz, par.p, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice %s failed: %s", pack ? "pack" : "unpack", hipGetErrorString(e));
+		return 0;
+	};
+
+	if (!inverse) {
+		for (int j = 0; j < levels; j++)
+			if (one_level(L[j], j + 1 < levels ? &L[j + 1] : nullptr))
+				return 1;
+		for (int j = levels - 1; j >= 1; j--)
+			if (lattice(j, false))
+				return 1;
+	} else {
+		for (int j = 1; j < levels; j++)
+			if (lattice(j, true))
+				return 1;
+		for (int j = levels - 1; j >= 0; j--) {
+			if (one_level(L[j], nullptr))
+				return 1;
+			if (j >= 1 && lattice(j, false))
+				return 1;
+		}
+	}
+	return 0;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

@@ -14,6 +14,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 dwt.dwt_util_init(); dwt.use_torch_stream()
 t_end = time.time() + secs
+t_report = time.time() + 30
 n_cases = bad = 0
 def rand_dim():
     r = rng.random()
@@ -134,6 +135,9 @@ while time.time() < t_end:
                 ok = ok and (r[:, :w_] - a[:, :w_]).abs().max().item() < 1e-3
             desc = f"interleaved {wav} flavour {flav} {h_}x{w_} pitch {pitch} J={J} d1={d1} inplace={inplace}"
     n_cases += 1
+    if time.time() > t_report:
+        print(f"... {n_cases} cases, {bad} mismatches", flush=True)
+        t_report = time.time() + 30
     if not ok:
         bad += 1
         print("MISMATCH:", desc, flush=True)

@@ -15,8 +15,7 @@
  * Element (y, x) lives at ptr + y*stride_x + x*stride_y (bytes).  `*j_max_ptr` < 0 or
  * beyond the limit asks for the full depth and receives the level count.  The inverse is
  * libdwt.h's dwt_cdf97_2i_inplace_s / dwt_cdf53_2i_inplace_s, as in
- * examples/simple-newapi/simple.c.  The 1-D and EAW entries of the reference header are
- * not part of the 2-D hot path and are not provided.
+ * examples/simple-newapi/simple.c.
  */
 #ifndef DWT_SIMPLE_H
 #define DWT_SIMPLE_H
@@ -31,6 +30,17 @@ void fdwt2_cdf97_diagonal_s(void *ptr, int size_x, int size_y, int stride_x, int
 void fdwt2_cdf53_horizontal_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
 void fdwt2_cdf53_vertical_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
 void fdwt2_cdf53_diagonal_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
+
+/* The complete 1-D transforms of the header (src/dwt-simple.h:78-100; src/dwt-simple.c:2059,
+ * 2118, 2166, 2195): one strided line, interleaved in place; `stride` is the element pitch in
+ * bytes.  They run through the same device path as a one-row image (bit-identical); kept for
+ * source compatibility -- a single line is PCIe-latency bound, not a GPU workload.  The partial
+ * building blocks of the header (fdwt_cdf97_horizontal_s etc., which are cores without their
+ * prolog / epilog) and the EAW entries are not provided. */
+void fdwt1_cdf97_horizontal_s(void *ptr, int size, int stride, int *j_max_ptr);
+void fdwt1_single_cdf97_horizontal_s(void *ptr, int size, int stride);
+void fdwt1_single_cdf97_horizontal_min5_s(void *ptr, int size, int stride);
+void fdwt1_single_cdf97_vertical_min5_s(void *ptr, int size, int stride);
 
 #ifdef __cplusplus
 }

@@ -167,6 +167,28 @@ DWT_NEWAPI(fdwt2_cdf53_vertical_s, DWT_HIP_CDF53_S)
 DWT_NEWAPI(fdwt2_cdf53_diagonal_s, DWT_HIP_CDF53_S)
 #undef DWT_NEWAPI
 
+/* 1-D: a line is a one-row image (src/dwt-simple.c:2059, 2118, 2166, 2195) */
+void fdwt1_cdf97_horizontal_s(void *ptr, int size, int stride, int *j_max_ptr)
+{
+	run_il(DWT_HIP_CDF97_S, 0, 1, ptr, stride * size, stride, size, 1, size, 1, j_max_ptr, 1, __func__);
+}
+
+void fdwt1_single_cdf97_horizontal_s(void *ptr, int size, int stride)
+{
+	int j = 1;
+	run_il(DWT_HIP_CDF97_S, 0, 1, ptr, stride * size, stride, size, 1, size, 1, &j, 1, __func__);
+}
+
+void fdwt1_single_cdf97_horizontal_min5_s(void *ptr, int size, int stride)
+{
+	fdwt1_single_cdf97_horizontal_s(ptr, size, stride);
+}
+
+void fdwt1_single_cdf97_vertical_min5_s(void *ptr, int size, int stride)
+{
+	fdwt1_single_cdf97_horizontal_s(ptr, size, stride);
+}
+
 /* src/libdwt.c:19158: platform bring-up.  The reference loads accelerator firmware
  * on ASVP and does nothing on x86; here the device context is created. */
 void dwt_util_init(void)

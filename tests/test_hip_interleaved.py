@@ -252,3 +252,33 @@ def test_errors(dwt):
         dwt.transform2d_interleaved("cdf97_s", 1, 1, a, a, 32, 4, 8, 8)
     with pytest.raises(dwt.DwtError):
         dwt.transform2d_interleaved("cdf97_s", 0, 0, a, a, 32, 4, 8, 8, 9, 8)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 37, 100, 1001, 4096])
+@pytest.mark.parametrize("stride", [4, 12])
+def test_one_dimensional_entries(dwt, oracle, n, stride):
+    """dwt-simple.h's complete 1-D transforms (fdwt1_*): a strided line through the device path of a
+    one-row image; bit-identical to the reference (oracle pinned in tests/test_oracle_interleaved.py)."""
+    import ctypes as C
+
+    L = dwt.lib
+    L.fdwt1_cdf97_horizontal_s.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.fdwt1_single_cdf97_horizontal_s.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(n * 5 + stride)
+    for jreq in (-1, 1, 3):
+        a = rng.random(n * stride // 4 + 4, dtype=np.float32)
+        got, want = a.copy(), a.copy()
+        jg = C.c_int(jreq)
+        L.fdwt1_cdf97_horizontal_s(got.ctypes.data, n, stride, C.byref(jg))
+        view = np.lib.stride_tricks.as_strided(want, shape=(1, n), strides=(stride * n + 64, stride))
+        jw = C.c_int(jreq)
+        oracle.lib.oracle_fdwt2_cdf97_s.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+        oracle.lib.oracle_fdwt2_cdf97_s(want.ctypes.data, n, 1, stride * n + 64, stride, C.byref(jw), 1)
+        assert jg.value == jw.value
+        assert np.array_equal(bits(got), bits(want)), (n, stride, jreq)
+    a = rng.random(n * stride // 4 + 4, dtype=np.float32)
+    got, want = a.copy(), a.copy()
+    L.fdwt1_single_cdf97_horizontal_s(got.ctypes.data, n, stride)
+    jw = C.c_int(1)
+    oracle.lib.oracle_fdwt2_cdf97_s(want.ctypes.data, n, 1, stride * n + 64, stride, C.byref(jw), 1)
+    assert np.array_equal(bits(got), bits(want))

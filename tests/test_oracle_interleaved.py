@@ -84,3 +84,30 @@ def test_oracle_bitwise_equals_reference_interleaved(oracle, reference, shape, d
         reference.inv(f"{wv}_2i_inplace_s", b, jr, decompose_one=d1)
         oracle.inv(f"{wv}_2i_inplace_s", c, jr, decompose_one=d1)
         assert np.array_equal(bits(b), bits(c)), wv
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 9, 37, 100, 257])
+def test_one_dimensional_entries_equal_the_one_row_image(oracle, reference, n):
+    """fdwt1_cdf97_horizontal_s / fdwt1_single_cdf97_horizontal_s (src/dwt-simple.c:2059, 2118) are the
+    2-D driver on a one-row image with decompose_one: what the device entries rely on."""
+    import ctypes as C
+
+    R, O = reference.lib, oracle.lib
+    R.fdwt1_cdf97_horizontal_s.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    R.fdwt1_single_cdf97_horizontal_s.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    O.oracle_fdwt2_cdf97_s.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    rng = np.random.default_rng(n)
+    for stride in (4, 12):
+        for jreq in (-1, 1, 2, 5):
+            a = rng.random(n * stride // 4 + 4, dtype=np.float32)
+            b, c = a.copy(), a.copy()
+            j1, j2 = C.c_int(jreq), C.c_int(jreq)
+            R.fdwt1_cdf97_horizontal_s(b.ctypes.data, n, stride, C.byref(j1))
+            O.oracle_fdwt2_cdf97_s(c.ctypes.data, n, 1, stride * n + 64, stride, C.byref(j2), 1)
+            assert j1.value == j2.value and np.array_equal(bits(b), bits(c))
+        a = rng.random(n * 3 + 4, dtype=np.float32)
+        b, c = a.copy(), a.copy()
+        R.fdwt1_single_cdf97_horizontal_s(b.ctypes.data, n, 12)
+        j2 = C.c_int(1)
+        O.oracle_fdwt2_cdf97_s(c.ctypes.data, n, 1, 12 * n + 64, 12, C.byref(j2), 1)
+        assert np.array_equal(bits(b), bits(c))

@@ -195,14 +195,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")  # RCCL on ROCm; used for the barrier and the max-reduce only
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libdwt_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     os.environ["DWT_HIP_DEVICE"] = str(local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL on ROCm, bound to this rank's GPU; used for the barrier and the max-reduce only
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import libdwt_amd as dwt
 

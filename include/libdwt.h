@@ -108,6 +108,16 @@ void dwt_cdf53_2f_inplace_s(void *ptr, int stride_x, int stride_y,
 void dwt_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
 	int j_max, int decompose_one, int zero_padding);
+/* fixed-point int32 CDF 9/7, interleaved in place (src/libdwt.h:1035, 1017).  As in the reference
+ * the strides are not scaled per level: above one level the dense top-left block is transformed
+ * again (src/libdwt.c:17423 "tested only with j=1"); bit-identical, forward + inverse restore
+ * the image exactly for any level count. */
+void dwt_cdf97_2f_inplace_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one, int zero_padding);
+void dwt_cdf97_2i_inplace_i(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int j_max, int decompose_one, int zero_padding);
 /* the reference's other CPU schedules of the same forward transform (identical bits):
  * src/libdwt.h:612, 625, 649 */
 void dwt_cdf97_2f_inplace_sep_s(void *ptr, int stride_x, int stride_y,

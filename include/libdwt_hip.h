@@ -78,7 +78,8 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 
 /* 2-D transforms in the INTERLEAVED (in-place lifting) layout: no de-interleave, level j
  * works on the stride-2^j lattice of the image (even lattice index = low-pass).
- * `wavelet` is DWT_HIP_CDF97_S or DWT_HIP_CDF53_S.  `flavour` 0 = libdwt.h's
+ * `wavelet` is DWT_HIP_CDF97_S or DWT_HIP_CDF53_S (and, flavour 0 only, DWT_HIP_CDF97_I for
+ * dwt_cdf97_2f_inplace_i / dwt_cdf97_2i_inplace_i, src/libdwt.c:17424, 17308).  `flavour` 0 = libdwt.h's
  * dwt_cdf97_2f_inplace_s / dwt_cdf97_2i_inplace_s / dwt_cdf53_2f_inplace_s /
  * dwt_cdf53_2i_inplace_s (src/libdwt.c:12926, 17474, 16553, 17886); flavour 1 =
  * dwt-simple.h's forward fdwt2_cdf97_* / fdwt2_cdf53_* (src/dwt-simple.c:2224, 2356).

@@ -346,6 +346,20 @@ def dwt_cdf53_2i_inplace_s(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, 
                             size_i_big_x, size_i_big_y, j_max, decompose_one)
 
 
+def dwt_cdf97_2f_inplace_i(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                           j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:17424 (fixed-point int 9/7, interleaved).  Returns the level count."""
+    return transform2d_interleaved(CDF97_I, 0, 0, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y,
+                                   size_i_big_x, size_i_big_y, j_max, decompose_one)
+
+
+def dwt_cdf97_2i_inplace_i(ptr, stride_x, stride_y, size_o_big_x, size_o_big_y, size_i_big_x, size_i_big_y,
+                           j_max=-1, decompose_one=0, zero_padding=0):
+    """src/libdwt.c:17308"""
+    transform2d_interleaved(CDF97_I, 1, 0, ptr, ptr, stride_x, stride_y, size_o_big_x, size_o_big_y,
+                            size_i_big_x, size_i_big_y, j_max, decompose_one)
+
+
 def _newapi(wavelet):
     def f(ptr, size_x, size_y, stride_x, stride_y, j_max=-1, decompose_one=0):
         return transform2d_interleaved(wavelet, 0, 1, ptr, ptr, stride_x, stride_y, size_x, size_y, size_x, size_y,

@@ -302,13 +302,46 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 	return il_level(w, true, scale_single, stage, dst, L[0].lx, L[0].ly, nullptr, 0);
 }
 
+// dwt_cdf97_2f_inplace_i / dwt_cdf97_2i_inplace_i (src/libdwt.c:17424, :17308): fixed-point int
+// 9/7, interleaved, exactly as the reference runs them -- the strides are NOT scaled per level,
+// so level j re-transforms the dense top-left ceil(size/2^j) block of the interleaved image (the
+// reference marks the pair "tested only with j=1", :17423).  Exact line passes; forward rows then
+// columns, inverse columns then rows.
+static int inplace_int2d(bool inverse, Img src, Img dst, int sox, int soy, int six, int siy, int *jp, int decompose_one)
+{
+	const int j_limit = ceil_log2(decompose_one ? (sox > soy ? sox : soy) : (sox < soy ? sox : soy));
+	int J = *jp;
+	if (J < 0 || J > j_limit)
+		J = j_limit;
+	if (!inverse)
+		*jp = J;
+	if (side_join())
+		return 1;
+	if (src.p != dst.p && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))
+		return 1;
+	for (int step = 0; step < J; step++) {
+		const int j = inverse ? J - 1 - step : step;
+		const int nx = ceil_div_pow2(six, j), ny = ceil_div_pow2(siy, j);
+		for (int pass = 0; pass < 2; pass++) {
+			const bool rows = inverse ? pass == 1 : pass == 0;
+			const int N = rows ? nx : ny, lines = rows ? ny : nx;
+			if (N < 2 || lines < 1)
+				continue; // the line kernels leave shorter lines alone (:17365, :17246)
+			if (generic_pass(kCdf97IIp, inverse, rows, dst, dst, nx, ny, lines, N, -1))
+				return 1;
+		}
+	}
+	return 0;
+}
+
 int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const void *src, void *dst, int stride_x, int stride_y,
 	int sox, int soy, int six, int siy, int *j, int decompose_one)
 {
 	if (check_inited())
 		return 1;
-	if (wavelet != kCdf97S && wavelet != kCdf53S)
-		return fail("the interleaved layout takes the float wavelets (CDF 9/7, CDF 5/3), not %d", wavelet);
+	const bool fixed = wavelet == kCdf97I && flavour == 0;
+	if (wavelet != kCdf97S && wavelet != kCdf53S && !fixed)
+		return fail("the interleaved layout takes float CDF 9/7, float CDF 5/3 and (libdwt.h entries) fixed-point int CDF 9/7, not %d", wavelet);
 	if (flavour != 0 && flavour != 1)
 		return fail("unknown flavour %d", flavour);
 	if (flavour == 1 && inverse)
@@ -328,6 +361,8 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 	if (dev_dst) {
 		if (stride_y != 4 || (stride_x % 4) || stride_x < sox * 4)
 			return fail("device images need stride_y == 4 and stride_x a multiple of it >= width*4 (got %d, %d)", stride_x, stride_y);
+		if (fixed)
+			return inplace_int2d(inverse != 0, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
 		return interleaved2d(w, inverse != 0, scale_single, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
 	}
 	// host pointers: stage the outer frame through HBM (any byte strides)
@@ -337,7 +372,8 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 	if (host_upload(src, stride_x, stride_y, 4, sox, soy, g.host_a, pitch))
 		return 1;
 	Img A{(char *)g.host_a, pitch, 4};
-	if (interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one))
+	if (fixed ? inplace_int2d(inverse != 0, A, A, sox, soy, six, siy, j, decompose_one)
+	          : interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one))
 		return 1;
 	return host_download(dst, stride_x, stride_y, 4, sox, soy, g.host_a, pitch);
 }

@@ -152,6 +152,21 @@ void dwt_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int 
 	run_il(DWT_HIP_CDF53_S, 1, 0, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, __func__);
 }
 
+/* fixed-point int 9/7, interleaved in place: src/libdwt.c:17424, :17308 */
+void dwt_cdf97_2f_inplace_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	run_il(DWT_HIP_CDF97_I, 0, 0, ptr, stride_x, stride_y, sox, soy, six, siy, j_max_ptr, decompose_one, __func__);
+}
+
+void dwt_cdf97_2i_inplace_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	run_il(DWT_HIP_CDF97_I, 1, 0, ptr, stride_x, stride_y, sox, soy, six, siy, &j_max, decompose_one, __func__);
+}
+
 /* dwt-simple.h: src/dwt-simple.c:2224 / :1615 / :3034 and :2356 / :1927 / :3166 -- three
  * CPU schedules per wavelet with identical results, one device path here */
 #define DWT_NEWAPI(name, wavelet)                                                                      \

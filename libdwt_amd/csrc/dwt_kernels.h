@@ -8,7 +8,8 @@ namespace dwt {
 
 enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2, kCdf97D = 3, kCdf53D = 4, kCdf97I = 5,
 	kCdf97SFma = 6 /* internal: float 9/7 with contracted steps, option "fma" */,
-	kCdf53SNew = 7 /* internal: float 5/3 of dwt-simple.c (odd scale 1/zeta in float), interleaved layout only */ };
+	kCdf53SNew = 7 /* internal: float 5/3 of dwt-simple.c (odd scale 1/zeta in float), interleaved layout only */,
+	kCdf97IIp = 8 /* internal: fixed-point int 9/7 of the interleaved in-place drivers (rounded terms added) */ };
 
 inline int elem_size(Wavelet w) { return (w == kCdf97D || w == kCdf53D) ? 8 : 4; }
 

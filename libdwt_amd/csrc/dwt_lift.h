@@ -106,6 +106,26 @@ struct Cdf97I {
 	static __device__ __forceinline__ T inv_single(T v) { return v; }
 };
 
+// The interleaved in-place int 9/7 drivers (src/libdwt.c:17356-17422 forward, :17237-17306
+// inverse) ADD the rounded terms where the Mallat int kernels subtract them:
+// (-203*s + 64) >> 7 is not -((203*s - 64) >> 7) in floor arithmetic.
+struct Cdf97IIp : Cdf97I {
+	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c + ((-203 * (l + r) + (1 << 6)) >> 7)
+		     : s == 1 ? c + ((-217 * (l + r) + (1 << 11)) >> 12)
+		     : s == 2 ? c + ((+113 * (l + r) + (1 << 6)) >> 7)
+		              : c + ((1817 * (l + r) + (1 << 11)) >> 12);
+	}
+	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
+	{
+		return s == 0 ? c - ((1817 * (l + r) + (1 << 11)) >> 12)
+		     : s == 1 ? c - ((+113 * (l + r) + (1 << 6)) >> 7)
+		     : s == 2 ? c - ((-217 * (l + r) + (1 << 11)) >> 12)
+		              : c - ((-203 * (l + r) + (1 << 6)) >> 7);
+	}
+};
+
 struct Cdf53S {
 	using T = float;
 	static constexpr int K = 2;

@@ -114,6 +114,7 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 	case kCdf53D: return line_pass_t<Cdf53D>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf97I: return line_pass_t<Cdf97I>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf53SNew: return line_pass_t<Cdf53SNew>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
+	case kCdf97IIp: return line_pass_t<Cdf97IIp>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf97SFma: break; // the contracted variant exists for the fused sweeps only
 	}
 	return hipErrorInvalidValue;

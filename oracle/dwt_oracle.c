@@ -945,6 +945,68 @@ void oracle_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, i
 	il_inverse(ptr, stride_x, stride_y, sox, soy, six, siy, j_max, decompose_one, &IL_53_I, 0);
 }
 
+/* ---- fixed-point int 9/7, interleaved in place: src/libdwt.c:17424 (forward), :17308 (inverse) ----
+ * The line kernels (:17356-17422, :17237-17306) add the rounded terms instead of subtracting
+ * them as the Mallat int kernels do ((-203*s + 64) >> 7 is not -((203*s - 64) >> 7)), and the
+ * drivers do NOT scale the strides by 2^j: level j re-transforms the dense top-left
+ * ceil(size/2^j) block of the already interleaved image (the reference marks them "tested only
+ * with j=1", :17423).  Restated as they are.  Forward: rows, then columns; inverse: columns,
+ * then rows. */
+static inline int *ii_at(char *line, long stride, int i) { return (int *)(line + (long)i * stride); }
+
+static void ii_step(char *line, long stride, int N, int parity, int mul, int add, int shift, int sign)
+{
+	for (int t = parity; t < N; t += 2) {
+		const int l = *ii_at(line, stride, t == 0 ? 1 : t - 1);
+		const int r = *ii_at(line, stride, t == N - 1 ? N - 2 : t + 1);
+		*ii_at(line, stride, t) += sign * ((mul * (l + r) + add) >> shift);
+	}
+}
+
+static void ii_line(char *line, long stride, int N, int inverse)
+{
+	if (N < 2)
+		return;
+	if (!inverse) {
+		ii_step(line, stride, N, 1, -203, 1 << 6, 7, +1);
+		ii_step(line, stride, N, 0, -217, 1 << 11, 12, +1);
+		ii_step(line, stride, N, 1, +113, 1 << 6, 7, +1);
+		ii_step(line, stride, N, 0, 1817, 1 << 11, 12, +1);
+	} else {
+		ii_step(line, stride, N, 0, 1817, 1 << 11, 12, -1);
+		ii_step(line, stride, N, 1, +113, 1 << 6, 7, -1);
+		ii_step(line, stride, N, 0, -217, 1 << 11, 12, -1);
+		ii_step(line, stride, N, 1, -203, 1 << 6, 7, -1);
+	}
+}
+
+void oracle_cdf97_2f_inplace_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	*j_max_ptr = il_levels(sox, soy, *j_max_ptr, decompose_one);
+	for (int j = 0; j < *j_max_ptr; j++) {
+		const int nx = oracle_ceil_div_pow2(six, j), ny = oracle_ceil_div_pow2(siy, j);
+		for (int y = 0; y < ny; y++)
+			ii_line((char *)ptr + (long)y * stride_x, stride_y, nx, 0);
+		for (int x = 0; x < nx; x++)
+			ii_line((char *)ptr + (long)x * stride_y, stride_x, ny, 0);
+	}
+}
+
+void oracle_cdf97_2i_inplace_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding)
+{
+	(void)zero_padding;
+	for (int j = il_levels(sox, soy, j_max, decompose_one); j > 0; j--) {
+		const int nx = oracle_ceil_div_pow2(six, j - 1), ny = oracle_ceil_div_pow2(siy, j - 1);
+		for (int x = 0; x < nx; x++)
+			ii_line((char *)ptr + (long)x * stride_y, stride_x, ny, 1);
+		for (int y = 0; y < ny; y++)
+			ii_line((char *)ptr + (long)y * stride_x, stride_y, nx, 1);
+	}
+}
+
 /* src/dwt-simple.c:2224 (fdwt2_cdf97_{horizontal,vertical,diagonal}_s) */
 void oracle_fdwt2_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
 {

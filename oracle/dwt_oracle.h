@@ -113,6 +113,10 @@ void oracle_cdf53_2f_inplace_s(void *ptr, int stride_x, int stride_y, int sox, i
 	int *j_max_ptr, int decompose_one, int zero_padding);
 void oracle_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
 	int j_max, int decompose_one, int zero_padding);
+void oracle_cdf97_2f_inplace_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int *j_max_ptr, int decompose_one, int zero_padding); /* src/libdwt.c:17424 */
+void oracle_cdf97_2i_inplace_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
+	int j_max, int decompose_one, int zero_padding);      /* src/libdwt.c:17308 */
 void oracle_fdwt2_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
 void oracle_fdwt2_cdf53_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
 

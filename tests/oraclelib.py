@@ -46,6 +46,8 @@ ENTRIES = {
     "cdf97_2i_inplace_s": (_INV, np.float32),
     "cdf53_2f_inplace_s": (_FWD, np.float32),
     "cdf53_2i_inplace_s": (_INV, np.float32),
+    "cdf97_2f_inplace_i": (_FWD, np.int32),
+    "cdf97_2i_inplace_i": (_INV, np.int32),
 }
 
 # dwt-simple.h entries: (ptr, size_x, size_y, stride_x, stride_y, int *j, decompose_one)

@@ -282,3 +282,32 @@ def test_one_dimensional_entries(dwt, oracle, n, stride):
     jw = C.c_int(1)
     oracle.lib.oracle_fdwt2_cdf97_s(want.ctypes.data, n, 1, stride * n + 64, stride, C.byref(jw), 1)
     assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (37, 53), (64, 5), (1, 17), (17, 1), (100, 100), (256, 192), (2, 2), (700, 900)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("j", [-1, 1, 3])
+def test_fixed_point_int_inplace_entries(dwt, oracle, shape, j):
+    """dwt_cdf97_2f_inplace_i / dwt_cdf97_2i_inplace_i (src/libdwt.c:17424, 17308): bit-exact, the
+    reference's unscaled-stride multi-level behaviour included; host and device pointers."""
+    h, w = shape
+    rng = np.random.default_rng(h * 13 + w + j)
+    a = rng.integers(-32768, 32768, (h, w)).astype(np.int32)
+    d1 = 1 if min(h, w) == 1 else 0
+    want = a.copy()
+    jw = oracle.fwd("cdf97_2f_inplace_i", want, j, decompose_one=d1)
+    got = a.copy()
+    assert dwt.dwt_cdf97_2f_inplace_i(got, got.strides[0], 4, w, h, w, h, j, d1) == jw
+    assert np.array_equal(got, want)
+    dwt.dwt_cdf97_2i_inplace_i(got, got.strides[0], 4, w, h, w, h, jw, d1)
+    assert np.array_equal(got, a), "exact round trip"
+    # device resident, out of place
+    pitch = ((w * 4 + 63) // 64) * 64
+    pad = np.zeros((h, pitch // 4), np.int32)
+    pad[:, :w] = a
+    src = dwt.DeviceImage(h, w, 4, pitch).upload(pad)
+    dst = dwt.DeviceImage(h, w, 4, pitch).upload(np.full_like(pad, 5))
+    assert dwt.transform2d_interleaved("cdf97_i", 0, 0, src.ptr, dst.ptr, pitch, 4, w, h, None, None, j, d1) == jw
+    assert np.array_equal(dst.download(np.int32)[:, :w], want)
+    src.free()
+    dst.free()

@@ -111,3 +111,20 @@ def test_one_dimensional_entries_equal_the_one_row_image(oracle, reference, n):
         j2 = C.c_int(1)
         O.oracle_fdwt2_cdf97_s(c.ctypes.data, n, 1, 12 * n + 64, 12, C.byref(j2), 1)
         assert np.array_equal(bits(b), bits(c))
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (37, 53), (5, 64), (1, 17), (17, 1), (3, 3), (130, 67)])
+@pytest.mark.parametrize("d1", [0, 1])
+def test_fixed_point_int_inplace_oracle_equals_reference(oracle, reference, shape, d1):
+    """src/libdwt.c:17424 / :17308, including what they do above one level (strides not scaled)."""
+    h, w = shape
+    rng = np.random.default_rng(h * 17 + w)
+    a = rng.integers(-32768, 32768, (h, w)).astype(np.int32)
+    for j in (-1, 1, 2, 4):
+        b, c = a.copy(), a.copy()
+        jr = reference.fwd("cdf97_2f_inplace_i", b, j, decompose_one=d1)
+        assert jr == oracle.fwd("cdf97_2f_inplace_i", c, j, decompose_one=d1)
+        assert np.array_equal(b, c)
+        reference.inv("cdf97_2i_inplace_i", b, jr, decompose_one=d1)
+        oracle.inv("cdf97_2i_inplace_i", c, jr, decompose_one=d1)
+        assert np.array_equal(b, c) and np.array_equal(c, a)

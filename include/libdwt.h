@@ -108,6 +108,10 @@ void dwt_cdf53_2f_inplace_s(void *ptr, int stride_x, int stride_y,
 void dwt_cdf53_2i_inplace_s(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
 	int j_max, int decompose_one, int zero_padding);
+/* level count only, no transform (src/libdwt.h:779, src/libdwt.c:16780) */
+void dwt_cdf53_2f_dummy_s(void *ptr, int stride_x, int stride_y,
+	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
+	int *j_max_ptr, int decompose_one);
 /* fixed-point int32 CDF 9/7, interleaved in place (src/libdwt.h:1035, 1017).  As in the reference
  * the strides are not scaled per level: above one level the dense top-left block is transformed
  * again (src/libdwt.c:17423 "tested only with j=1"); bit-identical, forward + inverse restore

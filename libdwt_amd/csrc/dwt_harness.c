@@ -390,3 +390,17 @@ int *dwt_util_addr_coeff_i(void *ptr, int y, int x, int stride_x, int stride_y)
 {
 	return (int *)((char *)ptr + (long)y * stride_x + (long)x * stride_y);
 }
+
+/* src/libdwt.c:16780-16799: computes the level count a transform would use and nothing else */
+void dwt_cdf53_2f_dummy_s(void *ptr, int stride_x, int stride_y, int size_o_big_x, int size_o_big_y,
+	int size_i_big_x, int size_i_big_y, int *j_max_ptr, int decompose_one)
+{
+	(void)ptr; (void)stride_x; (void)stride_y; (void)size_i_big_x; (void)size_i_big_y;
+	const int lo = size_o_big_x < size_o_big_y ? size_o_big_x : size_o_big_y;
+	const int hi = size_o_big_x > size_o_big_y ? size_o_big_x : size_o_big_y;
+	int j_limit = 0;
+	while (j_limit < 31 && (1 << j_limit) < (decompose_one ? hi : lo))
+		j_limit++;
+	if (*j_max_ptr < 0 || *j_max_ptr > j_limit)
+		*j_max_ptr = j_limit;
+}

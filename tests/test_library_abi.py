@@ -220,3 +220,19 @@ def test_pgm_and_mat_io_match_reference(dwt, reference, tmp_path):
     badm = tmp_path / "bad.mat"
     badm.write_text("1,2\nx,3\n")
     assert _load(dwt.lib, "dwt_util_load_from_mat_s", str(badm), np.float32, mat=True)[0] == 2
+
+
+def test_dummy_driver_level_count(dwt, reference):
+    """dwt_cdf53_2f_dummy_s (src/libdwt.c:16780): the level clamp every driver applies."""
+    import ctypes as C
+    sig = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    for lib in (dwt.lib, reference.lib):
+        lib.dwt_cdf53_2f_dummy_s.argtypes = sig
+        lib.dwt_cdf53_2f_dummy_s.restype = None
+    for (w, h) in [(1, 1), (2, 2), (512, 300), (37, 1000), (8192, 8192)]:
+        for j in (-1, 0, 3, 40):
+            for d1 in (0, 1):
+                a, b = C.c_int(j), C.c_int(j)
+                dwt.lib.dwt_cdf53_2f_dummy_s(None, 0, 0, w, h, w, h, C.byref(a), d1)
+                reference.lib.dwt_cdf53_2f_dummy_s(None, 0, 0, w, h, w, h, C.byref(b), d1)
+                assert a.value == b.value

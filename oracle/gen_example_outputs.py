@@ -21,7 +21,19 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-EXAMPLES = ["simple", "simple-int", "simple-double", "simple-newapi", "subbands"]
+EXAMPLES = ["simple", "simple-int", "simple-double", "simple-newapi", "subbands", "subbands-int", "start", "load", "load-int",
+            "simple-single-loop"]
+# programs that take an input file: a deterministic ASCII PGM written here and, identically, by the GPU test
+NEEDS_INPUT = {"load", "load-int"}
+
+
+def write_input_pgm(path, w=300, h=200):
+    """The input image of examples/load*: libdwt's integer test pattern scaled to 0..255."""
+    with open(path, "w") as f:
+        f.write("P2\n# synthetic input for examples/load\n%d %d\n255\n" % (w, h))
+        for y in range(h):
+            f.write(" ".join(str(255 * (2 * x * y) // (x * x + y * y + 1)) for x in range(w)) + "\n")
+
 
 
 def main():
@@ -35,9 +47,14 @@ def main():
                                    "-L", refdir, "-l:libdwt_ref.so", "-Wl,-rpath," + refdir, "-lm"])
             work = os.path.join(tmp, "run_" + ex)
             os.makedirs(work)
-            text = subprocess.run([exe], cwd=work, capture_output=True, text=True, check=True)
+            argv = [exe]
+            if ex in NEEDS_INPUT:
+                write_input_pgm(os.path.join(work, "input.pgm"))
+                argv.append("input.pgm")
+            text = subprocess.run(argv, cwd=work, capture_output=True, text=True, check=True)
             text = re.sub(r"\x1b\[[0-9;]*m", "", text.stdout + text.stderr)
-            files = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in sorted(glob.glob(os.path.join(work, "*.pgm")))}
+            files = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()
+                     for f in sorted(glob.glob(os.path.join(work, "*.pgm"))) if os.path.basename(f) != "input.pgm"}
             verdicts = [l.split("INFO: ")[-1] for l in text.splitlines() if "success" in l or "differs" in l]
             out[ex] = {"files": files, "verdicts": verdicts}
             print(ex, verdicts, len(files), "files")

@@ -165,6 +165,14 @@ def main():
                     assert jn == m[f"{wv}.j_out"]
                 assert all(np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)) for o in outs[1:])
                 arrays[f"{name}.{wv}.fdwt2"] = outs[0]
+        # fixed-point int 9/7 of the same layout family (src/libdwt.c:17424, 17308), own int input
+        isrc = make_input(ref, kind, np.int32, h, w + pad, w, seed=5000 + idx)
+        arrays[f"{name}.cdf97i.in"] = isrc
+        buf = isrc.copy()
+        m["cdf97i.j_out"] = ref.fwd("cdf97_2f_inplace_i", buf[:, :w], j, size_o=so, size_i=si, decompose_one=d1)
+        arrays[f"{name}.cdf97i.fwd"] = buf.copy()
+        ref.inv("cdf97_2i_inplace_i", buf[:, :w], m["cdf97i.j_out"], size_o=so, size_i=si, decompose_one=d1)
+        arrays[f"{name}.cdf97i.inv"] = buf.copy()
         meta.append(m)
     path = os.path.join(OUT, "interleaved_s.npz")
     np.savez_compressed(path, **arrays)

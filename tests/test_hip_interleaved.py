@@ -311,3 +311,16 @@ def test_fixed_point_int_inplace_entries(dwt, oracle, shape, j):
     assert np.array_equal(dst.download(np.int32)[:, :w], want)
     src.free()
     dst.free()
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_golden_fixed_point_int_inplace_host(dwt, case):
+    """dwt_cdf97_2f_inplace_i / _2i_inplace_i against the reference's own outputs, host-pointer entry."""
+    m, z = case
+    buf = z["cdf97i.in"].copy()
+    (sox, soy), (six, siy) = m["size_o"], m["size_i"]
+    j = dwt.dwt_cdf97_2f_inplace_i(buf, buf.strides[0], 4, sox, soy, six, siy, m["j_in"], m["decompose_one"])
+    assert j == m["cdf97i.j_out"]
+    assert np.array_equal(buf, z["cdf97i.fwd"])
+    dwt.dwt_cdf97_2i_inplace_i(buf, buf.strides[0], 4, sox, soy, six, siy, j, m["decompose_one"])
+    assert np.array_equal(buf, z["cdf97i.inv"])

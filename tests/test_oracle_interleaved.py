@@ -128,3 +128,15 @@ def test_fixed_point_int_inplace_oracle_equals_reference(oracle, reference, shap
         reference.inv("cdf97_2i_inplace_i", b, jr, decompose_one=d1)
         oracle.inv("cdf97_2i_inplace_i", c, jr, decompose_one=d1)
         assert np.array_equal(b, c) and np.array_equal(c, a)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_fixed_point_int_inplace_matches_golden(oracle, case):
+    m, z = case
+    buf = z["cdf97i.in"].copy()
+    so, si = tuple(m["size_o"]), tuple(m["size_i"])
+    j = oracle.fwd("cdf97_2f_inplace_i", _view(m, buf), m["j_in"], size_o=so, size_i=si, decompose_one=m["decompose_one"])
+    assert j == m["cdf97i.j_out"]
+    assert np.array_equal(buf, z["cdf97i.fwd"])
+    oracle.inv("cdf97_2i_inplace_i", _view(m, buf), j, size_o=so, size_i=si, decompose_one=m["decompose_one"])
+    assert np.array_equal(buf, z["cdf97i.inv"]) and np.array_equal(buf, z["cdf97i.in"])

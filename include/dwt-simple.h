@@ -31,6 +31,10 @@ void fdwt2_cdf53_horizontal_s(void *ptr, int size_x, int size_y, int stride_x, i
 void fdwt2_cdf53_vertical_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
 void fdwt2_cdf53_diagonal_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
 
+/* src/dwt-simple.h:127, 138: the rows (h1) or the columns (v1) of every level only; bit-identical */
+void fdwt2h1_cdf97_vertical_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
+void fdwt2v1_cdf97_vertical_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
+
 /* The complete 1-D transforms of the header (src/dwt-simple.h:78-100; src/dwt-simple.c:2059,
  * 2118, 2166, 2195): one strided line, interleaved in place; `stride` is the element pitch in
  * bytes.  They run through the same device path as a one-row image (bit-identical); kept for

@@ -82,7 +82,8 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
  * dwt_cdf97_2f_inplace_i / dwt_cdf97_2i_inplace_i, src/libdwt.c:17424, 17308).  `flavour` 0 = libdwt.h's
  * dwt_cdf97_2f_inplace_s / dwt_cdf97_2i_inplace_s / dwt_cdf53_2f_inplace_s /
  * dwt_cdf53_2i_inplace_s (src/libdwt.c:12926, 17474, 16553, 17886); flavour 1 =
- * dwt-simple.h's forward fdwt2_cdf97_* / fdwt2_cdf53_* (src/dwt-simple.c:2224, 2356).
+ * dwt-simple.h's forward fdwt2_cdf97_* / fdwt2_cdf53_* (src/dwt-simple.c:2224, 2356); flavours
+ * 2 / 3 = fdwt2h1_cdf97_vertical_s / fdwt2v1_cdf97_vertical_s (rows only / columns only, :1747, :1837).
  * Host or device pointers, in place (src == dst) or out of place. */
 int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const void *src, void *dst,
 	int stride_x, int stride_y, int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,

@@ -110,9 +110,10 @@ static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int
 
 // one level on dense images with a common pitch: rows completely, then columns
 static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
-	const Img *even_rows = nullptr)
+	const Img *even_rows = nullptr, int dirs = 3)
 {
-	const bool fused = !g.force_generic && lx >= 2 && ly >= 2 && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
+	// dirs: bit 0 rows, bit 1 columns (fdwt2h1_* / fdwt2v1_* lift one direction only: line passes)
+	const bool fused = dirs == 3 && !g.force_generic && lx >= 2 && ly >= 2 && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
 	if (even_rows && !fused)
 		return fail("internal: split rows need the fused sweep");
 	if (fused) {
@@ -140,7 +141,7 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 	// generic.  The phase-ordered entries reproduce the reference's order exactly when the
 	// generic path was asked for (accel 1); tiny levels of the fused path and the 5/3 _inplace_
 	// pair (rows, then columns in the reference too) take two exact line passes.
-	if (g.force_generic && il_is_phased(w) && !scale_single) {
+	if (dirs == 3 && g.force_generic && il_is_phased(w) && !scale_single) {
 		if (il_level_phased(w, inverse, in, out, lx, ly))
 			return 1;
 		if (ll && !inverse) {
@@ -157,7 +158,7 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 	Img tmp{(char *)g.host_b, in.sx, 4};
 	auto pass = [&](bool rows, Img from, Img to) -> int {
 		const int N = rows ? lx : ly, lines = rows ? ly : lx;
-		if (N == 1 && !scale_single)
+		if ((N == 1 && !scale_single) || !(dirs & (rows ? 1 : 2)))
 			return copy_rect(to, 0, 0, from, 0, 0, lx, ly);
 		hipError_t e = launch_line_pass(w, inverse, from.p, to.p, rows ? from.sx : 4, rows ? 4 : from.sx, lines, N, -1, !rows, g.stream);
 		if (e != hipSuccess)
@@ -175,7 +176,7 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 }
 
 static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
-	int *jp, int decompose_one)
+	int *jp, int decompose_one, int dirs = 3)
 {
 	const int j_limit = ceil_log2(decompose_one ? (sox > soy ? sox : soy) : (sox < soy ? sox : soy));
 	int J = *jp;
@@ -247,7 +248,7 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
 			const Img out = j == 0 ? (alias ? stage : dst) : dense(L[j].b, L[j]);
 			float *ll = j + 1 < J ? L[j + 1].a : nullptr;
-			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0))
+			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0, nullptr, dirs))
 				return 1;
 		}
 		if (J == 1)
@@ -342,10 +343,15 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 	const bool fixed = wavelet == kCdf97I && flavour == 0;
 	if (wavelet != kCdf97S && wavelet != kCdf53S && !fixed)
 		return fail("the interleaved layout takes float CDF 9/7, float CDF 5/3 and (libdwt.h entries) fixed-point int CDF 9/7, not %d", wavelet);
-	if (flavour != 0 && flavour != 1)
+	if (flavour < 0 || flavour > 3)
 		return fail("unknown flavour %d", flavour);
-	if (flavour == 1 && inverse)
+	if (flavour >= 1 && inverse)
 		return fail("dwt-simple.h has forward transforms only; use flavour 0 for the inverse");
+	if (flavour >= 2 && wavelet != kCdf97S)
+		return fail("the one-direction entries exist for float CDF 9/7 only");
+	// flavours 2 / 3: fdwt2h1_cdf97_vertical_s / fdwt2v1_cdf97_vertical_s (src/dwt-simple.c:1747, 1837) lift
+	// the rows / the columns of every level only
+	const int dirs = flavour == 2 ? 1 : flavour == 3 ? 2 : 3;
 	if (!src || !dst || !j)
 		return fail("null pointer argument");
 	if (sox <= 0 || soy <= 0 || six < 0 || siy < 0 || six > sox || siy > soy)
@@ -354,7 +360,7 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 	// single-sample lines: the 9/7 drivers and fdwt2_* leave them (guards `size > 1`,
 	// libdwt.c:12978, dwt-simple.c:2266), the 5/3 _inplace_ drivers scale them (:11041, :11840)
 	const bool scale_single = wavelet == kCdf53S && flavour == 0;
-	const Wavelet w = wavelet == kCdf97S ? ((g.fma && !inverse) ? kCdf97SFma : kCdf97S) : (flavour == 1 ? kCdf53SNew : kCdf53S);
+	const Wavelet w = wavelet == kCdf97S ? ((g.fma && !inverse && dirs == 3) ? kCdf97SFma : kCdf97S) : (flavour == 1 ? kCdf53SNew : kCdf53S);
 	const bool dev_src = dwt_hip_is_device_pointer(src), dev_dst = dwt_hip_is_device_pointer(dst);
 	if (dev_src != dev_dst)
 		return fail("src and dst must both be host or both be device pointers");
@@ -363,7 +369,7 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 			return fail("device images need stride_y == 4 and stride_x a multiple of it >= width*4 (got %d, %d)", stride_x, stride_y);
 		if (fixed)
 			return inplace_int2d(inverse != 0, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
-		return interleaved2d(w, inverse != 0, scale_single, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
+		return interleaved2d(w, inverse != 0, scale_single, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one, dirs);
 	}
 	// host pointers: stage the outer frame through HBM (any byte strides)
 	const long pitch = align_up((long)sox * 4, 256);
@@ -373,7 +379,7 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 		return 1;
 	Img A{(char *)g.host_a, pitch, 4};
 	if (fixed ? inplace_int2d(inverse != 0, A, A, sox, soy, six, siy, j, decompose_one)
-	          : interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one))
+	          : interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one, dirs))
 		return 1;
 	return host_download(dst, stride_x, stride_y, 4, sox, soy, g.host_a, pitch);
 }

@@ -180,6 +180,16 @@ DWT_NEWAPI(fdwt2_cdf97_diagonal_s, DWT_HIP_CDF97_S)
 DWT_NEWAPI(fdwt2_cdf53_horizontal_s, DWT_HIP_CDF53_S)
 DWT_NEWAPI(fdwt2_cdf53_vertical_s, DWT_HIP_CDF53_S)
 DWT_NEWAPI(fdwt2_cdf53_diagonal_s, DWT_HIP_CDF53_S)
+/* one direction only, every level (src/dwt-simple.c:1747, :1837) */
+void fdwt2h1_cdf97_vertical_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
+{
+	run_il(DWT_HIP_CDF97_S, 0, 2, ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, __func__);
+}
+
+void fdwt2v1_cdf97_vertical_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
+{
+	run_il(DWT_HIP_CDF97_S, 0, 3, ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, __func__);
+}
 #undef DWT_NEWAPI
 
 /* 1-D: a line is a one-row image (src/dwt-simple.c:2059, 2118, 2166, 2195) */

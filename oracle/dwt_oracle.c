@@ -847,13 +847,15 @@ static void il_line_phase(char *line, long stride, int N, const struct il_kind *
 }
 
 /* one level on the lattice: phases outermost, rows before columns inside each phase */
+static int il_dirs = 3; /* bit 0: rows, bit 1: columns (fdwt2h1_* / fdwt2v1_* transform one direction only) */
+
 static void il_level_phased(char *ptr, long sx, long sy, int nx, int ny, const struct il_kind *k)
 {
 	for (int ph = IL_SHORT; ph <= IL_EPILOG; ph++) {
-		if (nx > 1 && (ph == IL_SHORT) == (nx < k->min_phased))
+		if ((il_dirs & 1) && nx > 1 && (ph == IL_SHORT) == (nx < k->min_phased))
 			for (int y = 0; y < ny; y++)
 				il_line_phase(ptr + (long)y * sx, sy, nx, k, (enum il_phase)ph);
-		if (ny > 1 && (ph == IL_SHORT) == (ny < k->min_phased))
+		if ((il_dirs & 2) && ny > 1 && (ph == IL_SHORT) == (ny < k->min_phased))
 			for (int x = 0; x < nx; x++)
 				il_line_phase(ptr + (long)x * sy, sx, ny, k, (enum il_phase)ph);
 	}
@@ -1011,6 +1013,22 @@ void oracle_cdf97_2i_inplace_i(void *ptr, int stride_x, int stride_y, int sox, i
 void oracle_fdwt2_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
 {
 	il_forward(ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, &IL_97_F, 1);
+}
+
+/* src/dwt-simple.c:1747 (fdwt2h1_cdf97_vertical_s: the rows of every level only) and :1837
+ * (fdwt2v1_cdf97_vertical_s: the columns only) */
+void oracle_fdwt2h1_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
+{
+	il_dirs = 1;
+	il_forward(ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, &IL_97_F, 1);
+	il_dirs = 3;
+}
+
+void oracle_fdwt2v1_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one)
+{
+	il_dirs = 2;
+	il_forward(ptr, stride_x, stride_y, size_x, size_y, size_x, size_y, j_max_ptr, decompose_one, &IL_97_F, 1);
+	il_dirs = 3;
 }
 
 /* src/dwt-simple.c:2356 (fdwt2_cdf53_{horizontal,vertical,diagonal}_s): phased like the 9/7

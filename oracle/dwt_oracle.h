@@ -118,6 +118,8 @@ void oracle_cdf97_2f_inplace_i(void *ptr, int stride_x, int stride_y, int sox, i
 void oracle_cdf97_2i_inplace_i(void *ptr, int stride_x, int stride_y, int sox, int soy, int six, int siy,
 	int j_max, int decompose_one, int zero_padding);      /* src/libdwt.c:17308 */
 void oracle_fdwt2_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
+void oracle_fdwt2h1_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one); /* src/dwt-simple.c:1747 */
+void oracle_fdwt2v1_cdf97_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one); /* src/dwt-simple.c:1837 */
 void oracle_fdwt2_cdf53_s(void *ptr, int size_x, int size_y, int stride_x, int stride_y, int *j_max_ptr, int decompose_one);
 
 /* libdwt's synthetic inputs (src/libdwt.c:1201-1244, 1142-1167, 1338, 1270). */

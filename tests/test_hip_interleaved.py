@@ -324,3 +324,28 @@ def test_golden_fixed_point_int_inplace_host(dwt, case):
     assert np.array_equal(buf, z["cdf97i.fwd"])
     dwt.dwt_cdf97_2i_inplace_i(buf, buf.strides[0], 4, sox, soy, six, siy, j, m["decompose_one"])
     assert np.array_equal(buf, z["cdf97i.inv"])
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (37, 53), (64, 5), (1, 17), (17, 1), (100, 100), (513, 700), (3, 3)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("which", ["h1", "v1"])
+def test_one_direction_entries(dwt, oracle, shape, which):
+    """fdwt2h1_cdf97_vertical_s / fdwt2v1_cdf97_vertical_s (src/dwt-simple.c:1747, 1837): rows only /
+    columns only at every level; one direction has no phase interleaving, so bit-exact."""
+    import ctypes as C
+
+    h, w = shape
+    sig = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    fn = getattr(dwt.lib, f"fdwt2{which}_cdf97_vertical_s")
+    ofn = getattr(oracle.lib, f"oracle_fdwt2{which}_cdf97_s")
+    fn.argtypes = ofn.argtypes = sig
+    fn.restype = ofn.restype = None
+    rng = np.random.default_rng(h + 3 * w)
+    for j in (-1, 1, 3):
+        for d1 in (0, 1):
+            a = rng.random((h, w + 2), dtype=np.float32)
+            got, want = a.copy(), a.copy()
+            jg, jw = C.c_int(j), C.c_int(j)
+            fn(got.ctypes.data, w, h, got.strides[0], 4, C.byref(jg), d1)
+            ofn(want.ctypes.data, w, h, want.strides[0], 4, C.byref(jw), d1)
+            assert jg.value == jw.value
+            assert np.array_equal(bits(got), bits(want)), (which, shape, j, d1)

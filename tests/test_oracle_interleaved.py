@@ -140,3 +140,26 @@ def test_fixed_point_int_inplace_matches_golden(oracle, case):
     assert np.array_equal(buf, z["cdf97i.fwd"])
     oracle.inv("cdf97_2i_inplace_i", _view(m, buf), j, size_o=so, size_i=si, decompose_one=m["decompose_one"])
     assert np.array_equal(buf, z["cdf97i.inv"]) and np.array_equal(buf, z["cdf97i.in"])
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (37, 53), (5, 64), (1, 17), (17, 1), (3, 3), (130, 67)])
+def test_one_direction_drivers_equal_reference(oracle, reference, shape):
+    """fdwt2h1_cdf97_vertical_s / fdwt2v1_cdf97_vertical_s (src/dwt-simple.c:1747, 1837)."""
+    import ctypes as C
+
+    sig = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    h, w = shape
+    rng = np.random.default_rng(h * 19 + w)
+    for which in ("h1", "v1"):
+        rf = getattr(reference.lib, f"fdwt2{which}_cdf97_vertical_s")
+        of = getattr(oracle.lib, f"oracle_fdwt2{which}_cdf97_s")
+        rf.argtypes = of.argtypes = sig
+        rf.restype = of.restype = None
+        for j in (-1, 1, 2, 4):
+            for d1 in (0, 1):
+                a = rng.random((h, w), dtype=np.float32)
+                b, c = a.copy(), a.copy()
+                j1, j2 = C.c_int(j), C.c_int(j)
+                rf(b.ctypes.data, w, h, b.strides[0], 4, C.byref(j1), d1)
+                of(c.ctypes.data, w, h, c.strides[0], 4, C.byref(j2), d1)
+                assert j1.value == j2.value and np.array_equal(bits(b), bits(c)), (which, j, d1)

@@ -164,6 +164,9 @@ void dwt_util_free_image(void **pptr);
 /* synthetic test patterns, src/libdwt.c:1338, 1270 */
 void dwt_util_test_image_fill_s(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand);
 void dwt_util_test_image_fill_i(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand);
+/* the other synthetic patterns, selected by `type` (src/libdwt.h:1438, 1421; src/libdwt.c:1201-1244) */
+void dwt_util_test_image_fill2_s(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand, int type);
+void dwt_util_test_image_fill2_i(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand, int type);
 /* src/libdwt.c:21154, 21235 */
 void dwt_util_copy_s(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);
 void dwt_util_copy_i(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y);

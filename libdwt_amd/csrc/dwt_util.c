@@ -217,6 +217,59 @@ void dwt_util_test_image_fill_i(void *ptr, int stride_x, int stride_y, int size_
 		}
 }
 
+/* the other synthetic patterns (src/libdwt.c:1201-1244 float, :1142-1167 int): type 0 as above,
+ * 1 = type 0 modulated by |sin(x/10)| |cos(xy/5)| (float only), 2 = (x ^ y) & 0xff (float: / 32,
+ * 1-based x, y), 3 = the 2x2 parity pattern (float only) */
+void dwt_util_test_image_fill2_s(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand, int type)
+{
+	for (int y = 0; y < size_i_big_y; y++)
+		for (int x = 0; x < size_i_big_x; x++) {
+			int xx = x + 1;
+			const int yy = y + 1;
+			float v;
+			switch (type) {
+			case 0:
+				xx >>= rand;
+				v = 2 * xx * yy / (float)(xx * xx + yy * yy + 1);
+				break;
+			case 1:
+				xx >>= rand;
+				v = 2 * xx * yy / (float)(xx * xx + yy * yy + 1) * fabsf(sinf(xx / 10.f)) * fabsf(cosf(yy * xx / 5.f));
+				break;
+			case 2:
+				v = (float)((xx ^ yy) & 0xff) / 32;
+				break;
+			case 3:
+				v = ((((xx & 1) << 1) | (yy & 1)) + 1) / 4.f;
+				break;
+			default:
+				dwt_util_log(LOG_ERR, "Unknown test image type.\n");
+				dwt_util_abort();
+				return;
+			}
+			memcpy(px(ptr, y, x, stride_x, stride_y), &v, sizeof v);
+		}
+}
+
+void dwt_util_test_image_fill2_i(void *ptr, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y, int rand, int type)
+{
+	for (int y = 0; y < size_i_big_y; y++)
+		for (int x = 0; x < size_i_big_x; x++) {
+			int v;
+			if (type == 0) {
+				const int xx = x >> rand;
+				v = 255 * (2 * xx * y) / (xx * xx + y * y + 1);
+			} else if (type == 2) {
+				v = (x ^ y) & 0xff;
+			} else {
+				dwt_util_log(LOG_ERR, "Unknown test image type.\n");
+				dwt_util_abort();
+				return;
+			}
+			memcpy(px(ptr, y, x, stride_x, stride_y), &v, sizeof v);
+		}
+}
+
 void dwt_util_copy_s(const void *src, void *dst, int stride_x, int stride_y, int size_i_big_x, int size_i_big_y)
 {
 	for (int y = 0; y < size_i_big_y; y++)

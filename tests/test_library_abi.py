@@ -134,7 +134,8 @@ def test_reference_examples_link_unchanged(dwt, tmp_path):
     libdir = os.path.join(ROOT, "libdwt_amd")
     import glob
 
-    for ex in ("simple", "simple-int", "simple-perf", "subbands", "perf-plot", "simple-newapi", "simple-double", "test"):
+    for ex in ("simple", "simple-int", "simple-perf", "subbands", "perf-plot", "simple-newapi", "simple-double", "test", "cdf97-test", "start",
+               "load", "load-int", "subbands-int", "simple-single-loop", "simple-perf-int", "simple-perf-line"):
         exe = tmp_path / (ex + ".bin")
         src = sorted(glob.glob(os.path.join(ref, ex, "*.c")))[0]
         subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", INCLUDE, src,
@@ -236,3 +237,23 @@ def test_dummy_driver_level_count(dwt, reference):
                 dwt.lib.dwt_cdf53_2f_dummy_s(None, 0, 0, w, h, w, h, C.byref(a), d1)
                 reference.lib.dwt_cdf53_2f_dummy_s(None, 0, 0, w, h, w, h, C.byref(b), d1)
                 assert a.value == b.value
+
+
+def test_fill2_patterns_match_reference(dwt, reference):
+    import ctypes as C
+    sig = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    for lib in (dwt.lib, reference.lib):
+        for n in ("dwt_util_test_image_fill2_s", "dwt_util_test_image_fill2_i"):
+            getattr(lib, n).argtypes = sig
+            getattr(lib, n).restype = None
+    for t in (0, 1, 2, 3):
+        for rnd in (0, 2):
+            a, b = np.zeros((37, 53), np.float32), np.zeros((37, 53), np.float32)
+            dwt.lib.dwt_util_test_image_fill2_s(a.ctypes.data, a.strides[0], 4, 53, 37, rnd, t)
+            reference.lib.dwt_util_test_image_fill2_s(b.ctypes.data, b.strides[0], 4, 53, 37, rnd, t)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (t, rnd)
+    for t in (0, 2):
+        a, b = np.zeros((37, 53), np.int32), np.zeros((37, 53), np.int32)
+        dwt.lib.dwt_util_test_image_fill2_i(a.ctypes.data, a.strides[0], 4, 53, 37, 1, t)
+        reference.lib.dwt_util_test_image_fill2_i(b.ctypes.data, b.strides[0], 4, 53, 37, 1, t)
+        assert np.array_equal(a, b), t

@@ -86,3 +86,15 @@ def test_reference_interleaved_program(tmp_path):
 def test_reference_perf_programs(tmp_path, name):
     text = run(name, tmp_path, timeout=600)
     assert "rror" not in text and "differs" not in text, text[-2000:]
+
+
+def test_reference_perf_plot_program(tmp_path):
+    """examples/perf-plot: libdwt's size sweep (dwt_util_measure_perf_cdf97_2_s over array types,
+    strides, accel values) writes its gnuplot data files."""
+    os.makedirs(os.path.join(str(tmp_path), "data"))
+    text = run("perf-plot", tmp_path, timeout=600)
+    assert "rror" not in text, text[-2000:]
+    files = os.listdir(os.path.join(str(tmp_path), "data"))
+    assert len(files) >= 10
+    first = open(os.path.join(str(tmp_path), "data", sorted(files)[0])).read().split()
+    assert len(first) >= 2 and float(first[1]) > 0

@@ -5,20 +5,27 @@ Metric (BASELINE.json): Gsamples/s of the 2-D forward float CDF 9/7, 8192x8192,
 5 levels, device resident -- also quoted as a fraction of the 8 TB/s HBM3E peak via
 the algorithmic bytes of SURVEY.md s8(d) (10.656 B per input sample).
 
-A "step" is one pass of the hot path over one batch of `--images` distinct synthetic
-8192^2 images (default 8) resident in HBM (out-of-place entry dwt_cdf97_2f_s2 semantics, one
-kernel launch per level for the whole batch).  With N GPUs every rank transforms its
-own batch (independent images: no data-path collective); value = all ranks' samples
-divided by the slowest rank's time ("scaling": "weak").
+Workload (SURVEY.md s8e, strong scaling): a FIXED total batch of `--images` distinct
+synthetic 8192^2 images (default 64) is sharded over the N GPUs, image b -> rank b*N//B;
+a "step" is one pass of the hot path over the whole batch: every rank transforms its
+resident shard (out-of-place entry, dwt_cdf97_2f_s2 semantics, one kernel launch per
+level for the whole shard).  Images are independent: no data-path collective; RCCL does
+the barrier and the max-over-ranks only.  value = total samples / slowest rank's time.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...        # starts the N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  For N > 1 the line also carries `batch_split`: the time to
+scatter the whole batch from rank 0 and gather the coefficients back over RCCL (grouped
+point-to-point, libdwt_amd.batch) -- reported beside the transform, never inside `value`.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -36,11 +43,65 @@ def algorithmic_bytes(w, h, levels, itemsize=4):
     return total
 
 
+# ---------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent starts the rank processes.  It makes NO GPU call
+# (it never imports torch), and no process that touched the GPU is ever re-exec'ed.
+# ---------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Start `n` rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in
+    their environment), relay rank 0's JSON line, return non-zero if any rank failed."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is the result; drain it while the ranks run
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the child we started
+            p.wait()
+        rc = rc or p.returncode
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line:
+        print(line)
+    else:
+        sys.stderr.write(out0 or "")
+    if rc or not line:
+        sys.stderr.write(f"bench.py: a rank failed (exit codes {[p.returncode for p in procs]})\n")
+        return rc or 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): libdwt's own CPU path, timed beside the GPU in the same run
+# ---------------------------------------------------------------------------------------
 def cpu_baseline(size, levels):
-    """libdwt's own CPU path on the host cores (rank 0, N=1 only): oracle/_ref when it
-    was built (kind "reference"), else the bit-identical restatement (kind "port").
-    Bounded sample: ONE size x size image transformed repeatedly for ~2 s per schedule, best
-    single run, following dwt_util_perf_cdf97_2_s (src/libdwt.c:21444-21476; M=1)."""
+    """libdwt's own CPU path on the host cores: oracle/_ref when it was built (kind
+    "reference"), else the bit-identical restatement (kind "port").  SURVEY.md s8(d):
+    protocol of dwt_util_perf_cdf97_2_s (src/libdwt.c:21444-21476: minimum over N runs, M=1)
+    on ONE size x size image, for (1 thread, all of this GPU's host cores) x (dense pitch,
+    dwt_util_get_stride pitch) x (plain loop accel 0, the "fast SSE" setting accel 12 /
+    4 workers of examples/simple-perf/simple.c:15-16).  Bounded: ~1.5 s or 12 runs per row."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -60,54 +121,156 @@ def cpu_baseline(size, levels):
         if not os.path.exists(oraclelib.REF_SO):
             raise FileNotFoundError
         lib = oraclelib.Reference()
-        lib.lib.dwt_util_set_accel(0)
-        lib.lib.dwt_util_set_num_workers(1)
-        lib.lib.dwt_util_set_num_threads(cores)
     except Exception:
         kind = "port"
         lib = oraclelib.Oracle()
-        lib.set_threads(cores)
     rng = np.random.default_rng(1234)
-    # pitch as dwt_util_get_stride(.,2) would pick it (power-of-two pitches alias in cache)
-    pitch_elems = size + 144 if size % 1024 == 0 else size
-    buf = np.zeros((size, pitch_elems), np.float32)
     src = rng.random((size, size), dtype=np.float32)
-    # the reference's plain loop (accel 0) and its "fast SSE" setting of examples/simple-perf
-    # (accel 12, 4 workers); the port has one schedule.  Bounded: each runs for ~2 s of wall
-    # time (at most 40 transforms), the best single transform counts (dwt_util_perf protocol).
-    configs = [(0, 1), (12, 4)] if kind == "reference" else [(0, 1)]
-    results = []
-    for accel, workers in configs:
-        if kind == "reference":
-            lib.lib.dwt_util_set_accel(accel)
-            lib.lib.dwt_util_set_num_workers(workers)
-        best, runs, t_start = None, 0, time.perf_counter()
-        while runs < 40 and (runs < 3 or time.perf_counter() - t_start < 2.0):
-            buf[:, :size] = src
-            t0 = time.perf_counter()
-            lib.fwd("cdf97_2f_s", buf[:, :size], levels)
-            dt = time.perf_counter() - t0
-            if runs > 0:
-                best = dt if best is None else min(best, dt)
-            runs += 1
-        results.append((size * size / best / 1e9, accel, workers, runs, best))
-    results.sort(reverse=True)
-    val, accel, workers, runs, best = results[0]
-    detail = "; ".join(f"accel {a}/{w} workers: {v:.2f} Gsamples/s (best of {r - 1} runs, {b:.3f} s)" for v, a, w, r, b in results)
-    return {"value": val, "unit": "Gsamples/s", "cores": cores, "kind": kind,
-            "sample": f"1 image {size}x{size} float, {levels} levels, dwt_cdf97_2f_s, {cores} OpenMP threads, "
-                      f"pitch {pitch_elems * 4} B; {detail}"}
+    # dwt_util_get_stride(.,2) avoids power-of-two pitches (they alias in the CPU caches)
+    pitches = [size, size + 144] if size % 1024 == 0 else [size]
+    schedules = [(0, 1), (12, 4)] if kind == "reference" else [(0, 1)]
+    thread_counts = sorted({1, cores})
+    rows = []
+    for pitch_elems in pitches:
+        buf = np.zeros((size, pitch_elems), np.float32)
+        for threads in thread_counts:
+            for accel, workers in schedules:
+                if kind == "reference":
+                    lib.lib.dwt_util_set_accel(accel)
+                    lib.lib.dwt_util_set_num_workers(workers)
+                    lib.lib.dwt_util_set_num_threads(threads)
+                else:
+                    lib.set_threads(threads)
+                best, runs, t_start = None, 0, time.perf_counter()
+                while runs < 13 and (runs < 3 or time.perf_counter() - t_start < 1.5):
+                    buf[:, :size] = src
+                    t0 = time.perf_counter()
+                    lib.fwd("cdf97_2f_s", buf[:, :size], levels)
+                    dt = time.perf_counter() - t0
+                    if runs > 0:  # the first run warms caches and the OpenMP pool
+                        best = dt if best is None else min(best, dt)
+                    runs += 1
+                rows.append({"threads": threads, "pitch_bytes": pitch_elems * 4, "accel": accel, "workers": workers,
+                             "gsamples_per_s": round(size * size / best / 1e9, 3), "best_s": round(best, 4), "runs": runs - 1})
+    top = max(rows, key=lambda r: r["gsamples_per_s"])
+    return {"value": top["gsamples_per_s"], "unit": "Gsamples/s", "cores": top["threads"], "kind": kind,
+            "sample": f"1 image {size}x{size} float, {levels} levels, dwt_cdf97_2f_s in place, best single run per row "
+                      f"(dwt_util_perf protocol, M=1); value = best row: {top['threads']} OpenMP threads, pitch "
+                      f"{top['pitch_bytes']} B, accel {top['accel']} / {top['workers']} workers",
+            "rows": rows}
 
 
-def other_workload(args, dwt, torch, dist, world, rank, local_rank):
+def _profile_traffic(l0_bytes, n):
+    """HBM bytes per level-0 launch from the committed PMC passes (profiles/*_pmc_level0.json:
+    FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE), scaled to this run's bytes per launch.
+    Counters cannot be read from inside the run, so this is NOT an in-run measurement."""
+    try:
+        import glob
+
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_level0.json")))[-1]
+        pj = json.load(open(prof))
+        if n == 8192 and "hbm_traffic_bytes_per_launch" in pj:
+            return round(pj["hbm_traffic_bytes_per_launch"] * l0_bytes / pj["algorithmic_bytes_per_launch"]), os.path.relpath(prof, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
+def _event_times(torch, fn, reps, warm):
+    """HIP-event time of each of `reps` calls of fn(i) on the current stream (which is the
+    stream the library launches on); returns the per-call milliseconds."""
+    for i in range(warm):
+        fn(i)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        fn(i)
+        b.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in evs]
+
+
+def single_image_stats(torch, dwt, src, dst, n, J):
+    """the libdwt.h entries on ONE device-resident image -- the out-of-place
+    dwt_cdf97_2f_s2 and the in-place dwt_cdf97_2f_s -- HIP-event min and median over 100 calls
+    after 20 warm-up calls, each call on a different image of the resident batch (so nothing
+    is served from the 256 MiB Infinity Cache), against the same algorithmic bytes."""
+    nb = src.shape[0]
+    alg = algorithmic_bytes(n, n, J)
+    work = dst  # the batch's output images double as in-place work buffers
+
+    def s2(i):
+        k = i % nb
+        dwt.dwt_cdf97_2f_s2(src[k], dst[k], n * 4, 4, n, n, n, n, J)
+
+    def inplace(i):
+        k = i % nb
+        dwt.dwt_cdf97_2f_s(work[k], n * 4, 4, n, n, n, n, J)
+
+    out = {"reps": 100, "warmup": 20, "algorithmic_bytes": alg}
+    for name, fn in (("s2", s2), ("inplace", inplace)):
+        if name == "inplace":
+            work.copy_(src)
+        ms = _event_times(torch, fn, 100, 20)
+        mn, med = min(ms), statistics.median(ms)
+        out[f"{name}_us_min"] = round(mn * 1e3, 1)
+        out[f"{name}_us_median"] = round(med * 1e3, 1)
+        out[f"frac_{name}"] = round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
+def batch_split_times(torch, dist, src, total, n, rank, world, dev):
+    """Scatter the whole batch from rank 0 and gather it back (libdwt_amd.batch, grouped
+    point-to-point over RCCL/xGMI): the cost of a batch that starts and ends on one GPU."""
+    from libdwt_amd import batch as B
+
+    lo, hi = B.shard_range(total, rank, world)
+    full = None
+    if rank == 0:
+        full = torch.empty((total, n, n), dtype=torch.float32, device=dev)
+        full[lo:hi].copy_(src)
+    res = {}
+    for rep in range(2):  # the first pass opens the RCCL point-to-point channels
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        local = B.scatter_images(full, total, (n, n), torch.float32, dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        back = B.gather_images(local, total)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        res = {"scatter_ms": (t1 - t0) * 1e3, "gather_ms": (t2 - t1) * 1e3}
+        del local, back
+    moved = (total - (hi - lo if rank == 0 else 0)) * n * n * 4
+    t = torch.tensor([res["scatter_ms"], res["gather_ms"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    moved_t = torch.tensor([float(moved)], dtype=torch.float64, device=dev)
+    dist.broadcast(moved_t, 0)
+    sc, ga = float(t[0]), float(t[1])
+    b = float(moved_t[0])
+    return {"scatter_ms": round(sc, 3), "gather_ms": round(ga, 3), "bytes_each_way": int(b),
+            "scatter_GBps": round(b / sc / 1e6, 1), "gather_GBps": round(b / ga / 1e6, 1),
+            "how": "rank 0 -> all ranks and back, grouped isend/irecv (batch_isend_irecv), root-egress bound"}
+
+
+def other_workload(args, dwt, torch, dist, world, rank, dev, coll_dev):
     """The other BASELINE.json configs through the same contract (one JSON line, whole-job rate,
     barrier + synchronize on both sides, max over ranks): config3 = int CDF 5/3 4096^2 3 levels
-    forward + inverse; config4 = float 9/7 forward 4096^2 5 levels, 32 images per GPU (256 over 8
-    GPUs); config5 = float 9/7 forward 3-D 1024^3 3 levels, out of place."""
-    dev = torch.device("cuda", local_rank)
+    forward + inverse, 16 images per GPU; config4 = float 9/7 forward 4096^2 5 levels, a fixed
+    batch of 256 images sharded b*N//B (strong scaling); config5 = float 9/7 forward 3-D 1024^3
+    3 levels, out of place, one volume per GPU."""
+    from libdwt_amd.batch import max_over_ranks, shard_range
+
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     w = args.workload
+    scaling = "weak"
     if w == "config3":
         n, J, nb = 4096, 3, 16
         src = torch.randint(-32768, 32768, (nb, n, n), generator=gen, device=dev, dtype=torch.int32)
@@ -116,33 +279,37 @@ def other_workload(args, dwt, torch, dist, world, rank, local_rank):
         def step():
             dwt.transform2d_batch("cdf53_i", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
             dwt.transform2d_batch("cdf53_i", 1, dst, back, n * n * 4, nb, n * 4, n, n, J)
-        units, unit, dtype = nb * n * n, "Gsamples/s", "i32"
+        units, unit, dtype = world * nb * n * n, "Gsamples/s", "i32"
         alg = 2 * algorithmic_bytes(n, n, J) * nb
         metric = "Gsamples/s CDF 5/3 2-D int forward+inverse, 4096^2 3-level"
         name = f"CDF 5/3 forward + inverse 2-D int32, {n}x{n}, {J} levels, {nb} device-resident images per step per GPU"
         check = lambda: bool(torch.equal(back, src))
     elif w == "config4":
-        n, J, nb = 4096, 5, 32
+        n, J, total = 4096, 5, 256
+        lo, hi = shard_range(total, rank, world)
+        nb = hi - lo
         src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
         dst = torch.empty_like(src)
         def step():
             dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
-        units, unit, dtype = nb * n * n, "Gsamples/s", "f32"
+        units, unit, dtype = total * n * n, "Gsamples/s", "f32"
         alg = algorithmic_bytes(n, n, J) * nb
-        metric = "Gsamples/s CDF 9/7 2-D fwd float, batch of 4096^2 5-level"
-        name = f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, {nb} device-resident images per step per GPU (256 over 8 GPUs)"
-        check = lambda: True
+        scaling = "strong"
+        metric = "Gsamples/s CDF 9/7 2-D fwd float, batch of 256 x 4096^2 5-level"
+        name = (f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, fixed batch of {total} device-resident images "
+                f"sharded b*N//B over {world} GPU(s) ({nb} on rank 0)")
+        check = lambda: None
     else:
         n, J = 1024, 3
         src = torch.rand((n, n, n), generator=gen, device=dev, dtype=torch.float32)
         dst = torch.empty_like(src)
         def step():
             dwt.transform3d_op(src, dst, n * 4, n * n * 4, n, n, n, J)
-        units, unit, dtype = n ** 3, "Gvoxels/s", "f32"
+        units, unit, dtype = world * n ** 3, "Gvoxels/s", "f32"
         alg = sum(8 * ((n >> j) ** 3) for j in range(J))
         metric = "Gvoxels/s CDF 9/7 3-D fwd float, 1024^3 3-level"
         name = f"CDF 9/7 forward 3-D float, {n}^3, {J} levels, out of place (cdf97_3f_op semantics), one volume per step per GPU"
-        check = lambda: True
+        check = lambda: None
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,55 +324,56 @@ def other_workload(args, dwt, torch, dist, world, rank, local_rank):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    from libdwt_amd.batch import max_over_ranks
-    elapsed = max_over_ranks(elapsed, device=dev)
+    elapsed = max_over_ranks(elapsed, device=coll_dev)
     ok = check()
     if rank == 0:
         ach = alg * args.steps / elapsed / 1e9
         print(json.dumps({
-            "metric": metric, "value": round(world * units * args.steps / elapsed / 1e9, 3), "unit": unit, "n_gpus": world,
+            "metric": metric, "value": round(units * args.steps / elapsed / 1e9, 3), "unit": unit, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": name, "parallelism": f"batch-sharded x{world}", "round_trip_exact": ok},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "whole step (all levels): algorithmic bytes / step time"},
+                         "kernel": "whole step (all levels) on rank 0: algorithmic bytes / step time"},
         }))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--levels", type=int, default=5)
-    ap.add_argument("--images", type=int, default=8, help="distinct images per step and per GPU")
-    ap.add_argument("--inplace", action="store_true", help="time the in-place entry dwt_cdf97_2f_s instead of _s2")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")
-    ap.add_argument("--workload", default="headline", choices=["headline", "config3", "config4", "config5"],
-                    help="headline = BASELINE.json's metric (default); config3/4/5 = the other BASELINE configs, same JSON contract")
-    args = ap.parse_args()
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it as `python bench.py --gpus N` "
+                         f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if not torch.cuda.is_available():
+    use_dist = world > 1
+    ndev = torch.cuda.device_count()  # does not initialise the GPU
+    if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libdwt_amd has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    os.environ["DWT_HIP_DEVICE"] = str(local_rank)
+    # Fewer devices than ranks (a one-GPU box rehearsing the N-rank path): ranks share
+    # devices and coordinate over gloo -- RCCL refuses two ranks on one device.  The line is
+    # then flagged `devices_shared` and is not a scaling measurement.
+    shared = ndev < world
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    os.environ["DWT_HIP_DEVICE"] = str(dev_index)
+    dev = torch.device("cuda", dev_index)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL on ROCm, bound to this rank's GPU; used for the barrier and the max-reduce only
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            # RCCL on ROCm, bound to this rank's GPU; barrier, max-reduce and the batch split only
+            dist.init_process_group("nccl", device_id=dev)
+    coll_dev = torch.device("cpu") if shared else dev
 
     import libdwt_amd as dwt
+    from libdwt_amd.batch import max_over_ranks, shard_range
 
     dwt.dwt_util_init()
     for kv in args.opt:
@@ -215,25 +383,31 @@ def main():
     dwt.set_stream(stream.cuda_stream)
 
     if args.workload != "headline":
-        other_workload(args, dwt, torch, dist if use_dist else None, world, rank, local_rank)
+        other_workload(args, dwt, torch, dist if use_dist else None, world, rank, dev, coll_dev)
         if use_dist:
             dist.destroy_process_group()
         return
 
-    n, J, nb = args.size, args.levels, args.images
-    dev = torch.device("cuda", local_rank)
+    n, J, total = args.size, args.levels, args.images
+    lo, hi = shard_range(total, rank, world)
+    nb = hi - lo
+    if nb < 1:
+        raise SystemExit(f"bench.py: --images {total} leaves rank {rank} of {world} without an image")
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
     dst = src.clone() if args.inplace else torch.empty_like(src)
     img_bytes = n * n * 4
+    chunk = args.chunk if args.chunk > 0 else nb
 
     def step():
         if args.inplace:
             for k in range(nb):
                 dwt.dwt_cdf97_2f_s(dst[k], n * 4, 4, n, n, n, n, J)
         else:
-            dwt.transform2d_batch("cdf97_s", 0, src, dst, img_bytes, nb, n * 4, n, n, J)
+            for k in range(0, nb, chunk):
+                c = min(chunk, nb - k)
+                dwt.transform2d_batch("cdf97_s", 0, src[k:k + c], dst[k:k + c], img_bytes, c, n * 4, n, n, J)
 
     def barrier():
         torch.cuda.synchronize()
@@ -245,44 +419,42 @@ def main():
         step()
     barrier()
     dwt.prof_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()  # same stream as the launches: per-step HIP-event times
     barrier()
     elapsed = time.perf_counter() - t0
     k_ms, k_launches = dwt.prof_read()
     dwt.prof_enable(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
 
-    from libdwt_amd.batch import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device=coll_dev)
 
-    elapsed = max_over_ranks(elapsed, device=dev)
-
-    samples = world * nb * n * n * args.steps
+    samples = total * n * n * args.steps
     value = samples / elapsed / 1e9
     alg = algorithmic_bytes(n, n, J)
     # dominant kernel: the level-0 sweep; per launch it reads and writes the whole
-    # level-0 region of every image of the batch once
-    images_per_launch = 1 if args.inplace else nb
+    # level-0 region of every image of the call once
+    images_per_launch = 1 if args.inplace else min(chunk, nb)
     l0_bytes = 2 * 4 * n * n * images_per_launch
     l0_ms = k_ms / max(k_launches, 1)
     achieved = l0_bytes / (l0_ms * 1e-3) / 1e9 if k_launches else None
 
-    # HBM traffic of the dominant kernel from the PMC passes of the committed profile
-    # (profiles/<tag>_pmc_level0.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE per
-    # launch of 8 images); scaled to this run's images per launch.  None if absent.
-    traffic, traffic_src = None, None
-    try:
-        import glob
-
-        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_level0.json")))[-1]
-        pj = json.load(open(prof))
-        if n == 8192 and "hbm_traffic_bytes_per_launch" in pj:
-            traffic = pj["hbm_traffic_bytes_per_launch"] * l0_bytes / pj["algorithmic_bytes_per_launch"]
-            traffic_src = os.path.relpath(prof, ROOT)
-    except Exception:
-        pass
+    split = None
+    if use_dist and not args.no_split and not args.inplace:
+        try:
+            if shared:
+                split = {"skipped": "ranks share a device (gloo rehearsal); the RCCL batch split needs one GPU per rank"}
+            else:
+                split = batch_split_times(torch, dist, src, total, n, rank, world, dev)
+        except Exception as e:  # never lose the transform's line to the side measurement
+            split = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
+        traffic, traffic_src = _profile_traffic(l0_bytes, n)
         out = {
             "metric": "Gsamples/s (= % HBM3E BW) CDF 9/7 2-D fwd float, 8192^2 5-level",
             "value": round(value, 3),
@@ -292,22 +464,35 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, "
-                                   f"{nb} device-resident images per step per GPU, "
-                                   + ("in-place entry dwt_cdf97_2f_s" if args.inplace else "out-of-place entry (dwt_cdf97_2f_s2 semantics, batched)"),
+            "config": {"workload": f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, fixed batch of {total} device-resident "
+                                   f"images sharded b*N//B over {world} GPU(s) ({nb} per GPU), "
+                                   + ("in-place entry dwt_cdf97_2f_s per image" if args.inplace
+                                      else f"out-of-place entry (dwt_cdf97_2f_s2 semantics), {images_per_launch} images per launch"),
                        "entry": "dwt_cdf97_2f_s" if args.inplace else "dwt_cdf97_2f_s2",
-                       "images_per_step_per_gpu": nb, "parallelism": f"batch-sharded x{world}"},
+                       "images_total": total, "images_per_gpu": nb, "images_per_launch": images_per_launch,
+                       "parallelism": f"batch-sharded x{world}"},
             "hbm_frac_algorithmic": round(value * 1e9 * alg / (n * n) / (HBM_PEAK_GBS * 1e9) / world, 4),
+            "step_ms_rank0": {"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4), "n": len(step_ms),
+                              "how": "HIP events on the launch stream, rank 0's shard"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src,
+                         "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src,
                          "kernel": "k_fwd_sweep<Cdf97S> level 0",
                          "bytes_per_launch": l0_bytes, "avg_launch_ms": round(l0_ms, 5), "launches": k_launches},
         }
+        if shared:
+            out["devices_shared"] = True
+        if split is not None:
+            out["batch_split"] = split
+        if not args.no_single and not args.inplace:
+            try:
+                out["single_image"] = single_image_stats(torch, dwt, src, dst, n, J)
+            except Exception as e:
+                out["single_image"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, J)
@@ -315,7 +500,57 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Gsamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def launcher_selftest():
+    """CPU rehearsal of the N-rank plumbing (tests/test_bench_launcher.py): the ranks form a
+    gloo group, exercise barrier + max-over-ranks, and rank 0 prints a line.  No GPU."""
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    from libdwt_amd.batch import max_over_ranks, shard_range
+
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo")
+    t = max_over_ranks(1.0 + rank)
+    lo, hi = shard_range(64, rank, world)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "max_over_ranks": t, "images_rank0": hi - lo}))
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--images", type=int, default=64, help="images of the whole batch (sharded over the GPUs)")
+    ap.add_argument("--chunk", type=int, default=0, help="images per batched call (0 = the rank's whole shard)")
+    ap.add_argument("--inplace", action="store_true", help="time the in-place entry dwt_cdf97_2f_s instead of _s2")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-image entry timings")
+    ap.add_argument("--no-split", action="store_true", help="skip the RCCL scatter/gather timing (N > 1)")
+    ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")
+    ap.add_argument("--workload", default="headline", choices=["headline", "config3", "config4", "config5"],
+                    help="headline = BASELINE.json's metric (default); config3/4/5 = the other BASELINE configs, same JSON contract")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: start the rank processes (this parent never touches the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_launcher:
+        if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+            raise SystemExit("bench.py: --gpus does not match WORLD_SIZE")
+        return launcher_selftest()
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,16 @@ def _world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
+def _p2p(ops):
+    """One grouped launch of point-to-point transfers (ncclGroupStart/End on RCCL: the
+    root's sends leave over its 7 xGMI links concurrently instead of one after another;
+    on gloo the ops are posted individually)."""
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
 def scatter_images(batch_on_root, n_items, item_shape, dtype, device, root=0):
     """Split a (B, H, W) batch held by `root` into per-rank blocks.  Every rank passes
     the same n_items/item_shape/dtype; only root passes the tensor.  Returns this
@@ -36,20 +46,20 @@ def scatter_images(batch_on_root, n_items, item_shape, dtype, device, root=0):
     if world == 1:
         return batch_on_root[lo:hi]
     local = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=device)
-    # point-to-point sends from the root: on xGMI each destination has its own link, so
-    # the root's 7 egress links work in parallel (root-egress bound)
+    ops = []
     if rank == root:
-        reqs = []
+        if batch_on_root.dtype != dtype:
+            raise TypeError(f"batch dtype {batch_on_root.dtype} does not match the wavelet's {dtype}")
         for r in range(world):
             rlo, rhi = shard_range(n_items, r, world)
             if r == root:
                 local.copy_(batch_on_root[rlo:rhi])
             elif rhi > rlo:
-                reqs.append(dist.isend(batch_on_root[rlo:rhi].contiguous(), dst=r))
-        for q in reqs:
-            q.wait()
+                # a contiguous block of a contiguous batch: sent in place, no staging copy
+                ops.append(dist.P2POp(dist.isend, batch_on_root[rlo:rhi].contiguous(), r))
     elif hi > lo:
-        dist.recv(local, src=root)
+        ops.append(dist.P2POp(dist.irecv, local, root))
+    _p2p(ops)
     return local
 
 
@@ -58,6 +68,8 @@ def gather_images(local, n_items, root=0):
     rank, world = _world()
     if world == 1:
         return local
+    ops = []
+    out = None
     if rank == root:
         out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         for r in range(world):
@@ -65,11 +77,11 @@ def gather_images(local, n_items, root=0):
             if r == root:
                 out[rlo:rhi].copy_(local)
             elif rhi > rlo:
-                dist.recv(out[rlo:rhi], src=r)
-        return out
-    if local.shape[0] > 0:
-        dist.send(local.contiguous(), dst=root)
-    return None
+                ops.append(dist.P2POp(dist.irecv, out[rlo:rhi], r))
+    elif local.shape[0] > 0:
+        ops.append(dist.P2POp(dist.isend, local.contiguous(), root))
+    _p2p(ops)
+    return out
 
 
 def max_over_ranks(seconds, device="cpu"):
@@ -89,7 +101,7 @@ def transform_sharded(batch_on_root, n_items, item_shape, wavelet="cdf97_s", lev
     `transform(block, levels)` defaults to the HIP batch entry (device tensors); the CPU
     tests inject the oracle here, the product never does."""
     rank, world = _world()
-    dtype = torch.int32 if wavelet == "cdf53_i" else torch.float32
+    dtype = torch.int32 if wavelet in ("cdf53_i", "cdf97_i") else torch.float32
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     local = scatter_images(batch_on_root, n_items, item_shape, dtype, device, root)
@@ -100,6 +112,8 @@ def transform_sharded(batch_on_root, n_items, item_shape, wavelet="cdf97_s", lev
             if block.shape[0] == 0:
                 return block
             h, w = block.shape[1:]
+            if block.dtype != dtype:
+                raise TypeError(f"block dtype {block.dtype} does not match {wavelet}")
             out = torch.empty_like(block)
             dwt.use_torch_stream()
             dwt.transform2d_batch(wavelet, int(inverse), block, out, h * w * 4, block.shape[0], w * 4, w, h, lv)

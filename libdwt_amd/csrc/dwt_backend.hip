@@ -359,7 +359,9 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				f.out_h = dst.p;
 				f.h_pitch = dst.sx / 4;
 				f.h_bstride = dst_bstride / 4;
-				const int ll_out2 = last2 ? -1 : ((j + 1) & 1);
+				// never the buffer this launch reads (a pair that starts from scratch would
+				// otherwise overwrite its own input); band j+2 fits either buffer
+				const int ll_out2 = last2 ? -1 : (ll_in < 0 ? ((j + 1) & 1) : 1 - ll_in);
 				if (last2) {
 					f.out_ll2 = dst.p;
 					f.ll2_pitch = f.h_pitch;
@@ -410,7 +412,9 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			a.out_h = hdst.p;
 			a.h_pitch = hdst.sx / 4;
 			a.h_bstride = h_bstride / 4;
-			const int ll_out = last ? -1 : (j & 1);
+			// ping-pong: the other buffer than the one read (after a fused pair the parity
+			// of the level no longer tells which one that is); band j+1 fits either for j >= 1
+			const int ll_out = last ? -1 : (ll_in < 0 ? (j & 1) : 1 - ll_in);
 			if (last) {
 				a.out_ll = hdst.p;
 				a.ll_pitch = a.h_pitch;
@@ -786,6 +790,12 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.nt;
 	if (!strcmp(name, "nt_inv"))
 		return g.tune.nt_inv;
+	if (!strcmp(name, "ring_inv"))
+		return g.tune.ring_inv;
+	if (!strcmp(name, "wave_horiz_inv"))
+		return g.tune.wave_horiz_inv;
+	if (!strcmp(name, "vol_swizzle"))
+		return g.vol.swizzle;
 	if (!strcmp(name, "pipeline"))
 		return g.pipeline;
 	if (!strcmp(name, "fma"))

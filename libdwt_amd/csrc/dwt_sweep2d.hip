@@ -115,7 +115,8 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 	case kCdf97I: return line_pass_t<Cdf97I>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf53SNew: return line_pass_t<Cdf53SNew>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	case kCdf97IIp: return line_pass_t<Cdf97IIp>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
-	case kCdf97SFma: break; // the contracted variant exists for the fused sweeps only
+	// the contracted variant exists for the fused sweeps only: line passes of such a call are exact
+	case kCdf97SFma: return line_pass_t<Cdf97S>(inverse, src, dst, line_stride, elem_stride, n_lines, N, hoff, lanes_along_lines, s);
 	}
 	return hipErrorInvalidValue;
 }

@@ -93,9 +93,62 @@ def make_input(ref, kind, dt, h, w_alloc, w, seed):
     return buf
 
 
+# Multi-channel images as the reference's OpenCV wrapper passes them (src/cvdwt.cpp:98-135):
+# ptr = data + elemSize1*channel, stride_x = step, stride_y = elemSize (= channels*elemSize1),
+# outer size = the matrix, inner size = the caller's Size, flags -> decompose_one / zero_padding.
+# (name, (w, h), channels, channel, size_i or None, j, decompose_one, zero_padding, pitch pad in pixels)
+CASES_MC = [
+    ("mc3_40x24_c0", (40, 24), 3, 0, None, -1, 0, 0, 0),
+    ("mc3_40x24_c2_j2", (40, 24), 3, 2, None, 2, 0, 0, 0),
+    ("mc3_37x53_c1", (37, 53), 3, 1, None, -1, 0, 0, 1),
+    ("mc2_64x48_c1_sparse_zp", (64, 48), 2, 1, (50, 40), -1, 0, 1, 0),
+    ("mc4_33x17_c3_sparse", (33, 17), 4, 3, (20, 9), -1, 0, 0, 0),
+    ("mc3_5x64_c1_d1", (5, 64), 3, 1, None, -1, 1, 0, 0),
+    ("mc3_96x64_c1_j4", (96, 64), 3, 1, None, 4, 0, 0, 0),
+]
+# which wavelets run which case (keeps the fixture small): the two north-star wavelets run all
+MC_SUBSET = {"cdf53_s": {"mc3_40x24_c0", "mc2_64x48_c1_sparse_zp"}, "cdf97_i": {"mc3_40x24_c2_j2", "mc4_33x17_c3_sparse"},
+             "cdf97_d": {"mc3_40x24_c0", "mc4_33x17_c3_sparse"}, "cdf53_d": {"mc3_37x53_c1"}}
+
+
+def gen_multichannel(ref, manifest):
+    arrays, meta = {}, []
+    for idx, (name, (w, h), nch, ch, si, j, d1, zp, pad) in enumerate(CASES_MC):
+        for wname, (ff, fi, dt) in WAVELETS.items():
+            if wname in MC_SUBSET and name not in MC_SUBSET[wname]:
+                continue
+            rng = np.random.default_rng(6000 + idx)
+            shape = (h, w + pad, nch)
+            if dt == np.int32:
+                buf = rng.integers(-32768, 32768, size=shape, dtype=np.int32)
+            else:
+                buf = rng.random(shape).astype(dt)
+            img = buf[:, :w, :]
+            key = f"{name}.{wname}"
+            arrays[key + ".in"] = buf.copy()
+            jret = ref.call_channel(ff, img, ch, j, size_i=si, decompose_one=d1, zero_padding=zp)
+            arrays[key + ".fwd"] = buf.copy()
+            ref.call_channel(fi, img, ch, jret, size_i=si, decompose_one=d1, zero_padding=zp)
+            arrays[key + ".inv"] = buf.copy()
+            meta.append({"name": key, "wavelet": wname, "size_o": (w, h), "size_i": si or (w, h), "channels": nch, "channel": ch,
+                         "j_in": j, "j_out": jret, "decompose_one": d1, "zero_padding": zp, "pitch_pixels": w + pad})
+    path = os.path.join(OUT, "multichannel.npz")
+    np.savez_compressed(path, **arrays)
+    manifest["files"]["multichannel.npz"] = {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "cases": meta}
+    print(path, os.path.getsize(path), "bytes", len(meta), "cases")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = Reference()
+    if sys.argv[1:] == ["multichannel"]:
+        # add / refresh this one file, leaving the others (and their hashes) as they are
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_multichannel(ref, manifest)
+        with open(os.path.join(OUT, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return
     manifest = {"generator": "oracle/gen_golden.py", "reference": "libdwt 2015-02-18-dev (oracle/_ref/libdwt_ref.so)",
                 "files": {}}
     for wname, (ff, fi, dt) in WAVELETS.items():
@@ -204,6 +257,8 @@ def main():
     np.savez_compressed(path, **arrays)
     manifest["files"]["cdf97_3d_s.npz"] = {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "cases": meta}
     print(path, os.path.getsize(path), "bytes")
+
+    gen_multichannel(ref, manifest)
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)

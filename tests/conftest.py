@@ -67,3 +67,13 @@ def interleaved_cases():
         pre = m["name"] + "."
         out.append((m, {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}))
     return out
+
+
+def multichannel_cases():
+    """[(meta, in, fwd, inv)] of tests/golden/multichannel.npz: (H, pitch_pixels, C) arrays the
+    reference transformed one channel of, called the way src/cvdwt.cpp calls the entries."""
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)
+    z = np.load(os.path.join(GOLDEN, "multichannel.npz"))
+    return [(m, z[m["name"] + ".in"], z[m["name"] + ".fwd"], z[m["name"] + ".inv"])
+            for m in man["files"]["multichannel.npz"]["cases"]]

@@ -94,6 +94,24 @@ class _Lib:
         fn(img.ctypes.data, img.strides[0], es, sox, soy, six, siy, j, decompose_one, zero_padding)
         return j
 
+    def call_channel(self, name, img, channel, j, size_i=None, decompose_one=0, zero_padding=0):
+        """One channel of an interleaved multi-channel image `img` (H, W, C), in place, the way
+        the reference's OpenCV wrapper calls the entry (src/cvdwt.cpp:98-135): ptr = data +
+        elemSize1*channel, stride_x = step, stride_y = elemSize = C*elemSize1."""
+        sig, dt = ENTRIES[name]
+        es = np.dtype(dt).itemsize
+        assert img.dtype == dt and img.ndim == 3 and img.strides[2] == es and img.strides[1] == es * img.shape[2]
+        h, w, _ = img.shape
+        six, siy = size_i if size_i else (w, h)
+        fn = getattr(self.lib, self.prefix + name)
+        ptr = img.ctypes.data + es * channel
+        if "2f" in name:
+            jj = _I(j)
+            fn(ptr, img.strides[0], img.strides[1], w, h, six, siy, C.byref(jj), decompose_one, zero_padding)
+            return jj.value
+        fn(ptr, img.strides[0], img.strides[1], w, h, six, siy, j, decompose_one, zero_padding)
+        return j
+
     def fwd(self, name, img, j=-1, **kw):
         return self._call(name, img, j, **kw)
 

@@ -6,7 +6,7 @@ tolerance the north star allows, which is also asserted explicitly)."""
 import numpy as np
 import pytest
 
-from conftest import bits, golden_cases
+from conftest import bits, golden_cases, multichannel_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +76,45 @@ def test_golden_host_entry(dwt, wname, case, accel):
         assert np.array_equal(bits(buf), bits(inv)), "inverse differs from the reference's output"
     finally:
         dwt.dwt_util_set_accel(0)
+
+
+@pytest.mark.parametrize("case", multichannel_cases(), ids=lambda c: c[0]["name"])
+def test_golden_multichannel_host_entry(dwt, case):
+    """The calling convention of the reference's OpenCV wrapper (src/cvdwt.cpp:98-135): one channel
+    of an interleaved multi-channel host image, ptr = data + elemSize1*channel, stride_x = step,
+    stride_y = elemSize = channels*sizeof(T), inner size and flags as given.  Bit-identical to what
+    the reference produced, other channels and pitch padding untouched."""
+    meta, src, fwd, inv = case
+    wname = meta["wavelet"]
+    buf = src.copy()
+    es = buf.dtype.itemsize
+    (sox, soy), (six, siy) = meta["size_o"], meta["size_i"]
+    ptr = buf.ctypes.data + es * meta["channel"]
+    j = dwt.FORWARD[wname](ptr, buf.strides[0], buf.strides[1], sox, soy, six, siy, meta["j_in"],
+                           meta["decompose_one"], meta["zero_padding"])
+    assert j == meta["j_out"]
+    assert np.array_equal(bits(buf), bits(fwd)), "forward differs from the reference's coefficients"
+    dwt.INVERSE[wname](ptr, buf.strides[0], buf.strides[1], sox, soy, six, siy, j, meta["decompose_one"], meta["zero_padding"])
+    assert np.array_equal(bits(buf), bits(inv)), "inverse differs from the reference's output"
+
+
+def test_multichannel_all_channels_like_cv_dwt_transform(dwt, oracle):
+    """dwt::transform of the wrapper (src/cvdwt.cpp:303-350) loops over the channels of one Mat:
+    a 3-channel 512x384 float image, every channel transformed in place through the host entry,
+    equals the oracle channel by channel; then the inverse restores the image."""
+    rng = np.random.default_rng(8)
+    h, w, c = 384, 512, 3
+    img = rng.random((h, w, c), dtype=np.float32)
+    want = img.copy()
+    got = img.copy()
+    for ch in range(c):
+        jw = oracle.call_channel("cdf97_2f_s", want, ch, 4)
+        jg = dwt.dwt_cdf97_2f_s(got.ctypes.data + 4 * ch, got.strides[0], got.strides[1], w, h, w, h, 4)
+        assert jg == jw == 4
+    assert np.array_equal(bits(got), bits(want))
+    for ch in range(c):
+        dwt.dwt_cdf97_2i_s(got.ctypes.data + 4 * ch, got.strides[0], got.strides[1], w, h, w, h, 4)
+    assert np.abs(got - img).max() < 1e-5
 
 
 # ---- device-resident images vs the oracle ---------------------------------------------
@@ -329,6 +368,46 @@ def test_config4_batch(dwt, oracle):
     dwt.lib.dwt_hip_free(dst)
 
 
+def test_config4_per_gpu_shape_32x4096(dwt, oracle):
+    """configs[3] at its per-GPU scale: 32 images of 4096x4096, 5 levels, ONE
+    batched call (one launch per level for the shard of a GPU); image k seeded 1234+k; images 0
+    and 31 (first and last of rank 0's block b*G//B of the 256) bit-compared with the oracle,
+    every other image through size-independent checks."""
+    n, nb, J = 4096, 32, 5
+    imgs = np.empty((nb, n, n), np.float32)
+    for k in range(nb):
+        imgs[k] = np.random.default_rng(1234 + k).random((n, n), dtype=np.float32)
+    src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    one = dwt.DeviceImage(n, n)
+    assert src and dst
+    try:
+        assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+        j = dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
+        assert j == J
+        out = np.empty_like(imgs)
+        assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
+        for k in (0, 31):
+            want = imgs[k].copy()
+            assert oracle.fwd("cdf97_2f_s", want, J) == J
+            assert np.array_equal(bits(out[k]), bits(want)), f"image {k} differs from the oracle"
+        # every image: the LL band carries the DC gain 2^J ...
+        ll = out[:, : n >> J, : n >> J].mean(axis=(1, 2), dtype=np.float64)
+        mean = imgs.mean(axis=(1, 2), dtype=np.float64)
+        assert np.all(np.abs(ll / (mean * (1 << J)) - 1) < 1e-3)
+        # ... the batched call equals the single-image libdwt.h entry bit for bit ...
+        dwt.dwt_cdf97_2f_s2(src + 17 * n * n * 4, one.ptr, n * 4, 4, n, n, n, n, J)
+        assert np.array_equal(bits(one.download(np.float32)), bits(out[17]))
+        # ... and the inverse of the whole shard restores it
+        dwt.transform2d_batch("cdf97_s", 1, dst, src, n * n * 4, nb, n * 4, n, n, J)
+        assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, src, imgs.nbytes) == 0
+        assert np.abs(out - imgs).max() < 1e-4
+    finally:
+        dwt.lib.dwt_hip_free(src)
+        dwt.lib.dwt_hip_free(dst)
+        one.free()
+
+
 def test_linearity_and_constant(dwt):
     n = 2048
     rng = np.random.default_rng(5)
@@ -499,7 +578,9 @@ def test_two_level_fused_sweep(dwt, oracle, wname):
     ff, fi, dt = NAMES[wname]
     wid = dwt.WAVELET_ID[wname]
     try:
-        for (h, w), levels in [((256, 1024), 2), ((264, 1032), 3), ((1000, 1504), 5), ((2048, 2048), 4), ((64, 4096), 2)]:
+        for (h, w), levels in [((256, 1024), 2), ((264, 1032), 3), ((1000, 1504), 5), ((2048, 2048), 4), ((64, 4096), 2),
+                                   # a pair that starts from the LL scratch: after a single level, after a pair
+                                   ((2047, 2047), 4), ((4096, 4096), 5)]:
             rng = np.random.default_rng(h + w)
             img = rand_img(rng, h, w, dt)
             want = img.copy()
@@ -518,14 +599,18 @@ def test_two_level_fused_sweep(dwt, oracle, wname):
                 a.free()
                 b.free()
         # batch + automatic tile height on an image large enough for it
-        n, nb = 4096, 3
+        n, nb = 4096, 4  # 9 x 64 x 4 tiles of 16 pairs: enough for the automatic mode to engage
         rng = np.random.default_rng(5)
         imgs = np.stack([rand_img(rng, n, n, dt) for _ in range(nb)])
         src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
         dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
         assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
         dwt.set_option("fuse2", 1)
+        dwt.prof_enable(2)
         dwt.transform2d_batch(wname, 0, src, dst, n * n * 4, nb, n * 4, n, n, 5)
+        _, launches = dwt.prof_read_levels(6)
+        dwt.prof_enable(0)
+        assert launches[0] == 1 and launches[1] == 0, f"the two-level sweep did not run: launches per level {launches}"
         out = np.empty_like(imgs)
         assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
         for k in range(nb):

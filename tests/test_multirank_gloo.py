@@ -27,7 +27,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_items, h, w, out_path):
+def _worker(rank, world, port, n_items, h, w, out_path, wavelet="cdf97_s"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,24 +39,29 @@ def _worker(rank, world, port, n_items, h, w, out_path):
         orc = Oracle()
         orc.set_threads(1)
         rng = np.random.default_rng(2024)
-        full = torch.from_numpy(rng.random((n_items, h, w), dtype=np.float32))  # same on every rank; only root's is used
+        fname = {"cdf97_s": "cdf97_2f_s", "cdf53_i": "cdf53_2f_i", "cdf97_i": "cdf97_2f_i"}[wavelet]
+        if wavelet == "cdf97_s":
+            full = torch.from_numpy(rng.random((n_items, h, w), dtype=np.float32))  # same on every rank; only root's is used
+        else:
+            full = torch.from_numpy(rng.integers(-32768, 32768, size=(n_items, h, w), dtype=np.int32))
 
         def cpu_transform(block, levels):
+            assert block.dtype == full.dtype, "the scattered block lost its dtype"
             out = block.clone().numpy()
             for k in range(out.shape[0]):
-                orc.fwd("cdf97_2f_s", out[k], levels)
+                orc.fwd(fname, out[k], levels)
             return torch.from_numpy(out)
 
         lo, hi = B.shard_range(n_items, rank, world)
-        got = B.transform_sharded(full if rank == 0 else None, n_items, (h, w), "cdf97_s", 3,
+        got = B.transform_sharded(full if rank == 0 else None, n_items, (h, w), wavelet, 3,
                                   device=torch.device("cpu"), transform=cpu_transform)
         t = B.max_over_ranks(0.5 + rank)
         assert t == 0.5 + (world - 1), t
         if rank == 0:
             want = full.clone().numpy()
             for k in range(n_items):
-                orc.fwd("cdf97_2f_s", want[k], 3)
-            ok = np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+                orc.fwd(fname, want[k], 3)
+            ok = got.dtype == full.dtype and np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
             with open(out_path, "w") as f:
                 f.write("ok" if ok else "mismatch")
         else:
@@ -72,6 +77,14 @@ def _worker(rank, world, port, n_items, h, w, out_path):
 def test_sharded_batch_roundtrip_gloo(tmp_path, world, n_items):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, _free_port(), n_items, 48, 64, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
+@pytest.mark.parametrize("wavelet", ["cdf53_i", "cdf97_i"])
+def test_sharded_int_wavelets_keep_their_dtype(tmp_path, wavelet):
+    """int32 wavelets (reversible 5/3, fixed-point 9/7) through the batch split: blocks stay int32."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(2, _free_port(), 3, 48, 64, str(out), wavelet), nprocs=2, join=True)
     assert out.read_text() == "ok"
 
 

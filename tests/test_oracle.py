@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, bits, golden_cases
+from conftest import GOLDEN, bits, golden_cases, multichannel_cases
 from oraclelib import ENTRIES
 
 WAVELETS = {
@@ -159,3 +159,39 @@ def test_test_patterns_match_reference(oracle, reference):
         oracle.fill_i(ai)
         reference.fill_i(bi)
         assert np.array_equal(ai, bi)
+
+
+FWD_INV = {"cdf97_s": ("cdf97_2f_s", "cdf97_2i_s"), "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i"), "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s"),
+           "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d"), "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d"), "cdf97_i": ("cdf97_2f_i", "cdf97_2i_i")}
+
+
+@pytest.mark.parametrize("case", multichannel_cases(), ids=lambda c: c[0]["name"])
+def test_oracle_matches_multichannel_golden(oracle, case):
+    """One channel of an interleaved multi-channel image, stride_y = channels * sizeof(T): the
+    calling convention of the reference's OpenCV wrapper (src/cvdwt.cpp:98-135)."""
+    meta, src, fwd, inv = case
+    ff, fi = FWD_INV[meta["wavelet"]]
+    w = meta["size_o"][0]
+    buf = src.copy()
+    j = oracle.call_channel(ff, buf[:, :w, :], meta["channel"], meta["j_in"], size_i=tuple(meta["size_i"]),
+                            decompose_one=meta["decompose_one"], zero_padding=meta["zero_padding"])
+    assert j == meta["j_out"]
+    assert np.array_equal(bits(buf), bits(fwd)), "forward differs (other channels must stay untouched)"
+    oracle.call_channel(fi, buf[:, :w, :], meta["channel"], j, size_i=tuple(meta["size_i"]),
+                        decompose_one=meta["decompose_one"], zero_padding=meta["zero_padding"])
+    assert np.array_equal(bits(buf), bits(inv))
+
+
+def test_oracle_multichannel_equals_reference_seeded(oracle, reference):
+    rng = np.random.default_rng(31)
+    for wname, (ff, fi) in FWD_INV.items():
+        dt = ENTRIES[ff][1]
+        for (h, w, c, ch) in [(33, 47, 3, 2), (64, 64, 4, 0), (9, 130, 2, 1)]:
+            img = (rng.integers(-1000, 1000, size=(h, w, c)).astype(dt) if dt == np.int32 else rng.random((h, w, c)).astype(dt))
+            a, b = img.copy(), img.copy()
+            ja = oracle.call_channel(ff, a, ch, -1)
+            jb = reference.call_channel(ff, b, ch, -1)
+            assert ja == jb and np.array_equal(bits(a), bits(b)), (wname, h, w, c, ch)
+            oracle.call_channel(fi, a, ch, ja)
+            reference.call_channel(fi, b, ch, jb)
+            assert np.array_equal(bits(a), bits(b)), (wname, h, w, c, ch)

@@ -54,6 +54,31 @@ int grow(void **p, size_t *have, size_t need)
 
 bool skip_single(Wavelet w) { return w == kCdf97S; } // only the 9/7 drivers guard on lines > 1
 
+// several rectangles (element coordinates) between two device images in one kernel launch
+struct Rect {
+	long dx, dy, sx, sy, w, h;
+};
+int copy_rects_on(hipStream_t st, Img dst, Img src, const Rect *rc, int n)
+{
+	CopyRects r{};
+	r.n = 0;
+	for (int k = 0; k < n && r.n < 3; k++) {
+		if (rc[k].w <= 0 || rc[k].h <= 0)
+			continue;
+		const int i = r.n++;
+		r.src[i] = src.p + rc[k].sy * src.sx + rc[k].sx * src.es;
+		r.dst[i] = dst.p + rc[k].dy * dst.sx + rc[k].dx * dst.es;
+		r.spitch[i] = src.sx;
+		r.dpitch[i] = dst.sx;
+		r.wbytes[i] = (int)(rc[k].w * dst.es);
+		r.h[i] = (int)rc[k].h;
+	}
+	hipError_t e = launch_copy_rects(r, st);
+	if (e != hipSuccess)
+		return fail("rectangle copy launch failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
 int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h)
 {
 	if (w <= 0 || h <= 0)
@@ -435,9 +460,8 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				// only touch the top-left quadrant and run meanwhile.
 				if (side_fork())
 					return 1;
-				if (copy_rect_on(g.side, dst, Wd, 0, hdst, Wd, 0, Wo - Wd, Ho) || copy_rect_on(g.side, dst, 0, Hd, hdst, 0, Hd, Wd, Ho - Hd))
-					return 1;
-				if (last && copy_rect_on(g.side, dst, 0, 0, hdst, 0, 0, Wd, Hd))
+				const Rect rc[3] = {{Wd, 0, Wd, 0, Wo - Wd, Ho}, {0, Hd, 0, Hd, Wd, Ho - Hd}, {0, 0, 0, 0, last ? Wd : 0, Hd}};
+				if (copy_rects_on(g.side, dst, hdst, rc, 3))
 					return 1;
 			}
 			ll_in = ll_out;
@@ -518,7 +542,8 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 			Img st{(char *)g.stage_img, dst.sx};
 			if (side_fork())
 				return 1;
-			if (copy_rect_on(g.side, st, Ws, 0, src, Ws, 0, Wo - Ws, Ho) || copy_rect_on(g.side, st, 0, Hs, src, 0, Hs, Ws, Ho - Hs))
+			const Rect rc[2] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}};
+			if (copy_rects_on(g.side, st, src, rc, 2))
 				return 1;
 			aside_early = true;
 		}
@@ -562,9 +587,8 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 						if (side_join()) // the copy started before the deeper levels
 							return 1;
 					} else {
-						if (copy_rect(st, Ws, 0, cur, Ws, 0, Wo - Ws, Ho) || copy_rect(st, 0, Hs, cur, 0, Hs, Ws, Ho - Hs))
-							return 1;
-						if (ll_in < 0 && copy_rect(st, 0, 0, cur, 0, 0, Ws, Hs))
+						const Rect rc[3] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}, {0, 0, 0, 0, ll_in < 0 ? Ws : 0, Hs}};
+						if (copy_rects_on(g.stream, st, cur, rc, 3))
 							return 1;
 					}
 					a.in_h = st.p;
@@ -753,6 +777,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fma = value;
 	else if (!strcmp(name, "fuse2"))
 		g.tune.fuse2 = value;
+	else if (!strcmp(name, "fuse2_pc"))
+		g.tune.fuse2_pc = value;
 	else if (!strcmp(name, "vol_cpt"))
 		g.vol.cpt = value;
 	else if (!strcmp(name, "vol_tile_pairs"))
@@ -802,6 +828,8 @@ int dwt_hip_get_option(const char *name)
 		return g.fma;
 	if (!strcmp(name, "fuse2"))
 		return g.tune.fuse2;
+	if (!strcmp(name, "fuse2_pc"))
+		return g.tune.fuse2_pc;
 	if (!strcmp(name, "vol_cpt"))
 		return g.vol.cpt;
 	if (!strcmp(name, "vol_tile_pairs"))

@@ -133,6 +133,11 @@ static __device__ __forceinline__ unsigned lds_read_dword(unsigned addr)
 	return r;
 }
 
+static __device__ __forceinline__ void lds_write_dword(unsigned addr, unsigned v)
+{
+	asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
 static __device__ __forceinline__ void wg_barrier_lds()
 {
 	// LDS traffic of this wave done, then the barrier; outstanding LDS-DMA keeps flying

@@ -25,6 +25,7 @@ struct SweepTuning {
 	                     // bit 2 keep the LL band's stores temporal (the next level reads it)
 	int nt_inv = 1;      // inverse sweep: non-temporal stores only (measured best)
 	int fuse2 = 0;       // two-level fused forward sweep: 0 off, 1 auto tile height, >1 explicit
+	int fuse2_pc = 1;    // ... with the two levels on producer / consumer waves (k_fwd2_pc) instead of one wave
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
 	int wave_horiz_inv = 0;
 };
@@ -152,6 +153,17 @@ hipError_t launch_il_compose(const float *base, long base_pitch, float *out, lon
 	const IlPyramid &py, hipStream_t s, bool out_dense = false);
 // decompose: every level's lattice gathered from `img` into its dense image, one pass
 hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s);
+
+// Up to three device-to-device rectangle copies in one launch; widths in BYTES (multiples of 4).
+struct CopyRects {
+	const char *src[3];
+	char *dst[3];
+	long spitch[3], dpitch[3];
+	int wbytes[3], h[3];
+	int first_block[4];
+	int n;
+};
+hipError_t launch_copy_rects(CopyRects r, hipStream_t s);
 
 // device-side view helpers: pitch in BYTES, 4-byte elements
 hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s);

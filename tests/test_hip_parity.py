@@ -570,13 +570,15 @@ def test_fma_option_within_tolerance(dwt, oracle):
         dwt.set_option("fma", 0)
 
 
+@pytest.mark.parametrize("pc", [1, 0], ids=["producer-consumer", "one-wave"])
 @pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"])
-def test_two_level_fused_sweep(dwt, oracle, wname):
+def test_two_level_fused_sweep(dwt, oracle, wname, pc):
     """Option "fuse2": levels j and j+1 in one sweep (the LL band between them stays on
     chip).  Same bits as the level-by-level path and as the oracle, for every tile height,
     at image borders (reflection at the right/bottom of the INNER level) and with batches."""
     ff, fi, dt = NAMES[wname]
     wid = dwt.WAVELET_ID[wname]
+    dwt.set_option("fuse2_pc", pc)
     try:
         for (h, w), levels in [((256, 1024), 2), ((264, 1032), 3), ((1000, 1504), 5), ((2048, 2048), 4), ((64, 4096), 2),
                                    # a pair that starts from the LL scratch: after a single level, after a pair
@@ -621,6 +623,7 @@ def test_two_level_fused_sweep(dwt, oracle, wname):
         dwt.lib.dwt_hip_free(dst)
     finally:
         dwt.set_option("fuse2", 0)
+        dwt.set_option("fuse2_pc", 1)
 
 
 def test_device_side_conv_show_and_compare(dwt):

@@ -362,52 +362,6 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 		const int Wo = ge.Wo(j), Ho = ge.Ho(j), Wi = ge.Wi(j), Hi = ge.Hi(j);
 		const int Wd = ge.Wo(j + 1), Hd = ge.Ho(j + 1);
 		if (level_fused_ok(ge, j)) {
-			// two levels in one sweep when both are fused-ok, nothing is in place and the
-			// launch is big enough (fwd2_tile_pairs decides); the LL band between them
-			// then never reaches HBM
-			if (j + 1 < J && level_fused_ok(ge, j + 1) && !(ll_in < 0 && cur.p == dst.p)) {
-				const int W2 = ge.Wo(j + 2), H2 = ge.Ho(j + 2);
-				const bool last2 = (j + 1 == J - 1) || !level_fused_ok(ge, j + 2);
-				Fwd2LevelArgs f;
-				f.W = Wo;
-				f.H = Ho;
-				f.batch = batch;
-				if (ll_in < 0) {
-					f.in = cur.p;
-					f.in_pitch = cur.sx / 4;
-					f.in_bstride = (cur.p == src.p ? src_bstride : dst_bstride) / 4;
-				} else {
-					f.in = g.ll[ll_in];
-					f.in_pitch = ll_pitch_elems(Wo);
-					f.in_bstride = f.in_pitch * Ho;
-				}
-				f.out_h = dst.p;
-				f.h_pitch = dst.sx / 4;
-				f.h_bstride = dst_bstride / 4;
-				// never the buffer this launch reads (a pair that starts from scratch would
-				// otherwise overwrite its own input); band j+2 fits either buffer
-				const int ll_out2 = last2 ? -1 : (ll_in < 0 ? ((j + 1) & 1) : 1 - ll_in);
-				if (last2) {
-					f.out_ll2 = dst.p;
-					f.ll2_pitch = f.h_pitch;
-					f.ll2_bstride = f.h_bstride;
-				} else {
-					f.out_ll2 = g.ll[ll_out2];
-					f.ll2_pitch = ll_pitch_elems(W2);
-					f.ll2_bstride = f.ll2_pitch * H2;
-				}
-				if (fwd2_tile_pairs(f, g.tune) > 0) {
-					prof_before(j);
-					hipError_t e = launch_fwd2_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, f, g.tune, g.stream);
-					prof_after(j);
-					if (e != hipSuccess)
-						return fail("forward levels %d+%d launch failed: %s", j, j + 1, hipGetErrorString(e));
-					ll_in = ll_out2;
-					cur = dst;
-					j++; // the next level is done too
-					continue;
-				}
-			}
 			const bool last = (j == J - 1) || !level_fused_ok(ge, j + 1);
 			FwdLevelArgs a;
 			a.W = Wo;
@@ -775,10 +729,6 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.wave_horiz_inv = value;
 	else if (!strcmp(name, "fma"))
 		g.fma = value;
-	else if (!strcmp(name, "fuse2"))
-		g.tune.fuse2 = value;
-	else if (!strcmp(name, "fuse2_pc"))
-		g.tune.fuse2_pc = value;
 	else if (!strcmp(name, "vol_cpt"))
 		g.vol.cpt = value;
 	else if (!strcmp(name, "vol_tile_pairs"))
@@ -826,10 +776,6 @@ int dwt_hip_get_option(const char *name)
 		return g.pipeline;
 	if (!strcmp(name, "fma"))
 		return g.fma;
-	if (!strcmp(name, "fuse2"))
-		return g.tune.fuse2;
-	if (!strcmp(name, "fuse2_pc"))
-		return g.tune.fuse2_pc;
 	if (!strcmp(name, "vol_cpt"))
 		return g.vol.cpt;
 	if (!strcmp(name, "vol_tile_pairs"))

@@ -24,8 +24,6 @@ struct SweepTuning {
 	int nt = 7;          // forward: bit 0 non-temporal stores, bit 1 non-temporal LDS-DMA loads,
 	                     // bit 2 keep the LL band's stores temporal (the next level reads it)
 	int nt_inv = 1;      // inverse sweep: non-temporal stores only (measured best)
-	int fuse2 = 0;       // two-level fused forward sweep: 0 off, 1 auto tile height, >1 explicit
-	int fuse2_pc = 1;    // ... with the two levels on producer / consumer waves (k_fwd2_pc) instead of one wave
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
 	int wave_horiz_inv = 0;
 };
@@ -63,21 +61,6 @@ struct InvLevelArgs {
 
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
 
-// Two forward levels in one sweep (dense frame): reads the W x H region at `in`, writes
-// the detail subbands of BOTH levels at their Mallat offsets relative to `out_h` and the
-// LL band of the second level (ceil(W/4) x ceil(H/4)) to `out_ll2`.  The LL band between
-// the two levels stays on chip.  fwd2_tile_pairs() > 0 says the launch applies.
-struct Fwd2LevelArgs {
-	const void *in;
-	long in_pitch, in_bstride;
-	void *out_ll2;
-	long ll2_pitch, ll2_bstride;
-	void *out_h;
-	long h_pitch, h_bstride;
-	int W, H, batch;
-};
-int fwd2_tile_pairs(const Fwd2LevelArgs &a, const SweepTuning &t);
-hipError_t launch_fwd2_level(Wavelet w, const Fwd2LevelArgs &a, const SweepTuning &t, hipStream_t s);
 hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s);
 // true when launch_inv_level has a fused kernel for this wavelet
 bool have_fused_inverse(Wavelet w);

@@ -935,735 +935,6 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	return cpt == 8 ? inv_pick<W, 8>(a, g, grid, waves, ring, t.nt_inv, s) : inv_pick<W, 4>(a, g, grid, waves, ring, t.nt_inv, s);
 }
 
-// ---- forward, two levels in one sweep ---------------------------------------------
-// Levels j and j+1 of the forward driver fused: the LL band between them never
-// reaches HBM (-2 of the 10.66 B per sample of a 5-level transform).  A wave runs the
-// level-j sweep exactly as k_fwd_sweep does on 512 columns, but keeps every LL row it
-// produces in a wave-private LDS ring; whenever an even LL row arrives it runs one
-// iteration of a second, level-(j+1) sweep on the ring (4 LL columns per lane, the
-// 4-column neighbour taps read back from the ring).  Lanes 0 and 63 only feed their
-// neighbours: a tile advances by 62 lanes = 496 columns (1984 B = 31 x 64 B), and a
-// tile's level-j sweep starts K LL rows early / ends K-2 late for the inner sweep's
-// warm-up.  Image borders: the outer sweep reflects the source address as before; at
-// the left/top the LL rows/columns it produces from reflected input ARE the inner
-// level's symmetric extension, at the right/bottom (even sizes) they are not, so the
-// inner sweep reflects its ring index there explicitly.
-struct Fwd2Geom {
-	int tile_pairs1, ntx, swz, in_vec_ok, out_vec_ok;
-	int nty = 0; // producer/consumer variant: tiles are packed linearly, four to a workgroup
-};
-
-template <class W, int RING, int NT>
-__global__ __launch_bounds__(256) void k_fwd2_sweep(Fwd2LevelArgs a, Fwd2Geom g)
-{
-	using T = typename W::T;
-	constexpr int K = W::K;
-	constexpr int CPT = 8, TW = 512, RS = TW + 8, NARR = CPT + 2 * K;
-	constexpr int kAhead = RING / 2 - 1;
-	constexpr int kDmaPerIter = 2 * (CPT / 4 + 1);
-	constexpr int kLdAux = (NT & 2) ? 2 : 0;
-	constexpr bool kNtStore = (NT & 1) != 0;
-	constexpr int kLLRing = 8;             // LL rows kept (the bottom reflection reaches 4 back)
-	constexpr int kStride = 62 * CPT;      // columns a tile advances by
-	constexpr int kWaveLds = RING * RS * 4 + kLLRing * 1024;
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-
-	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
-	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int bid = tile_block_id(g.swz);
-	const int ntxb = (g.ntx + nwv - 1) / nwv;
-	const int tx = (bid % ntxb) * nwv + wv;
-	const int ty = bid / ntxb;
-	const int img = blockIdx.y;
-	const int Wd0 = (a.W + 1) >> 1, Hd0 = (a.H + 1) >> 1; // level j+1 input = LL of level j
-	const int Wd1 = (Wd0 + 1) >> 1, Hd1 = (Hd0 + 1) >> 1;
-	const int A1 = ty * g.tile_pairs1;
-	if (A1 >= Hd1 || tx >= g.ntx)
-		return;
-	const int B1 = min(A1 + g.tile_pairs1, Hd1);
-	const int c0 = kStride * tx - CPT;  // lane 0 is a halo lane
-	const int cl = c0 / 2;              // LL column of lane 0's first value (c0 is a multiple of 8)
-	const int kstart = 2 * A1 - K;
-	const int kend = min(2 * B1 + K - 2, Hd0 - 1);
-	const int n_iter = (kend + 1 - kstart) + K;
-	const int q0 = kstart - K / 2;
-
-	const T *in = (const T *)a.in + (long)img * a.in_bstride;
-	T *out_ll2 = (T *)a.out_ll2 + (long)img * a.ll2_bstride;
-	T *out_h = (T *)a.out_h + (long)img * a.h_bstride;
-
-	char *ring = smem + (size_t)wv * kWaveLds;
-	const unsigned ring_off = lds_offset(ring);
-	const unsigned ll_off = ring_off + RING * RS * 4;
-
-	const bool main16 = g.in_vec_ok && c0 >= 0 && c0 + TW <= a.W;
-	int colmap[CPT];
-#pragma unroll
-	for (int i = 0; i < CPT; i++)
-		colmap[i] = reflect(c0 + i * 64 + lane, a.W);
-	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
-
-	// ring slots advance by two rows per iteration; kept as running counters (RING need
-	// not be a power of two); rows reflect with a single bounce (H >= 64 here)
-	int islot = 0, rslot = 0;
-	auto issue = [&](int it) {
-#pragma unroll
-		for (int rr = 0; rr < 2; rr++) {
-			const int r = reflect1(2 * (q0 + it) - 1 + rr, a.H);
-			char *lrow = ring + (size_t)(islot + rr) * RS * 4;
-			const T *grow = in + (long)r * a.in_pitch;
-			if (main16) {
-#pragma unroll
-				for (int i = 0; i < CPT / 4; i++)
-					dma16<kLdAux>(grow + c0 + i * 256 + lane * 4, lrow + i * 1024);
-			} else {
-#pragma unroll
-				for (int i = 0; i < CPT; i++)
-					dma4<kLdAux>(grow + colmap[i], lrow + i * 256);
-			}
-			if (lane < 8)
-				dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
-		}
-		islot = islot + 2 >= RING ? 0 : islot + 2;
-	};
-
-	T st0[K][CPT], st1[K][4];
-#pragma unroll
-	for (int s = 0; s < K; s++) {
-#pragma unroll
-		for (int v = 0; v < CPT; v++)
-			st0[s][v] = 0;
-#pragma unroll
-		for (int v = 0; v < 4; v++)
-			st1[s][v] = 0;
-	}
-
-	const bool lane_valid = lane >= 1 && lane <= 62;
-	const int ci = cl + 4 * lane;      // first LL / detail column of this lane at level j
-	const int c2 = cl / 2 + 2 * lane;  // first column of this lane at level j+1 (cl is even)
-	const bool ll_edge = cl + 256 + K > Wd0; // the inner taps may cross the right border
-
-	// one iteration of the inner (level j+1) sweep: consumes LL rows 2*q1-1 and 2*q1
-	auto inner = [&](int q1) {
-		T row1[2][4];
-#pragma unroll
-		for (int rr = 0; rr < 2; rr++) {
-			int r = 2 * q1 - 1 + rr;
-			if (r >= Hd0)
-				r = 2 * (Hd0 - 1) - r; // bottom border: whole-sample reflection of the LL row index
-			const unsigned rowb = ll_off + (unsigned)(r & (kLLRing - 1)) * 1024;
-			T x[12];
-			if (!ll_edge) {
-				// positions 4*lane-4 .. 4*lane+7 of the ring row (halo lanes read clamped garbage)
-				const unsigned own = rowb + lane * 16;
-				const unsigned la = lane == 0 ? own : own - 16;
-				const unsigned ra = lane == 63 ? own : own + 16;
-				u4 L4, O4, R4;
-				lds_read3(la, own, ra, L4, O4, R4);
-#pragma unroll
-				for (int e = 0; e < 4; e++) {
-					x[e] = from_bits<T>(L4[e]);
-					x[4 + e] = from_bits<T>(O4[e]);
-					x[8 + e] = from_bits<T>(R4[e]);
-				}
-			} else {
-#pragma unroll
-				for (int j = 0; j < 12; j++) {
-					int i = ci - 4 + j; // LL column
-					if (i >= Wd0)
-						i = 2 * (Wd0 - 1) - i; // right border
-					int p = i - cl;
-					p = p < 0 ? 0 : (p > 255 ? 255 : p);
-					x[j] = from_bits<T>(lds_read_dword(rowb + p * 4));
-				}
-			}
-			lift_fwd_regs<W, 12>(x);
-#pragma unroll
-			for (int v = 0; v < 4; v++)
-				row1[rr][v] = W::fwd_scale(v & 1, x[4 + v]);
-		}
-		T lo1[4], hi1[4];
-#pragma unroll
-		for (int v = 0; v < 4; v++) {
-			const T ov = row1[0][v], ev = row1[1][v];
-			if constexpr (K == 4) {
-				const T d1n = W::fwd_step(0, ov, st1[0][v], ev);
-				const T s1n = W::fwd_step(1, st1[0][v], st1[1][v], d1n);
-				const T d2n = W::fwd_step(2, st1[1][v], st1[2][v], s1n);
-				const T s2n = W::fwd_step(3, st1[2][v], st1[3][v], d2n);
-				lo1[v] = W::fwd_scale(0, s2n);
-				hi1[v] = W::fwd_scale(1, d2n);
-				st1[0][v] = ev;
-				st1[1][v] = d1n;
-				st1[2][v] = s1n;
-				st1[3][v] = d2n;
-			} else {
-				const T d1n = W::fwd_step(0, ov, st1[0][v], ev);
-				const T s1n = W::fwd_step(1, st1[0][v], st1[1][v], d1n);
-				lo1[v] = W::fwd_scale(0, s1n);
-				hi1[v] = W::fwd_scale(1, d1n);
-				st1[0][v] = ev;
-				st1[1][v] = d1n;
-			}
-		}
-		const int k1 = q1 - K / 2;
-		if (k1 >= A1 && k1 < B1 && lane_valid && c2 < Wd1) {
-			T *ll = out_ll2 + (long)k1 * a.ll2_pitch + c2;
-			T *hl = out_h + (long)k1 * a.h_pitch + Wd1 + c2;
-			T *lh = out_h + (long)(Hd1 + k1) * a.h_pitch + c2;
-			T *hh = lh + Wd1;
-			const bool hrow = k1 < (Hd0 >> 1);
-			const int nh = Wd0 >> 1;
-			if (g.out_vec_ok && c2 + 2 <= nh) {
-				*(u2 *)ll = u2{to_bits(lo1[0]), to_bits(lo1[2])};
-				store_vec<kNtStore>((u2 *)hl, u2{to_bits(lo1[1]), to_bits(lo1[3])});
-				if (hrow) {
-					store_vec<kNtStore>((u2 *)lh, u2{to_bits(hi1[0]), to_bits(hi1[2])});
-					store_vec<kNtStore>((u2 *)hh, u2{to_bits(hi1[1]), to_bits(hi1[3])});
-				}
-			} else {
-#pragma unroll
-				for (int e = 0; e < 2; e++) {
-					if (c2 + e < Wd1) {
-						ll[e] = lo1[2 * e];
-						if (hrow)
-							lh[e] = hi1[2 * e];
-					}
-					if (c2 + e < nh) {
-						hl[e] = lo1[2 * e + 1];
-						if (hrow)
-							hh[e] = hi1[2 * e + 1];
-					}
-				}
-			}
-		}
-	};
-
-	for (int it = 0; it < kAhead && it < n_iter; it++)
-		issue(it);
-	int next_q1 = A1 - K / 2;
-
-	for (int it = 0; it < n_iter; it++) {
-		if (it + kAhead < n_iter) {
-			issue(it + kAhead);
-			DWT_WAIT_VMCNT(kAhead * kDmaPerIter);
-		} else {
-			DWT_WAIT_VMCNT(0);
-		}
-		T row[2][CPT];
-#pragma unroll
-		for (int rr = 0; rr < 2; rr++) {
-			const unsigned base = ring_off + (unsigned)(rslot + rr) * RS * 4;
-			const unsigned own = base + lane * CPT * 4;
-			const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
-			const unsigned ra = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
-			T x[NARR];
-			u4 L4, R4, O0, O1;
-			lds_read4(la, own, ra, L4, O0, O1, R4);
-#pragma unroll
-			for (int e = 0; e < K; e++) {
-				x[e] = from_bits<T>(L4[4 - K + e]);
-				x[K + CPT + e] = from_bits<T>(R4[e]);
-			}
-#pragma unroll
-			for (int e = 0; e < 4; e++) {
-				x[K + e] = from_bits<T>(O0[e]);
-				x[K + 4 + e] = from_bits<T>(O1[e]);
-			}
-			lift_fwd_regs<W, NARR>(x);
-#pragma unroll
-			for (int v = 0; v < CPT; v++)
-				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
-		}
-		rslot = rslot + 2 >= RING ? 0 : rslot + 2;
-		T lo[CPT], hi[CPT];
-#pragma unroll
-		for (int v = 0; v < CPT; v++) {
-			const T ov = row[0][v], ev = row[1][v];
-			if constexpr (K == 4) {
-				const T d1n = W::fwd_step(0, ov, st0[0][v], ev);
-				const T s1n = W::fwd_step(1, st0[0][v], st0[1][v], d1n);
-				const T d2n = W::fwd_step(2, st0[1][v], st0[2][v], s1n);
-				const T s2n = W::fwd_step(3, st0[2][v], st0[3][v], d2n);
-				lo[v] = W::fwd_scale(0, s2n);
-				hi[v] = W::fwd_scale(1, d2n);
-				st0[0][v] = ev;
-				st0[1][v] = d1n;
-				st0[2][v] = s1n;
-				st0[3][v] = d2n;
-			} else {
-				const T d1n = W::fwd_step(0, ov, st0[0][v], ev);
-				const T s1n = W::fwd_step(1, st0[0][v], st0[1][v], d1n);
-				lo[v] = W::fwd_scale(0, s1n);
-				hi[v] = W::fwd_scale(1, d1n);
-				st0[0][v] = ev;
-				st0[1][v] = d1n;
-			}
-		}
-		if (it >= K) {
-			const int k0 = kstart + it - K;
-			// detail subbands of the outer level: this tile's own rows and lanes only
-			if (k0 >= 2 * A1 && k0 < 2 * B1 && lane_valid && ci < Wd0) {
-				T *hl = out_h + (long)k0 * a.h_pitch + Wd0 + ci;
-				T *lh = out_h + (long)(Hd0 + k0) * a.h_pitch + ci;
-				T *hh = lh + Wd0;
-				const bool hrow = k0 < (a.H >> 1);
-				const int nh = a.W >> 1;
-				if (g.out_vec_ok && ci + 4 <= nh) {
-					store_vec<kNtStore>((u4 *)hl, u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])});
-					if (hrow) {
-						store_vec<kNtStore>((u4 *)lh, u4{to_bits(hi[0]), to_bits(hi[2]), to_bits(hi[4]), to_bits(hi[6])});
-						store_vec<kNtStore>((u4 *)hh, u4{to_bits(hi[1]), to_bits(hi[3]), to_bits(hi[5]), to_bits(hi[7])});
-					}
-				} else {
-#pragma unroll
-					for (int e = 0; e < 4; e++) {
-						if (ci + e < Wd0 && hrow)
-							lh[e] = hi[2 * e];
-						if (ci + e < nh) {
-							hl[e] = lo[2 * e + 1];
-							if (hrow)
-								hh[e] = hi[2 * e + 1];
-						}
-					}
-				}
-			}
-			// the LL row goes to the ring (every lane: the halo lanes feed their neighbours)
-			lds_write4(ll_off + (unsigned)(k0 & (kLLRing - 1)) * 1024 + lane * 16,
-				u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
-			if ((k0 & 1) == 0) {
-				inner(k0 >> 1);
-				next_q1 = (k0 >> 1) + 1;
-			}
-		}
-	}
-	// bottom tiles: the remaining inner iterations take reflected rows from the ring
-	for (int q1 = next_q1; q1 <= B1 + K / 2 - 1; q1++)
-		inner(q1);
-}
-
-// ---- two levels in one sweep, producer / consumer waves ----------------------------------
-// Same tiles, same arithmetic and the same on-chip LL ring as k_fwd2_sweep, but the two levels
-// run on DIFFERENT waves: wave p (0..3) of a workgroup is the PRODUCER of pair p -- the level-j
-// sweep of k_fwd_sweep, whose LL rows go to the pair's LDS ring instead of HBM -- and wave 4+p is
-// its CONSUMER, the level-(j+1) sweep on that ring.  One wave cannot overlap its own DMA waits,
-// LDS latencies and lifting arithmetic (in-order issue, one wave per SIMD at this LDS
-// footprint: k_fwd2_sweep is issue-bound); here each SIMD hosts one producer and one consumer,
-// so the level-(j+1) work fills the issue slots the producer leaves idle while it waits on HBM.
-// Hand-off through two counters in LDS per pair: `prod` = last LL row written, `cons` = last LL
-// row the consumer is done with (the producer reuses a ring slot only then).  A producer
-// publishes a row one iteration late, after the s_waitcnt of its next LDS read batch has covered
-// the ds_write.  Pairs are independent (halo lanes as in k_fwd2_sweep), so tiles are packed
-// four to a workgroup in linear order whatever the tile grid is.
-template <class W, int RING, int NT>
-__global__ __launch_bounds__(512) void k_fwd2_pc(Fwd2LevelArgs a, Fwd2Geom g)
-{
-	using T = typename W::T;
-	constexpr int K = W::K;
-	constexpr int CPT = 8, TW = 512, RS = TW + 8, NARR = CPT + 2 * K;
-	constexpr int kAhead = RING / 2 - 1;
-	constexpr int kDmaPerIter = 2 * (CPT / 4 + 1);
-	constexpr int kLdAux = (NT & 2) ? 2 : 0;
-	constexpr bool kNtStore = (NT & 1) != 0;
-	constexpr int kLLRing = 8;
-	constexpr int kStride = 62 * CPT;
-	constexpr int kPairs = 4;
-	constexpr int kPairLds = RING * RS * 4 + kLLRing * 1024 + 16;
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-
-	const int lane = threadIdx.x & 63;
-	const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const bool consumer = wvi >= kPairs;
-	const int pair = wvi & (kPairs - 1);
-	const int tile = tile_block_id(g.swz) * kPairs + pair;
-	const bool active = tile < g.ntx * g.nty;
-	const int tx = active ? tile % g.ntx : 0;
-	const int ty = active ? tile / g.ntx : 0;
-	const int img = blockIdx.y;
-	const int Wd0 = (a.W + 1) >> 1, Hd0 = (a.H + 1) >> 1;
-	const int Wd1 = (Wd0 + 1) >> 1, Hd1 = (Hd0 + 1) >> 1;
-	const int A1 = ty * g.tile_pairs1;
-	const int B1 = min(A1 + g.tile_pairs1, Hd1);
-	const int c0 = kStride * tx - CPT;
-	const int cl = c0 / 2;
-	const int kstart = 2 * A1 - K;
-	const int kend = min(2 * B1 + K - 2, Hd0 - 1);
-
-	char *ring = smem + (size_t)pair * kPairLds;
-	const unsigned ring_off = lds_offset(ring);
-	const unsigned ll_off = ring_off + RING * RS * 4;
-	const unsigned flag_prod = ll_off + kLLRing * 1024, flag_cons = flag_prod + 4;
-
-	// the counters hold LL row numbers; before the first row: kstart - 1
-	if (!consumer && lane == 0) {
-		lds_write_dword(flag_prod, (unsigned)(kstart - 1));
-		lds_write_dword(flag_cons, (unsigned)(kstart - 1));
-	}
-	__syncthreads();
-	if (!active)
-		return;
-
-	T *out_ll2 = (T *)a.out_ll2 + (long)img * a.ll2_bstride;
-	T *out_h = (T *)a.out_h + (long)img * a.h_bstride;
-	const bool lane_valid = lane >= 1 && lane <= 62;
-
-	if (consumer) {
-		// ---------------- level j+1 on the LL ring ----------------
-		const int ci = cl + 4 * lane;
-		const int c2 = cl / 2 + 2 * lane;
-		const bool ll_edge = cl + 256 + K > Wd0;
-		T st1[K][4];
-#pragma unroll
-		for (int s = 0; s < K; s++)
-#pragma unroll
-			for (int v = 0; v < 4; v++)
-				st1[s][v] = 0;
-		int have = kstart - 1; // last row known to be in the ring
-		for (int q1 = A1 - K / 2; q1 <= B1 + K / 2 - 1; q1++) {
-			const int need = min(2 * q1, kend);
-			while (have < need) {
-				have = __builtin_amdgcn_readfirstlane((int)lds_read_dword(flag_prod));
-				if (have < need)
-					__builtin_amdgcn_s_sleep(2);
-			}
-			T row1[2][4];
-#pragma unroll
-			for (int rr = 0; rr < 2; rr++) {
-				int r = 2 * q1 - 1 + rr;
-				if (r >= Hd0)
-					r = 2 * (Hd0 - 1) - r;
-				const unsigned rowb = ll_off + (unsigned)(r & (kLLRing - 1)) * 1024;
-				T x[12];
-				if (!ll_edge) {
-					const unsigned own = rowb + lane * 16;
-					const unsigned la = lane == 0 ? own : own - 16;
-					const unsigned ra = lane == 63 ? own : own + 16;
-					u4 L4, O4, R4;
-					lds_read3(la, own, ra, L4, O4, R4);
-#pragma unroll
-					for (int e = 0; e < 4; e++) {
-						x[e] = from_bits<T>(L4[e]);
-						x[4 + e] = from_bits<T>(O4[e]);
-						x[8 + e] = from_bits<T>(R4[e]);
-					}
-				} else {
-#pragma unroll
-					for (int j = 0; j < 12; j++) {
-						int i = ci - 4 + j;
-						if (i >= Wd0)
-							i = 2 * (Wd0 - 1) - i;
-						int p = i - cl;
-						p = p < 0 ? 0 : (p > 255 ? 255 : p);
-						x[j] = from_bits<T>(lds_read_dword(rowb + p * 4));
-					}
-				}
-				lift_fwd_regs<W, 12>(x);
-#pragma unroll
-				for (int v = 0; v < 4; v++)
-					row1[rr][v] = W::fwd_scale(v & 1, x[4 + v]);
-			}
-			// both rows are in registers: the producer may reuse every slot up to row 2*q1.
-			// (Rows a bottom reflection reads again are the last ones written: nothing follows them.)
-			if (lane == 0)
-				lds_write_dword(flag_cons, (unsigned)(2 * q1));
-			T lo1[4], hi1[4];
-#pragma unroll
-			for (int v = 0; v < 4; v++) {
-				const T ov = row1[0][v], ev = row1[1][v];
-				if constexpr (K == 4) {
-					const T d1n = W::fwd_step(0, ov, st1[0][v], ev);
-					const T s1n = W::fwd_step(1, st1[0][v], st1[1][v], d1n);
-					const T d2n = W::fwd_step(2, st1[1][v], st1[2][v], s1n);
-					const T s2n = W::fwd_step(3, st1[2][v], st1[3][v], d2n);
-					lo1[v] = W::fwd_scale(0, s2n);
-					hi1[v] = W::fwd_scale(1, d2n);
-					st1[0][v] = ev;
-					st1[1][v] = d1n;
-					st1[2][v] = s1n;
-					st1[3][v] = d2n;
-				} else {
-					const T d1n = W::fwd_step(0, ov, st1[0][v], ev);
-					const T s1n = W::fwd_step(1, st1[0][v], st1[1][v], d1n);
-					lo1[v] = W::fwd_scale(0, s1n);
-					hi1[v] = W::fwd_scale(1, d1n);
-					st1[0][v] = ev;
-					st1[1][v] = d1n;
-				}
-			}
-			const int k1 = q1 - K / 2;
-			if (k1 >= A1 && k1 < B1 && lane_valid && c2 < Wd1) {
-				T *ll = out_ll2 + (long)k1 * a.ll2_pitch + c2;
-				T *hl = out_h + (long)k1 * a.h_pitch + Wd1 + c2;
-				T *lh = out_h + (long)(Hd1 + k1) * a.h_pitch + c2;
-				T *hh = lh + Wd1;
-				const bool hrow = k1 < (Hd0 >> 1);
-				const int nh = Wd0 >> 1;
-				if (g.out_vec_ok && c2 + 2 <= nh) {
-					*(u2 *)ll = u2{to_bits(lo1[0]), to_bits(lo1[2])};
-					store_vec<kNtStore>((u2 *)hl, u2{to_bits(lo1[1]), to_bits(lo1[3])});
-					if (hrow) {
-						store_vec<kNtStore>((u2 *)lh, u2{to_bits(hi1[0]), to_bits(hi1[2])});
-						store_vec<kNtStore>((u2 *)hh, u2{to_bits(hi1[1]), to_bits(hi1[3])});
-					}
-				} else {
-#pragma unroll
-					for (int e = 0; e < 2; e++) {
-						if (c2 + e < Wd1) {
-							ll[e] = lo1[2 * e];
-							if (hrow)
-								lh[e] = hi1[2 * e];
-						}
-						if (c2 + e < nh) {
-							hl[e] = lo1[2 * e + 1];
-							if (hrow)
-								hh[e] = hi1[2 * e + 1];
-						}
-					}
-				}
-			}
-		}
-		return;
-	}
-
-	// ---------------- level j: the k_fwd_sweep march, LL rows to the ring ----------------
-	__builtin_amdgcn_s_setprio(2); // the HBM stream sets the pace; the consumer takes what is left
-	const int n_iter = (kend + 1 - kstart) + K;
-	const int q0 = kstart - K / 2;
-	const T *in = (const T *)a.in + (long)img * a.in_bstride;
-	const bool main16 = g.in_vec_ok && c0 >= 0 && c0 + TW <= a.W;
-	int colmap[CPT];
-#pragma unroll
-	for (int i = 0; i < CPT; i++)
-		colmap[i] = reflect(c0 + i * 64 + lane, a.W);
-	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
-	int islot = 0, rslot = 0;
-	auto issue = [&](int it) {
-#pragma unroll
-		for (int rr = 0; rr < 2; rr++) {
-			const int r = reflect1(2 * (q0 + it) - 1 + rr, a.H);
-			char *lrow = ring + (size_t)(islot + rr) * RS * 4;
-			const T *grow = in + (long)r * a.in_pitch;
-			if (main16) {
-#pragma unroll
-				for (int i = 0; i < CPT / 4; i++)
-					dma16<kLdAux>(grow + c0 + i * 256 + lane * 4, lrow + i * 1024);
-			} else {
-#pragma unroll
-				for (int i = 0; i < CPT; i++)
-					dma4<kLdAux>(grow + colmap[i], lrow + i * 256);
-			}
-			if (lane < 8)
-				dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
-		}
-		islot = islot + 2 >= RING ? 0 : islot + 2;
-	};
-	T st0[K][CPT];
-#pragma unroll
-	for (int s = 0; s < K; s++)
-#pragma unroll
-		for (int v = 0; v < CPT; v++)
-			st0[s][v] = 0;
-	const int ci = cl + 4 * lane;
-	int done = kstart - 1;    // last LL row the consumer is known to be done with
-	int unpublished = kstart - 1; // last LL row written to the ring
-	int published = kstart - 1;
-
-	for (int it = 0; it < kAhead && it < n_iter; it++)
-		issue(it);
-	for (int it = 0; it < n_iter; it++) {
-		if (it + kAhead < n_iter) {
-			issue(it + kAhead);
-			DWT_WAIT_VMCNT(kAhead * kDmaPerIter);
-		} else {
-			DWT_WAIT_VMCNT(0);
-		}
-		T row[2][CPT];
-#pragma unroll
-		for (int rr = 0; rr < 2; rr++) {
-			const unsigned base = ring_off + (unsigned)(rslot + rr) * RS * 4;
-			const unsigned own = base + lane * CPT * 4;
-			const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
-			const unsigned ra = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
-			T x[NARR];
-			u4 L4, R4, O0, O1;
-			lds_read4(la, own, ra, L4, O0, O1, R4);
-			if (rr == 0 && unpublished != published) {
-				// the wait inside lds_read4 covered last iteration's ds_write of the LL row
-				if (lane == 0)
-					lds_write_dword(flag_prod, (unsigned)unpublished);
-				published = unpublished;
-			}
-#pragma unroll
-			for (int e = 0; e < K; e++) {
-				x[e] = from_bits<T>(L4[4 - K + e]);
-				x[K + CPT + e] = from_bits<T>(R4[e]);
-			}
-#pragma unroll
-			for (int e = 0; e < 4; e++) {
-				x[K + e] = from_bits<T>(O0[e]);
-				x[K + 4 + e] = from_bits<T>(O1[e]);
-			}
-			lift_fwd_regs<W, NARR>(x);
-#pragma unroll
-			for (int v = 0; v < CPT; v++)
-				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
-		}
-		rslot = rslot + 2 >= RING ? 0 : rslot + 2;
-		T lo[CPT], hi[CPT];
-#pragma unroll
-		for (int v = 0; v < CPT; v++) {
-			const T ov = row[0][v], ev = row[1][v];
-			if constexpr (K == 4) {
-				const T d1n = W::fwd_step(0, ov, st0[0][v], ev);
-				const T s1n = W::fwd_step(1, st0[0][v], st0[1][v], d1n);
-				const T d2n = W::fwd_step(2, st0[1][v], st0[2][v], s1n);
-				const T s2n = W::fwd_step(3, st0[2][v], st0[3][v], d2n);
-				lo[v] = W::fwd_scale(0, s2n);
-				hi[v] = W::fwd_scale(1, d2n);
-				st0[0][v] = ev;
-				st0[1][v] = d1n;
-				st0[2][v] = s1n;
-				st0[3][v] = d2n;
-			} else {
-				const T d1n = W::fwd_step(0, ov, st0[0][v], ev);
-				const T s1n = W::fwd_step(1, st0[0][v], st0[1][v], d1n);
-				lo[v] = W::fwd_scale(0, s1n);
-				hi[v] = W::fwd_scale(1, d1n);
-				st0[0][v] = ev;
-				st0[1][v] = d1n;
-			}
-		}
-		if (it >= K) {
-			const int k0 = kstart + it - K;
-			if (k0 >= 2 * A1 && k0 < 2 * B1 && lane_valid && ci < Wd0) {
-				T *hl = out_h + (long)k0 * a.h_pitch + Wd0 + ci;
-				T *lh = out_h + (long)(Hd0 + k0) * a.h_pitch + ci;
-				T *hh = lh + Wd0;
-				const bool hrow = k0 < (a.H >> 1);
-				const int nh = a.W >> 1;
-				if (g.out_vec_ok && ci + 4 <= nh) {
-					store_vec<kNtStore>((u4 *)hl, u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])});
-					if (hrow) {
-						store_vec<kNtStore>((u4 *)lh, u4{to_bits(hi[0]), to_bits(hi[2]), to_bits(hi[4]), to_bits(hi[6])});
-						store_vec<kNtStore>((u4 *)hh, u4{to_bits(hi[1]), to_bits(hi[3]), to_bits(hi[5]), to_bits(hi[7])});
-					}
-				} else {
-#pragma unroll
-					for (int e = 0; e < 4; e++) {
-						if (ci + e < Wd0 && hrow)
-							lh[e] = hi[2 * e];
-						if (ci + e < nh) {
-							hl[e] = lo[2 * e + 1];
-							if (hrow)
-								hh[e] = hi[2 * e + 1];
-						}
-					}
-				}
-			}
-			// ring slot of row k0 last held row k0 - kLLRing: wait until the consumer is done with it
-			while (done < k0 - kLLRing) {
-				done = __builtin_amdgcn_readfirstlane((int)lds_read_dword(flag_cons));
-				if (done < k0 - kLLRing)
-					__builtin_amdgcn_s_sleep(1);
-			}
-			lds_write4(ll_off + (unsigned)(k0 & (kLLRing - 1)) * 1024 + lane * 16,
-				u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
-			unpublished = k0;
-		}
-	}
-	if (unpublished != published) {
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		if (lane == 0)
-			lds_write_dword(flag_prod, (unsigned)unpublished);
-	}
-}
-
-template <class W, int RING, int NT>
-static hipError_t fwd2_pc_launch(const Fwd2LevelArgs &a, const Fwd2Geom &g, dim3 grid, hipStream_t s)
-{
-	const size_t lds = (size_t)4 * (RING * (512 + 8) * 4 + 8 * 1024 + 16);
-	if (hipError_t e = allow_lds((const void *)k_fwd2_pc<W, RING, NT>, lds))
-		return e;
-	k_fwd2_pc<W, RING, NT><<<grid, 512, lds, s>>>(a, g);
-	return hipGetLastError();
-}
-
-template <class W, int RING, int NT>
-static hipError_t fwd2_launch(const Fwd2LevelArgs &a, const Fwd2Geom &g, dim3 grid, int waves, hipStream_t s)
-{
-	const size_t lds = (size_t)waves * (RING * (512 + 8) * 4 + 8 * 1024);
-	if (hipError_t e = allow_lds((const void *)k_fwd2_sweep<W, RING, NT>, lds))
-		return e;
-	k_fwd2_sweep<W, RING, NT><<<grid, 64 * waves, lds, s>>>(a, g);
-	return hipGetLastError();
-}
-
-// tile height (in level j+1 output pairs) or 0 when the fused sweep does not apply
-int fwd2_tile_pairs(const Fwd2LevelArgs &a, const SweepTuning &t)
-{
-	if (t.fuse2 <= 0)
-		return 0;
-	// even sizes down to level j+1's output, room for the 496-column tiles, vector stores
-	if ((a.W & 7) || (a.H & 3) || a.W < 1024 || a.H < 64)
-		return 0;
-	if (!aligned16(a.in) || (a.in_pitch & 3) || (a.in_bstride & 3) || !aligned16(a.out_h) || (a.h_pitch & 3) ||
-		(a.h_bstride & 3) || ((uintptr_t)a.out_ll2 & 7) || (a.ll2_pitch & 1) || (a.ll2_bstride & 1))
-		return 0;
-	if (t.fuse2 > 1)
-		return t.fuse2; // explicit tile height
-	const long ntx = (a.W + 495) / 496;
-	const int Hd1 = a.H / 4;
-	for (int tp = 64; tp >= 16; tp >>= 1)
-		if (ntx * ((Hd1 + tp - 1) / tp) * a.batch >= 2048)
-			return tp;
-	return 0; // too few tiles to fill the chip: the separate levels do better
-}
-
-template <class W>
-static hipError_t fwd2_level_t(const Fwd2LevelArgs &a, const SweepTuning &t, hipStream_t s)
-{
-	Fwd2Geom g;
-	g.tile_pairs1 = fwd2_tile_pairs(a, t);
-	if (g.tile_pairs1 <= 0)
-		return hipErrorInvalidValue;
-	g.ntx = (a.W + 495) / 496;
-	g.swz = t.xcd_swizzle;
-	g.in_vec_ok = 1;
-	g.out_vec_ok = 1;
-	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
-	const int Hd1 = (a.H / 2 + 1) / 2;
-	const int nty = (Hd1 + g.tile_pairs1 - 1) / g.tile_pairs1;
-	if (t.fuse2_pc) {
-		g.nty = nty;
-		dim3 gridpc((g.ntx * nty + 3) / 4, a.batch);
-		if (t.ring == 8)
-			return fwd2_pc_launch<W, 8, 3>(a, g, gridpc, s);
-		if (t.ring == 10)
-			return fwd2_pc_launch<W, 10, 3>(a, g, gridpc, s);
-		if (t.ring == 12)
-			return fwd2_pc_launch<W, 12, 3>(a, g, gridpc, s);
-		return fwd2_pc_launch<W, 14, 3>(a, g, gridpc, s);
-	}
-	dim3 grid(((g.ntx + waves - 1) / waves) * nty, a.batch);
-	if (t.ring == 8)
-		return fwd2_launch<W, 8, 3>(a, g, grid, waves, s);
-	return fwd2_launch<W, 14, 3>(a, g, grid, waves, s);
-}
-
-hipError_t launch_fwd2_level(Wavelet w, const Fwd2LevelArgs &a, const SweepTuning &t, hipStream_t s)
-{
-	switch (w) {
-	case kCdf97S: return fwd2_level_t<Cdf97S>(a, t, s);
-	case kCdf53I: return fwd2_level_t<Cdf53I>(a, t, s);
-	case kCdf53S: return fwd2_level_t<Cdf53S>(a, t, s);
-	case kCdf97I: return fwd2_level_t<Cdf97I>(a, t, s);
-	case kCdf97SFma: return fwd2_level_t<Cdf97SFma>(a, t, s);
-	default: break;
-	}
-	return hipErrorInvalidValue;
-}
-
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s)
 {
 	switch (w) {

@@ -570,62 +570,6 @@ def test_fma_option_within_tolerance(dwt, oracle):
         dwt.set_option("fma", 0)
 
 
-@pytest.mark.parametrize("pc", [1, 0], ids=["producer-consumer", "one-wave"])
-@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"])
-def test_two_level_fused_sweep(dwt, oracle, wname, pc):
-    """Option "fuse2": levels j and j+1 in one sweep (the LL band between them stays on
-    chip).  Same bits as the level-by-level path and as the oracle, for every tile height,
-    at image borders (reflection at the right/bottom of the INNER level) and with batches."""
-    ff, fi, dt = NAMES[wname]
-    wid = dwt.WAVELET_ID[wname]
-    dwt.set_option("fuse2_pc", pc)
-    try:
-        for (h, w), levels in [((256, 1024), 2), ((264, 1032), 3), ((1000, 1504), 5), ((2048, 2048), 4), ((64, 4096), 2),
-                                   # a pair that starts from the LL scratch: after a single level, after a pair
-                                   ((2047, 2047), 4), ((4096, 4096), 5)]:
-            rng = np.random.default_rng(h + w)
-            img = rand_img(rng, h, w, dt)
-            want = img.copy()
-            jw = oracle.fwd(ff, want, levels)
-            for tp in (4, 16, 64, 6):
-                dwt.set_option("fuse2", tp)
-                a = dwt.DeviceImage(h, w).upload(img)
-                b = dwt.DeviceImage(h, w).upload(np.zeros_like(img))
-                j = dwt._fwd(wid, a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, levels, 0, 0, "fwd")
-                got = b.download(dt)
-                assert j == jw
-                if not np.array_equal(bits(got), bits(want)):
-                    bad = np.argwhere(bits(got) != bits(want))
-                    raise AssertionError(f"{wname} {h}x{w} J={levels} tp={tp}: {len(bad)} differ, first {bad[:4].tolist()}, "
-                                         f"rows {bad[:,0].min()}..{bad[:,0].max()} cols {bad[:,1].min()}..{bad[:,1].max()}")
-                a.free()
-                b.free()
-        # batch + automatic tile height on an image large enough for it
-        n, nb = 4096, 4  # 9 x 64 x 4 tiles of 16 pairs: enough for the automatic mode to engage
-        rng = np.random.default_rng(5)
-        imgs = np.stack([rand_img(rng, n, n, dt) for _ in range(nb)])
-        src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
-        dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
-        assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
-        dwt.set_option("fuse2", 1)
-        dwt.prof_enable(2)
-        dwt.transform2d_batch(wname, 0, src, dst, n * n * 4, nb, n * 4, n, n, 5)
-        _, launches = dwt.prof_read_levels(6)
-        dwt.prof_enable(0)
-        assert launches[0] == 1 and launches[1] == 0, f"the two-level sweep did not run: launches per level {launches}"
-        out = np.empty_like(imgs)
-        assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
-        for k in range(nb):
-            want = imgs[k].copy()
-            oracle.fwd(ff, want, 5)
-            assert np.array_equal(bits(out[k]), bits(want)), k
-        dwt.lib.dwt_hip_free(src)
-        dwt.lib.dwt_hip_free(dst)
-    finally:
-        dwt.set_option("fuse2", 0)
-        dwt.set_option("fuse2_pc", 1)
-
-
 def test_device_side_conv_show_and_compare(dwt):
     """dwt_hip_conv_show / dwt_hip_compare: the view and the comparison of examples/simple
     (src/libdwt.c:21075, 1593) on images that stay in HBM."""

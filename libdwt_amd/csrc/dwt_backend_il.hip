@@ -108,12 +108,50 @@ static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int
 	return 0;
 }
 
+// Exact border strips for the fused sweep.  The fused level finishes the rows before the
+// columns; the reference's phase order (rows' prolog, columns' prolog, rows' core, columns'
+// core, rows' epilog, columns' epilog) rounds differently only where a column phase runs
+// BEFORE a row phase that touches the same coefficients: the rows the columns' prolog reaches
+// (0 .. 7, forward and inverse) and the columns the rows' epilog updates (the last 5).  Both
+// strips are recomputed from the level's input in the reference's order (k_il_strip, one launch
+// for both) and written over the sweep's result and over the dense low-pass copy the next level reads.
+//   in_even: rows 0, 2, 4, ... of the level input when they live packed in a buffer of their own
+static int il_exact_strips(Wavelet w, bool inverse, Img in, const Img *in_even, Img out, int lx, int ly, float *ll, long ll_pitch)
+{
+	const int K = w == kCdf53SNew ? 2 : 4;
+	IlStripArgs a;
+	// with packed even rows, `in` holds the image's odd rows at their place (row y at y * pitch)
+	a.in = (const float *)in.p;
+	a.in_pitch = in.sx / 4;
+	a.in_even = in_even ? (const float *)in_even->p : nullptr;
+	a.even_pitch = in_even ? in_even->sx / 4 : 0;
+	a.out = (float *)out.p;
+	a.out_pitch = out.sx / 4;
+	a.ll = inverse ? nullptr : ll;
+	a.ll_pitch = ll_pitch;
+	a.lx = lx;
+	a.ly = ly;
+	for (int phase = 1; phase <= 3; phase++) {
+		il_phase_ranges(lx, K, inverse, phase, &a.rph[phase - 1]);
+		il_phase_ranges(ly, K, inverse, phase, &a.cph[phase - 1]);
+	}
+	a.n_top = 0;
+	hipError_t e = launch_il_strip(w == kCdf97SFma ? kCdf97S : w, inverse, a, g.stream);
+	if (e != hipSuccess)
+		return fail("interleaved exact strip launch failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
 // one level on dense images with a common pitch: rows completely, then columns
 static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
 	const Img *even_rows = nullptr, int dirs = 3)
 {
 	// dirs: bit 0 rows, bit 1 columns (fdwt2h1_* / fdwt2v1_* lift one direction only: line passes)
-	const bool fused = dirs == 3 && !g.force_generic && lx >= 2 && ly >= 2 && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
+	// phase-ordered wavelets: the fused sweep plus exact border strips needs room for the strips;
+	// smaller levels take the exact phase passes for the whole level (below)
+	const bool phased_small = il_is_phased(w) && w != kCdf97SFma && !scale_single && (lx < 64 || ly < 64);
+	const bool fused = dirs == 3 && !g.force_generic && !(phased_small && !even_rows) && lx >= 2 && ly >= 2 &&
+		(((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
 	if (even_rows && !fused)
 		return fail("internal: split rows need the fused sweep");
 	if (fused) {
@@ -136,12 +174,15 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 		}
 		if (e != hipSuccess)
 			return fail("interleaved sweep launch failed: %s", hipGetErrorString(e));
+		// the reference's phase order, where it rounds differently from rows-then-columns
+		if (il_is_phased(w) && w != kCdf97SFma && !scale_single)
+			return il_exact_strips(w, inverse, in, even_rows, out, lx, ly, inverse ? nullptr : ll, ll_pitch);
 		return 0;
 	}
 	// generic.  The phase-ordered entries reproduce the reference's order exactly when the
 	// generic path was asked for (accel 1); tiny levels of the fused path and the 5/3 _inplace_
 	// pair (rows, then columns in the reference too) take two exact line passes.
-	if (dirs == 3 && g.force_generic && il_is_phased(w) && !scale_single) {
+	if (dirs == 3 && (g.force_generic || phased_small) && il_is_phased(w) && !scale_single) {
 		if (il_level_phased(w, inverse, in, out, lx, ly))
 			return 1;
 		if (ll && !inverse) {
@@ -287,7 +328,8 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 	// rows from a packed copy that carries the reconstructed LL band (one compose pass).  In
 	// place the sweep must not read what it overwrites: its whole input is built in the staging
 	// image (odd rows copied, even rows composed) and the sweep writes the caller's image.
-	const bool split = !alias && !g.force_generic && L[0].lx >= 2 && L[0].ly >= 2;
+	const bool phased_small = il_is_phased(w) && w != kCdf97SFma && !scale_single && (L[0].lx < 64 || L[0].ly < 64);
+	const bool split = !alias && !g.force_generic && !phased_small && L[0].lx >= 2 && L[0].ly >= 2;
 	if (split) {
 		const Img even{stage.p, stage.sx, 4}; // (siy+1)/2 packed rows
 		e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)even.p, even.sx / 4, six, siy, pyramid(true, 2), g.stream, true);

@@ -118,8 +118,29 @@ struct IlPhase {
 	int lo[4], hi[4];
 	int sc_lo, sc_hi;
 };
+// k_lo / k_hi: only the coefficient pairs k_lo .. k_hi-1 of every line are computed and written
+// (k_hi < 0: to the end of the line) -- the exact border strips of the fused interleaved path.
 hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, long line_stride, long elem_stride,
-	int n_lines, int N, bool lanes_along_lines, const IlPhase &ph, hipStream_t s);
+	int n_lines, int N, bool lanes_along_lines, const IlPhase &ph, hipStream_t s, int k_lo = 0, int k_hi = -1);
+
+// The two exact border strips of a fused interleaved level (k_il_strip, one launch): the level's input (odd rows at
+// `in`, even rows there too or packed at `in_even`), the sweep's output `out` it corrects, the
+// optional dense low-pass copy `ll`; pitches in ELEMENTS; rph / cph: the prolog, core and epilog
+// ranges of the row (N = lx) and column (N = ly) transforms.
+struct IlStripArgs {
+	const float *in;
+	long in_pitch;
+	const float *in_even;
+	long even_pitch;
+	float *out;
+	long out_pitch;
+	float *ll;
+	long ll_pitch;
+	int lx, ly;
+	int n_top; // set by the launcher: workgroups of the top strip (the rest take the right strip)
+	IlPhase rph[3], cph[3];
+};
+hipError_t launch_il_strip(Wavelet w, bool inverse, IlStripArgs a, hipStream_t s);
 
 // Interleaved (in-place lifting) layout, multi-level: the dense per-level images of the
 // levels 1..J-1 (level j has ceil(W/2^j) x ceil(H/2^j) samples and lives on the stride-2^j

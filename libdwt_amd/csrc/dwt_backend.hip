@@ -739,6 +739,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.vol.fused = value;
 	else if (!strcmp(name, "vol_swizzle"))
 		g.vol.swizzle = value;
+	else if (!strcmp(name, "vol_rows"))
+		g.vol.rows = value;
 	else if (!strcmp(name, "pipeline"))
 		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else
@@ -772,6 +774,8 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.wave_horiz_inv;
 	if (!strcmp(name, "vol_swizzle"))
 		return g.vol.swizzle;
+	if (!strcmp(name, "vol_rows"))
+		return g.vol.rows;
 	if (!strcmp(name, "pipeline"))
 		return g.pipeline;
 	if (!strcmp(name, "fma"))

@@ -62,6 +62,23 @@ static __device__ __forceinline__ void lds_read4(unsigned a0, unsigned a1, unsig
 		: "memory");
 }
 
+// Split form for software pipelines: issue three reads now, consume them after lds_arrived3<N>
+// ("all but the N newest LDS operations of this wave are done"; the operands pass through the
+// wait statement so that no use can be scheduled above it).
+static __device__ __forceinline__ void lds_issue3(unsigned a0, unsigned a1, unsigned a2, u4 &r0, u4 &r1, u4 &r2)
+{
+	asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5"
+		: "=&v"(r0), "=&v"(r1), "=&v"(r2)
+		: "v"(a0), "v"(a1), "v"(a2)
+		: "memory");
+}
+
+template <int N>
+static __device__ __forceinline__ void lds_arrived3(u4 &r0, u4 &r1, u4 &r2)
+{
+	asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
+}
+
 static __device__ __forceinline__ void lds_read2x3(unsigned a0, unsigned a1, unsigned a2, u2 &r0, u2 &r1, u2 &r2)
 {
 	asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"

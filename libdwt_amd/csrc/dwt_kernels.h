@@ -81,6 +81,7 @@ struct VolTuning {
 	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
 	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes
 	int swizzle = 1;    // fused level: hand contiguous runs of tiles to one XCD
+	int rows = 8;       // fused level: output rows per wave, 8 (measured best) or 6 (two workgroups per CU)
 };
 
 // z pass of the 3-D path: CDF 9/7 float along the slice axis of an interleaved volume,

@@ -773,6 +773,11 @@ static int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batc
 	// levels of a few million samples are latency bound -- a wave's sweep is a serial
 	// chain -- and want the shortest tiles so that all CUs work at once.
 	const int Hd = (H + 1) / 2;
+	// (round 2, single-image sweep of 1024^2 / 512^2 / 256^2: 2 pairs 8.7 / 8.3 / 8.0 us against
+	// 10.4 / 10.0 / 9.5 us with 4 pairs -- a launch this small is one round of waves whatever the
+	// tile height, and its duration is the length of one wave's serial chain)
+	if (!inverse && (long)W * H * batch <= (1L << 20))
+		return 2;
 	if ((long)W * H * batch <= (4L << 20))
 		return 4;
 	const long ntx = (W + 64 * cpt - 1) / (64 * cpt);

@@ -216,14 +216,26 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 // march.  The intermediate volume of the two-pass path never exists: 8 B per voxel (+ 25 %
 // halo rows, + z warm-up) instead of 16.  Same arithmetic and operand order as
 // k_fwd_sweep / k_vol_z, hence the same bits.
-template <int NT>
-__global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
+// RW: output rows per wave (the tile has 4 RW rows).  8 rows hold 128 + 32 + 32 + 60 live values
+// per lane in the vertical / z phase: 304 registers (48 of them accumulator registers), ONE wave
+// per SIMD, one workgroup per CU.  6 rows fit 256 registers and 64 KiB of LDS -- two workgroups per
+// CU -- but lift 31/24 instead of 39/32 input rows per output row: measured slower (1024^3: 2.43
+// against 2.12-2.21 ms), because the level is bound by VALU issue (a wave64 fp32 instruction holds
+// the SIMD for 4 cycles; 557 M of them per launch = 0.95 ms per SIMD), not by latency.  Built,
+// measured and taken out again in round 2: the z state's deeper planes in LDS and the vertical
+// window in two halves (no accumulator-register moves, 249 registers): 2.24-2.28 ms, no gain.
+template <int NT, int RW>
+__global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
 {
 	using W = Cdf97S;
-	// the 8 output rows of a wave need x-lifted rows -4 .. +10 around its first row: the tile's
-	// 32 rows need 39 input rows; wave w stages rows w, w+4, ... (10, 10, 10, 9 of them)
-	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, TY = 32, NR = TY + 2 * K - 1, RPW = (NR + 3) / 4;
+	// the RW output rows of a wave need x-lifted rows -4 .. RW+2 around its first row: a tile of
+	// 32 rows needs 39 input rows; wave w stages rows w, w+4, ... (10, 10, 10, 9 of them)
+	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, TY = 4 * RW, NR = TY + 2 * K - 1, RPW = (NR + 3) / 4;
+	constexpr int NV = RW + 2 * K - 1; // slab rows a wave's vertical lift reads
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
+	// bit 2: the halo columns (lines the x-neighbour tile streams as its own) with the default
+	// cache policy, so that whichever of the two comes second can hit in L2
+	constexpr int kHaloAux = (NT & 4) ? 0 : kLdAux;
 	constexpr bool kNtStore = (NT & 1) != 0;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = threadIdx.x & 63;
@@ -250,6 +262,9 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
 	// tiles that overhang the volume (or unaligned volumes) are staged column by column
 	const bool full = vec_ok && c0 + TW <= a.nx;
+	// interior tiles fetch each 4-column halo as ONE aligned 16 B piece (two lanes) instead of four
+	// 4 B ones; tiles at the volume's x borders reflect column by column
+	const bool halo16 = full && c0 >= 4 && c0 + TW + 4 <= a.nx;
 	int colmap[CPT];
 #pragma unroll
 	for (int i = 0; i < CPT; i++)
@@ -270,17 +285,21 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 					for (int e = 0; e < CPT; e++)
 						dma4<kLdAux>(grow + colmap[e], lrow + e * 256);
 				}
-				if (lane < 8)
-					dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
+				if (halo16) {
+					if (lane < 2)
+						dma16<kHaloAux>(grow + (lane == 0 ? c0 - 4 : c0 + TW), lrow + TW * 4);
+				} else if (lane < 8) {
+					dma4<kHaloAux>(grow + halo_col, lrow + TW * 4);
+				}
 			}
 		}
 	};
 
-	float st[K][8][CPT], ra[8][CPT];
+	float st[K][RW][CPT], ra[RW][CPT];
 #pragma unroll
 	for (int s = 0; s < K; s++)
 #pragma unroll
-		for (int r = 0; r < 8; r++)
+		for (int r = 0; r < RW; r++)
 #pragma unroll
 			for (int e = 0; e < CPT; e++)
 				st[s][r][e] = 0.f;
@@ -288,27 +307,37 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 	issue(0);
 	for (int t = 0; t < n_slices; t++) {
 		DWT_WAIT_VMCNT(0); // this slice's rows have landed (and the previous stores are out)
-		// horizontal lift of this wave's rows, parked in the shared slab
+		// horizontal lift of this wave's rows, parked in the shared slab.  Software pipeline: the LDS
+		// reads of row i+1 are in flight while row i is lifted (counted lgkmcnt: LDS operations of
+		// a wave complete in order, so "all but the newest three" means row i has arrived).
+		{
+			const unsigned own0 = ring_off + lane * CPT * 4;
+			const unsigned la0 = lane == 0 ? ring_off + TW * 4 : own0 - 16;
+			const unsigned ra0 = lane == 63 ? ring_off + TW * 4 + 16 : own0 + CPT * 4;
+			u4 L[2], O[2], R[2];
+			lds_issue3(la0, own0, ra0, L[0], O[0], R[0]);
 #pragma unroll
-		for (int i = 0; i < RPW; i++) {
-			if (wv + 4 * i < NR) {
-				const unsigned base = ring_off + (unsigned)i * RS * 4;
-				const unsigned own = base + lane * CPT * 4;
-				const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
-				const unsigned ra_ = lane == 63 ? base + TW * 4 + 16 : own + CPT * 4;
-				u4 L4, O0, R4;
-				lds_read3(la, own, ra_, L4, O0, R4);
-				float x[CPT + 2 * K];
-#pragma unroll
-				for (int e = 0; e < K; e++) {
-					x[e] = from_bits<float>(L4[e]);
-					x[K + e] = from_bits<float>(O0[e]);
-					x[K + CPT + e] = from_bits<float>(R4[e]);
+			for (int i = 0; i < RPW; i++) {
+				const int b = i & 1;
+				if (i + 1 < RPW) {
+					lds_issue3(la0 + (i + 1) * RS * 4, own0 + (i + 1) * RS * 4, ra0 + (i + 1) * RS * 4, L[b ^ 1], O[b ^ 1], R[b ^ 1]);
+					lds_arrived3<3>(L[b], O[b], R[b]);
+				} else {
+					lds_arrived3<0>(L[b], O[b], R[b]);
 				}
-				lift_fwd_regs<W, CPT + 2 * K>(x);
-				const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
-					to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
-				lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
+				if (wv + 4 * i < NR) { // (the last wave stages one row fewer: its read of that slot is harmless)
+					float x[CPT + 2 * K];
+#pragma unroll
+					for (int e = 0; e < K; e++) {
+						x[e] = from_bits<float>(L[b][e]);
+						x[K + e] = from_bits<float>(O[b][e]);
+						x[K + CPT + e] = from_bits<float>(R[b][e]);
+					}
+					lift_fwd_regs<W, CPT + 2 * K>(x);
+					const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
+						to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
+					lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
+				}
 			}
 		}
 		// the staging rows are consumed: the next slice's DMA flies during the rest of the iteration
@@ -316,38 +345,36 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 			issue(t + 1);
 		wg_barrier_lds(); // the slab is complete
 
-		// vertical lift: slab rows 8 wv .. 8 wv + 14 give this wave's 8 output rows
-		u4 v[15];
+		// vertical lift: slab rows RW wv .. RW wv + NV - 1 give this wave's RW output rows
+		u4 v[NV];
 		{
-			const unsigned vb = slab_off + (unsigned)(8 * wv) * TW * 4 + lane * 16;
-			asm volatile(
-				"ds_read_b128 %0, %15\n\tds_read_b128 %1, %15 offset:1024\n\tds_read_b128 %2, %15 offset:2048\n\tds_read_b128 %3, %15 offset:3072\n\t"
-				"ds_read_b128 %4, %15 offset:4096\n\tds_read_b128 %5, %15 offset:5120\n\tds_read_b128 %6, %15 offset:6144\n\tds_read_b128 %7, %15 offset:7168\n\t"
-				"ds_read_b128 %8, %15 offset:8192\n\tds_read_b128 %9, %15 offset:9216\n\tds_read_b128 %10, %15 offset:10240\n\tds_read_b128 %11, %15 offset:11264\n\t"
-				"ds_read_b128 %12, %15 offset:12288\n\tds_read_b128 %13, %15 offset:13312\n\tds_read_b128 %14, %15 offset:14336\n\t"
-				"s_waitcnt lgkmcnt(0)\n\ts_barrier"
-				: "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-				  "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14])
-				: "v"(vb)
-				: "memory"); // the barrier: every wave has read the slab, the next slice may overwrite it
+			const unsigned vb = slab_off + (unsigned)(RW * wv) * TW * 4 + lane * 16;
+#pragma unroll
+			for (int j = 0; j < NV; j++)
+				asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[j]) : "v"(vb), "n"(j * TW * 4) : "memory");
+			// the barrier: every wave has read the slab, the next slice may overwrite it
+			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+			for (int j = 0; j < NV; j++)
+				asm volatile("" : "+v"(v[j])); // uses of v[j] stay below the wait
 		}
-		float cur[8][CPT];
+		float cur[RW][CPT];
 #pragma unroll
 		for (int e = 0; e < CPT; e++) {
-			float col[15];
+			float col[NV];
 #pragma unroll
-			for (int j = 0; j < 15; j++)
+			for (int j = 0; j < NV; j++)
 				col[j] = from_bits<float>(v[j][e]);
-			lift_fwd_regs<W, 15>(col);
+			lift_fwd_regs<W, NV>(col);
 #pragma unroll
-			for (int r = 0; r < 8; r++)
+			for (int r = 0; r < RW; r++)
 				cur[r][e] = W::fwd_scale(r & 1, col[K + r]);
 		}
 
 		// z: slices arrive as (2q-1, 2q); the odd one waits in registers for its partner
 		if (!(t & 1)) {
 #pragma unroll
-			for (int r = 0; r < 8; r++)
+			for (int r = 0; r < RW; r++)
 #pragma unroll
 				for (int e = 0; e < CPT; e++)
 					ra[r][e] = cur[r][e];
@@ -356,7 +383,7 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 		const int it = t >> 1;
 		const int k = A + it - K;
 #pragma unroll
-		for (int r = 0; r < 8; r++) {
+		for (int r = 0; r < RW; r++) {
 			float o0[CPT], o1[CPT];
 #pragma unroll
 			for (int e = 0; e < CPT; e++) {
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(256) void k_vol_fwd_fused(VolFusedArgs a, int tile_
 				st[2][r][e] = s1n;
 				st[3][r][e] = d2n;
 			}
-			const int y = y0 + 8 * wv + r;
+			const int y = y0 + RW * wv + r;
 			if (it >= K && y < a.ny) {
 				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + c;
 				const bool hz = 2 * k + 1 < a.nz;
@@ -416,13 +443,25 @@ static bool vol_fused_vec_ok(const VolFusedArgs &a)
 		(!a.lll || (((uintptr_t)a.lll & 7) == 0 && a.lll_sy % 2 == 0 && a.lll_sz % 2 == 0));
 }
 
+template <int NT, int RW>
+static hipError_t vol_fused_launch(const VolFusedArgs &a, int tp, int ntx, int nty, int nzt, int swz, hipStream_t s)
+{
+	constexpr int NR = 4 * RW + 7;
+	const size_t lds = (size_t)NR * (256 + 8) * 4 + (size_t)NR * 256 * 4;
+	if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<NT, RW>, lds))
+		return e;
+	k_vol_fwd_fused<NT, RW><<<dim3(ntx * nty * nzt), 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
+	return hipGetLastError();
+}
+
 hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s)
 {
 	if (a.in == a.out || a.nx < 2 || a.ny < 2 || a.nz < 2)
 		return hipErrorInvalidValue;
+	const int rw = vt.rows == 6 ? 6 : 8;
 	const int Zd = (a.nz + 1) / 2;
-	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
-	// z lines are split until the 512 workgroup slots (two per CU) are filled, but not below 32
+	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 4 * rw - 1) / (4 * rw);
+	// z lines are split until the workgroup slots (two per CU) are filled, but not below 32
 	// slice pairs per march: the 8-slice warm-up is 12 % there (512^3: 32 pairs 0.31 ms, 16
 	// pairs 0.37, 64 pairs -- half the CUs idle -- 0.55)
 	int tp = 128;
@@ -433,19 +472,13 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	const int nzt = (Zd + tp - 1) / tp;
 	if ((long)ntx * nty * nzt > 0x7fffffffL)
 		return hipErrorInvalidValue;
-	const size_t lds = (size_t)39 * (256 + 8) * 4 + (size_t)39 * 256 * 4;
-	dim3 grid(ntx * nty * nzt);
 	const int swz = vt.swizzle;
-	if (vt.nt < 0 || (vt.nt & 1)) {
-		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<3>, lds))
-			return e;
-		k_vol_fwd_fused<3><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
-	} else {
-		if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<2>, lds))
-			return e;
-		k_vol_fwd_fused<2><<<grid, 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
-	}
-	return hipGetLastError();
+	const int nt = vt.nt == 7 ? 7 : (vt.nt < 0 || (vt.nt & 1)) ? 3 : 2;
+	if (rw == 8)
+		return nt == 7 ? vol_fused_launch<7, 8>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 8>(a, tp, ntx, nty, nzt, swz, s)
+		                                                                             : vol_fused_launch<2, 8>(a, tp, ntx, nty, nzt, swz, s);
+	return nt == 7 ? vol_fused_launch<7, 6>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 6>(a, tp, ntx, nty, nzt, swz, s)
+	                                                                             : vol_fused_launch<2, 6>(a, tp, ntx, nty, nzt, swz, s);
 }
 
 __global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ src, long s_sx, long s_sy, long s_sz,

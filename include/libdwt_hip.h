@@ -15,10 +15,13 @@
  * crosses PCIe).  The double-precision wavelets run on the exact line-pass kernels
  * (two passes per level); the fused sweeps exist for the 32-bit types.
  *
- * Threading: one context per process, not reentrant -- like the reference, whose 2-D
- * drivers mutate process globals (src/libdwt.c:12839-12862).  Calls are asynchronous for
- * device pointers (stream-ordered on the stream given to dwt_hip_set_stream) and
- * synchronous for host pointers.
+ * Threading: one context PER HOST THREAD (device binding, stream, workspace, options), so
+ * calls from different threads never share scratch memory -- unlike the reference, whose 2-D
+ * drivers mutate process globals (src/libdwt.c:12839-12862).  One process drives several
+ * GPUs with one thread per device: each thread calls dwt_hip_set_device(d) first.  Options
+ * (dwt_hip_set_option, dwt_util_set_accel) and dwt_hip_set_stream are per thread as well.
+ * Calls are asynchronous for device pointers (stream-ordered on the stream given to
+ * dwt_hip_set_stream) and synchronous for host pointers.
  *
  * Error rule: every int function returns 0 on success and non-zero on failure with
  * a message retrievable by dwt_hip_last_error().  There is NO CPU fallback: without
@@ -48,6 +51,11 @@ enum dwt_hip_wavelet {
  * (src/libdwt.c:19158-19181). */
 int dwt_hip_init(void);
 void dwt_hip_finish(void);
+/* Bind the CALLING THREAD's context to a device (0 .. dwt_hip_device_count()-1); a thread that
+ * never calls it uses DWT_HIP_DEVICE / LOCAL_RANK / 0.  Rebinding frees the thread's workspace on
+ * the old device.  dwt_hip_get_device: the bound device, -1 before the first use. */
+int dwt_hip_set_device(int device);
+int dwt_hip_get_device(void);
 int dwt_hip_device_count(void);
 const char *dwt_hip_device_name(void);
 const char *dwt_hip_last_error(void);

@@ -59,6 +59,9 @@ for _n, _sig in (("dwt_cdf97_2f_s", _FWD), ("dwt_cdf97_2i_s", _INV), ("dwt_cdf97
 
 lib.dwt_hip_init.restype = _I
 lib.dwt_hip_device_count.restype = _I
+lib.dwt_hip_set_device.argtypes = [_I]
+lib.dwt_hip_set_device.restype = _I
+lib.dwt_hip_get_device.restype = _I
 lib.dwt_hip_device_name.restype = C.c_char_p
 lib.dwt_hip_last_error.restype = C.c_char_p
 lib.dwt_hip_set_stream.argtypes = [_P]
@@ -153,6 +156,15 @@ def dwt_util_get_accel():
 
 def device_count():
     return lib.dwt_hip_device_count()
+
+
+def set_device(device):
+    """Bind the calling thread's context to `device` (one host thread per GPU drives several GPUs)."""
+    _check(lib.dwt_hip_set_device(int(device)), "dwt_hip_set_device")
+
+
+def get_device():
+    return lib.dwt_hip_get_device()
 
 
 def device_name():

@@ -19,6 +19,7 @@ using namespace dwt;
 struct Ctx {
 	bool inited = false;
 	int device = 0;
+	int want_device = -1; // dwt_hip_set_device: the device this thread's context binds to (-1: environment / 0)
 	hipStream_t stream = nullptr;
 	char devname[256] = {0};
 	// workspace
@@ -65,8 +66,13 @@ struct Ctx {
 	int prof_level_n[16] = {0};
 };
 
-extern Ctx g;
-extern bool g_elems_are_32bit; // set per call: the fused sweeps exist for 4-byte elements only
+// One context PER HOST THREAD: its own device binding, stream, workspace and options.  Calls from
+// different threads therefore never share scratch buffers (the library is reentrant across
+// threads), and one process drives several GPUs with one thread per device: each thread calls
+// dwt_hip_set_device(d) first ("single process, 8 devices, one host thread per
+// device").  Options set through dwt_hip_set_option / dwt_util_set_accel are per thread too.
+extern thread_local Ctx g;
+extern thread_local bool g_elems_are_32bit; // set per call: the fused sweeps exist for 4-byte elements only
 
 int fail(const char *fmt, ...);
 

@@ -24,7 +24,7 @@
 
 namespace dwtb {
 
-Ctx g;
+thread_local Ctx g;
 thread_local char g_err[512] = "";
 
 int fail(const char *fmt, ...)
@@ -334,7 +334,7 @@ int ensure_ll(const Geom &ge, int batch)
 	return 0;
 }
 
-bool g_elems_are_32bit = true;
+thread_local bool g_elems_are_32bit = true;
 
 bool level_fused_ok(const Geom &ge, int j)
 {
@@ -641,8 +641,13 @@ int dwt_hip_init(void)
 	const char *env = getenv("DWT_HIP_DEVICE");
 	if (!env)
 		env = getenv("LOCAL_RANK");
-	if (env)
+	if (g.want_device >= 0) {
+		if (g.want_device >= n)
+			return fail("dwt_hip_set_device(%d): the process sees %d device(s)", g.want_device, n);
+		dev = g.want_device;
+	} else if (env) {
 		dev = atoi(env) % n;
+	}
 	HIP_TRY(hipSetDevice(dev));
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -652,6 +657,24 @@ int dwt_hip_init(void)
 	g.device = dev;
 	g.inited = true;
 	return 0;
+}
+
+int dwt_hip_set_device(int device)
+{
+	if (device < 0)
+		return fail("dwt_hip_set_device(%d): bad device index", device);
+	if (g.inited && g.device != device) {
+		// rebinding: this thread's workspace lives on the old device
+		dwt_hip_finish();
+		g.inited = false;
+	}
+	g.want_device = device;
+	return check_inited();
+}
+
+int dwt_hip_get_device(void)
+{
+	return g.inited ? g.device : -1;
 }
 
 void dwt_hip_finish(void)
@@ -1021,7 +1044,7 @@ int dwt_hip_compare(int is_int, const void *ptr1, const void *ptr2, int stride_x
 		fail("device images need stride_y == 4 and stride_x a multiple of 4");
 		return -1;
 	}
-	static unsigned *counter = nullptr;
+	static thread_local unsigned *counter = nullptr; // per thread, like the context (and its device)
 	if (!counter && hipMalloc((void **)&counter, sizeof(unsigned)) != hipSuccess) {
 		fail("hipMalloc failed");
 		return -1;

@@ -65,7 +65,7 @@ if "TCC_HIT_sum" in pmc:
 json.dump(summary, open(f"{out}/{tag}_pmc_level0.json", "w"), indent=1)
 
 with open(f"{out}/{tag}_summary.md", "w") as f:
-    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu` "
+    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-single` "
             f"(+ separate `--pmc` passes), MI355X, see scripts/profile_gpu.sh.\n\n## per-kernel (kernel-trace --stats)\n\n")
     f.write("| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
     for r in keep:

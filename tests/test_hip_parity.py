@@ -408,6 +408,52 @@ def test_config4_per_gpu_shape_32x4096(dwt, oracle):
         one.free()
 
 
+def test_threads_have_their_own_context(dwt, oracle):
+    """One context per host thread: four threads transform different images at the same time (device
+    pointers and host pointers, different sizes, so their workspaces differ) and every result is
+    the oracle's; dwt_hip_set_device binds a thread, an out-of-range device is refused."""
+    import threading
+
+    assert dwt.get_device() == 0
+    shapes = [(1024, 1024), (768, 1280), (2048, 512), (640, 640)]
+    results, errors = {}, []
+
+    def work(i):
+        try:
+            dwt.set_device(0)
+            h, w = shapes[i]
+            rng = np.random.default_rng(100 + i)
+            for rep in range(6):
+                img = rng.random((h, w), dtype=np.float32)
+                want = img.copy()
+                j = oracle.fwd("cdf97_2f_s", want, 4)
+                if rep % 2:
+                    got = img.copy()
+                    assert dwt.dwt_cdf97_2f_s(got, got.strides[0], 4, w, h, w, h, 4) == j
+                else:
+                    d = dwt.DeviceImage(h, w).upload(img)
+                    assert dwt.dwt_cdf97_2f_s(d.ptr, d.stride_x, 4, w, h, w, h, 4) == j
+                    got = d.download(np.float32)
+                    d.free()
+                if not np.array_equal(bits(got), bits(want)):
+                    errors.append((i, rep))
+            results[i] = True
+            dwt.dwt_util_finish()  # this thread's workspace
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 4
+    with pytest.raises(dwt.DwtError):
+        dwt.set_device(dwt.device_count() + 3)
+    dwt.set_device(0)
+
+
 def test_linearity_and_constant(dwt):
     n = 2048
     rng = np.random.default_rng(5)

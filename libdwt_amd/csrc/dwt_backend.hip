@@ -434,15 +434,28 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			ll_in = -1;
 			cur = dst;
 		}
-		if (!skip_single(w) || Wo > 1) {
-			if (generic_pass(w, false, true, cur, dst, Wo, Ho, Ho, Wi, Wd))
+		if (Wi == Wo && Hi == Ho && Wo >= 2 && Ho >= 2) {
+			// dense frame: each pass writes every element of the level's frame, so the two passes
+			// ping-pong through the staging image (rows: image -> stage, columns: stage -> image)
+			// instead of each staging and copying back a frame of its own: 4 instead of 12 frame
+			// transfers per level (the double-precision drivers and accel 1 live on these passes)
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 				return 1;
-			cur = dst; // src/libdwt.c:12709
-		}
-		if (!skip_single(w) || Ho > 1) {
-			if (generic_pass(w, false, false, cur, dst, Wo, Ho, Wo, Hi, Hd))
+			const Img S{(char *)g.stage_img, dst.sx, dst.es};
+			if (generic_pass(w, false, true, cur, S, Wo, Ho, Ho, Wi, Wd) || generic_pass(w, false, false, S, dst, Wo, Ho, Wo, Hi, Hd))
 				return 1;
-			cur = dst; // src/libdwt.c:12742
+			cur = dst;
+		} else {
+			if (!skip_single(w) || Wo > 1) {
+				if (generic_pass(w, false, true, cur, dst, Wo, Ho, Ho, Wi, Wd))
+					return 1;
+				cur = dst; // src/libdwt.c:12709
+			}
+			if (!skip_single(w) || Ho > 1) {
+				if (generic_pass(w, false, false, cur, dst, Wo, Ho, Wo, Hi, Hd))
+					return 1;
+				cur = dst; // src/libdwt.c:12742
+			}
 		}
 		if (zero_padding) {
 			// dwt_zero_padding_f_stride_* (src/libdwt.c:12079-12131) over rows then columns
@@ -583,6 +596,16 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				return 1;
 			ll_in = -1;
 		}
+		if (Wi == Wo && Hi == Ho && Wo >= 2 && Ho >= 2) {
+			// dense frame: ping-pong through the staging image, as in the forward driver
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
+				return 1;
+			const Img S{(char *)g.stage_img, dst.sx, dst.es};
+			const bool rows_first = !cols_first;
+			if (generic_pass(w, true, rows_first, dst, S, Wo, Ho, rows_first ? Ho : Wo, rows_first ? Wi : Hi, rows_first ? Ws : Hs) ||
+				generic_pass(w, true, !rows_first, S, dst, Wo, Ho, rows_first ? Wo : Ho, rows_first ? Hi : Wi, rows_first ? Hs : Ws))
+				return 1;
+		} else
 		for (int pass = 0; pass < 2; pass++) {
 			const bool rows = cols_first ? (pass == 1) : (pass == 0);
 			if (rows) {

@@ -12,8 +12,8 @@
  * memory (any byte strides; staged through HBM, result copied back) or device
  * memory (hipMalloc / dwt_hip_malloc / a torch tensor's data_ptr; requires
  * stride_y == element size and stride_x a multiple of it; transformed in HBM, nothing
- * crosses PCIe).  The double-precision wavelets run on the exact line-pass kernels
- * (two passes per level); the fused sweeps exist for the 32-bit types.
+ * crosses PCIe).  Every wavelet runs on fused tile sweeps (float, int32 and, since round 2,
+ * double); the exact line-pass kernels serve sparse frames, single-line directions and accel 1.
  *
  * Threading: one context PER HOST THREAD (device binding, stream, workspace, options), so
  * calls from different threads never share scratch memory -- unlike the reference, whose 2-D

@@ -55,6 +55,7 @@ struct Ctx {
 	VolTuning vol;
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
+	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
 	// profiling
 	int prof_on = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -324,11 +324,11 @@ void swap_lane(Ctx::Lane &l)
 
 long ll_pitch_elems(int w) { return align_up(w, 4); }
 
-int ensure_ll(const Geom &ge, int batch)
+int ensure_ll(const Geom &ge, int batch, int es)
 {
 	for (int k = 0; k < 2; k++) {
 		const int w = ge.Wo(k + 1), h = ge.Ho(k + 1);
-		if (grow(&g.ll[k], &g.ll_bytes[k], (size_t)ll_pitch_elems(w) * h * 4 * batch + 64))
+		if (grow(&g.ll[k], &g.ll_bytes[k], (size_t)ll_pitch_elems(w) * h * es * batch + 64))
 			return 1;
 	}
 	return 0;
@@ -336,9 +336,12 @@ int ensure_ll(const Geom &ge, int batch)
 
 thread_local bool g_elems_are_32bit = true;
 
+// the fused sweeps exist for the 32-bit types and, since round 2, for the double-precision wavelets
+// (dwt_sweep2d_d.hip; option "fused_d" = 0 sends those back to the exact line passes)
 bool level_fused_ok(const Geom &ge, int j)
 {
-	return !g.force_generic && g_elems_are_32bit && ge.Wi(j) == ge.Wo(j) && ge.Hi(j) == ge.Ho(j) && ge.Wo(j) >= 2 && ge.Ho(j) >= 2;
+	return !g.force_generic && (g_elems_are_32bit || g.fused_d) && ge.Wi(j) == ge.Wo(j) && ge.Hi(j) == ge.Ho(j) && ge.Wo(j) >= 2 &&
+		ge.Ho(j) >= 2;
 }
 
 // ---- forward ---------------------------------------------------------------------
@@ -352,7 +355,9 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 	const int J = *jp;
 	if (J == 0)
 		return 0;
-	if (ensure_ll(ge, batch))
+	const int es = elem_size(w);
+	const bool dbl = es == 8;
+	if (ensure_ll(ge, batch, es))
 		return 1;
 
 	// where the running LL band lives: -1 = in `cur` image (src before level 0, dst after), else scratch index
@@ -370,8 +375,8 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			bool detour = false;
 			if (ll_in < 0) {
 				a.in = cur.p;
-				a.in_pitch = cur.sx / 4;
-				a.in_bstride = (cur.p == src.p ? src_bstride : dst_bstride) / 4;
+				a.in_pitch = cur.sx / es;
+				a.in_bstride = (cur.p == src.p ? src_bstride : dst_bstride) / es;
 				detour = (cur.p == dst.p); // reading the image we also write: stage the outputs
 			} else {
 				a.in = g.ll[ll_in];
@@ -385,12 +390,12 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 					return fail("in-place batches are not supported; use distinct src and dst");
 				if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 					return 1;
-				hdst = Img{(char *)g.stage_img, dst.sx};
+				hdst = Img{(char *)g.stage_img, dst.sx, es};
 				h_bstride = 0;
 			}
 			a.out_h = hdst.p;
-			a.h_pitch = hdst.sx / 4;
-			a.h_bstride = h_bstride / 4;
+			a.h_pitch = hdst.sx / es;
+			a.h_bstride = h_bstride / es;
 			// ping-pong: the other buffer than the one read (after a fused pair the parity
 			// of the level no longer tells which one that is); band j+1 fits either for j >= 1
 			const int ll_out = last ? -1 : (ll_in < 0 ? (j & 1) : 1 - ll_in);
@@ -404,7 +409,8 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				a.ll_bstride = a.ll_pitch * Hd;
 			}
 			prof_before(j);
-			hipError_t e = launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
+			hipError_t e = dbl ? launch_fwd_level_d(w, a, g.tune, g.stream)
+			                   : launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
 			prof_after(j);
 			if (e != hipSuccess)
 				return fail("forward level %d launch failed: %s", j, hipGetErrorString(e));
@@ -428,7 +434,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			return fail("batched transforms need dense frames with both sides >= 2 at every level");
 		if (ll_in >= 0) {
 			// bring the LL band back into the image
-			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Wo) * 4};
+			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Wo) * es, es};
 			if (copy_rect(dst, 0, 0, s, 0, 0, Wo, Ho))
 				return 1;
 			ll_in = -1;
@@ -482,7 +488,9 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 			return 1;
 		return 0;
 	}
-	if (ensure_ll(ge, batch))
+	const int es = elem_size(w);
+	const bool dbl = es == 8;
+	if (ensure_ll(ge, batch, es))
 		return 1;
 	const bool cols_first = (w == kCdf53I || w == kCdf97I); // the int inverses undo columns first
 
@@ -506,7 +514,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 			const int Ws = ge.Wo(1), Hs = ge.Ho(1), Wo = ge.Wo(0), Ho = ge.Ho(0);
 			if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 				return 1;
-			Img st{(char *)g.stage_img, dst.sx};
+			Img st{(char *)g.stage_img, dst.sx, es};
 			if (side_fork())
 				return 1;
 			const Rect rc[2] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}};
@@ -525,12 +533,12 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 			a.H = Ho;
 			a.batch = batch;
 			a.in_h = cur.p;
-			a.h_pitch = cur.sx / 4;
-			a.h_bstride = cur_bstride / 4;
+			a.h_pitch = cur.sx / es;
+			a.h_bstride = cur_bstride / es;
 			if (ll_in < 0) {
 				a.in_ll = cur.p;
-				a.ll_pitch = cur.sx / 4;
-				a.ll_bstride = cur_bstride / 4;
+				a.ll_pitch = cur.sx / es;
+				a.ll_bstride = cur_bstride / es;
 			} else {
 				a.in_ll = g.ll[ll_in];
 				a.ll_pitch = ll_pitch_elems(Ws);
@@ -540,8 +548,8 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 			int ll_out = -1;
 			if (last) {
 				a.out = dst.p;
-				a.out_pitch = dst.sx / 4;
-				a.out_bstride = dst_bstride / 4;
+				a.out_pitch = dst.sx / es;
+				a.out_bstride = dst_bstride / es;
 				if (cur.p == dst.p) {
 					// in place: the final level would overwrite subbands it still reads;
 					// move them (right half + bottom-left, and LL if it is still there) aside
@@ -549,7 +557,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 						return fail("in-place batches are not supported; use distinct src and dst");
 					if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 						return 1;
-					Img st{(char *)g.stage_img, dst.sx};
+					Img st{(char *)g.stage_img, dst.sx, es};
 					if (aside_early) {
 						if (side_join()) // the copy started before the deeper levels
 							return 1;
@@ -570,7 +578,8 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				a.out_bstride = a.out_pitch * Ho;
 			}
 			prof_before(j - 1);
-			hipError_t e = launch_inv_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
+			hipError_t e = dbl ? launch_inv_level_d(w, a, g.tune, g.stream)
+			                   : launch_inv_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
 			prof_after(j - 1);
 			if (e != hipSuccess)
 				return fail("inverse level %d launch failed: %s", j, hipGetErrorString(e));
@@ -591,7 +600,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 		cur_bstride = dst_bstride;
 		if (ll_in >= 0) {
 			// a deeper fused level left its result in scratch: bring it back into the image
-			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Ws) * 4};
+			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Ws) * es, es};
 			if (copy_rect(dst, 0, 0, s, 0, 0, Ws, Hs))
 				return 1;
 			ll_in = -1;
@@ -775,6 +784,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.wave_horiz_inv = value;
 	else if (!strcmp(name, "fma"))
 		g.fma = value;
+	else if (!strcmp(name, "fused_d"))
+		g.fused_d = value;
 	else if (!strcmp(name, "vol_cpt"))
 		g.vol.cpt = value;
 	else if (!strcmp(name, "vol_tile_pairs"))
@@ -826,6 +837,8 @@ int dwt_hip_get_option(const char *name)
 		return g.pipeline;
 	if (!strcmp(name, "fma"))
 		return g.fma;
+	if (!strcmp(name, "fused_d"))
+		return g.fused_d;
 	if (!strcmp(name, "vol_cpt"))
 		return g.vol.cpt;
 	if (!strcmp(name, "vol_tile_pairs"))

@@ -62,6 +62,9 @@ struct InvLevelArgs {
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
 
 hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s);
+// the same two sweeps for the double-precision wavelets (dwt_sweep2d_d.hip); pitches in 8-byte ELEMENTS
+hipError_t launch_fwd_level_d(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
+hipError_t launch_inv_level_d(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s);
 // true when launch_inv_level has a fused kernel for this wavelet
 bool have_fused_inverse(Wavelet w);
 

@@ -21,5 +21,11 @@ def t(name, fn, reps=10):
 t(f"cdf97 double fwd {n}^2 J={J} in place", lambda: dwt.dwt_cdf97_2f_d(a, n * 8, 8, n, n, n, n, J))
 t(f"cdf97 double inv {n}^2 J={J} in place", lambda: dwt.dwt_cdf97_2i_d(a, n * 8, 8, n, n, n, n, J))
 t(f"cdf53 double fwd {n}^2 J={J} in place", lambda: dwt.dwt_cdf53_2f_d(a, n * 8, 8, n, n, n, n, J))
+c = torch.empty_like(a)
+t(f"cdf97 double fwd {n}^2 J={J} out of place", lambda: dwt._fwd(dwt.CDF97_D, a, c, n * 8, 8, n, n, n, n, J, 0, 0, "fwd"))
+t(f"cdf97 double inv {n}^2 J={J} out of place", lambda: dwt._inv(dwt.CDF97_D, c, a, n * 8, 8, n, n, n, n, J, 0, 0, "inv"))
+dwt.set_option("fused_d", 0)
+t(f"cdf97 double fwd {n}^2 J={J} in place, line passes", lambda: dwt.dwt_cdf97_2f_d(a, n * 8, 8, n, n, n, n, J))
+dwt.set_option("fused_d", 1)
 b = torch.rand((n, n), device="cuda", dtype=torch.float32)
 t(f"cdf97 float  fwd {n}^2 J={J} in place (for scale)", lambda: dwt.dwt_cdf97_2f_s(b, n * 4, 4, n, n, n, n, J))

@@ -1004,19 +1004,20 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 {
 	if (check_inited())
 		return 1;
-	if (wavelet < 0 || wavelet > 5 || elem_size((Wavelet)wavelet) != 4)
-		return fail("unknown wavelet %d (batches take the 32-bit wavelets)", wavelet);
-	g_elems_are_32bit = true;
+	if (wavelet < 0 || wavelet > 5)
+		return fail("unknown wavelet %d", wavelet);
+	const int es = elem_size((Wavelet)wavelet);
+	g_elems_are_32bit = es == 4;
 	if (!src || !dst || !j || batch < 1 || batch > 65535)
 		return fail("bad argument (batch must be 1..65535)");
 	if (!dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
 		return fail("batched transforms take device pointers");
-	if ((stride_x & 3) || stride_x < size_x * 4 || (batch_stride & 3) || batch_stride < (size_t)stride_x * size_y)
+	if ((stride_x % es) || stride_x < size_x * es || (batch_stride % es) || batch_stride < (size_t)stride_x * size_y)
 		return fail("bad strides");
 	if (batch > 1 && src == dst)
 		return fail("in-place batches are not supported; use distinct src and dst");
 	const Geom ge{size_x, size_y, size_x, size_y};
-	Img s{(char *)src, stride_x}, d{(char *)dst, stride_x};
+	Img s{(char *)src, stride_x, es}, d{(char *)dst, stride_x, es};
 	if (g.pipeline >= 2 && batch >= 2) {
 		// per-image pipelines on internal streams, forked from and joined to the caller's stream
 		const int nl = g.pipeline < batch ? g.pipeline : batch;
@@ -1035,7 +1036,7 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 		const int j_in = *j;
 		for (int k = 0; k < batch && !rc; k++) {
 			Ctx::Lane &lane = g.lanes[k % nl];
-			Img sk{s.p + (size_t)k * batch_stride, s.sx}, dk{d.p + (size_t)k * batch_stride, d.sx};
+			Img sk{s.p + (size_t)k * batch_stride, s.sx, es}, dk{d.p + (size_t)k * batch_stride, d.sx, es};
 			int jk = j_in;
 			swap_lane(lane);
 			rc = inverse ? inverse2d((Wavelet)wavelet, sk, dk, ge, jk, 0, 0, 1, 0, 0)

@@ -368,6 +368,29 @@ def test_config4_batch(dwt, oracle):
     dwt.lib.dwt_hip_free(dst)
 
 
+def test_double_precision_batch(dwt, oracle):
+    """The batched entry takes the double-precision wavelets too (fused double sweeps)."""
+    n, nb = 768, 3
+    rng = np.random.default_rng(4)
+    imgs = rng.random((nb, n, n)) * 2 - 1
+    src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+    try:
+        assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+        for wname, ff in (("cdf97_d", "cdf97_2f_d"), ("cdf53_d", "cdf53_2f_d")):
+            j = dwt.transform2d_batch(wname, 0, src, dst, n * n * 8, nb, n * 8, n, n, 4)
+            out = np.empty_like(imgs)
+            assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
+            assert j == 4
+            for k in range(nb):
+                want = imgs[k].copy()
+                oracle.fwd(ff, want, 4)
+                assert np.array_equal(bits(out[k]), bits(want)), (wname, k)
+    finally:
+        dwt.lib.dwt_hip_free(src)
+        dwt.lib.dwt_hip_free(dst)
+
+
 def test_config4_per_gpu_shape_32x4096(dwt, oracle):
     """configs[3] at its per-GPU scale: 32 images of 4096x4096, 5 levels, ONE
     batched call (one launch per level for the shard of a GPU); image k seeded 1234+k; images 0

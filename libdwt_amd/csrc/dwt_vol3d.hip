@@ -307,36 +307,53 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 	issue(0);
 	for (int t = 0; t < n_slices; t++) {
 		DWT_WAIT_VMCNT(0); // this slice's rows have landed (and the previous stores are out)
-		// horizontal lift of this wave's rows, parked in the shared slab.  Software pipeline: the LDS
-		// reads of row i+1 are in flight while row i is lifted (counted lgkmcnt: LDS operations of
-		// a wave complete in order, so "all but the newest three" means row i has arrived).
+		// horizontal lift of this wave's rows, parked in the shared slab.  TWO rows at a time as the
+		// two halves of packed fp32 operations (v_pk_add_f32 / v_pk_mul_f32: the level is bound by
+		// VALU issue, and a row pair shares every instruction of the lift), software-pipelined: the
+		// LDS reads of the next pair are in flight while this pair is lifted (counted lgkmcnt: LDS
+		// operations of a wave complete in order).
 		{
+			typedef float f2 __attribute__((ext_vector_type(2)));
+			static_assert(RPW % 2 == 0, "rows per wave are lifted in pairs");
 			const unsigned own0 = ring_off + lane * CPT * 4;
 			const unsigned la0 = lane == 0 ? ring_off + TW * 4 : own0 - 16;
 			const unsigned ra0 = lane == 63 ? ring_off + TW * 4 + 16 : own0 + CPT * 4;
-			u4 L[2], O[2], R[2];
-			lds_issue3(la0, own0, ra0, L[0], O[0], R[0]);
+			u4 L[2][2], O[2][2], R[2][2]; // [buffer][row of the pair]
+			lds_issue3(la0, own0, ra0, L[0][0], O[0][0], R[0][0]);
+			lds_issue3(la0 + RS * 4, own0 + RS * 4, ra0 + RS * 4, L[0][1], O[0][1], R[0][1]);
 #pragma unroll
-			for (int i = 0; i < RPW; i++) {
-				const int b = i & 1;
-				if (i + 1 < RPW) {
-					lds_issue3(la0 + (i + 1) * RS * 4, own0 + (i + 1) * RS * 4, ra0 + (i + 1) * RS * 4, L[b ^ 1], O[b ^ 1], R[b ^ 1]);
-					lds_arrived3<3>(L[b], O[b], R[b]);
+			for (int ip = 0; ip < RPW / 2; ip++) {
+				const int b = ip & 1;
+				if (ip + 1 < RPW / 2) {
+					const unsigned d = (unsigned)(2 * ip + 2) * RS * 4;
+					lds_issue3(la0 + d, own0 + d, ra0 + d, L[b ^ 1][0], O[b ^ 1][0], R[b ^ 1][0]);
+					lds_issue3(la0 + d + RS * 4, own0 + d + RS * 4, ra0 + d + RS * 4, L[b ^ 1][1], O[b ^ 1][1], R[b ^ 1][1]);
+					lds_arrived3<6>(L[b][0], O[b][0], R[b][0]);
+					lds_arrived3<6>(L[b][1], O[b][1], R[b][1]);
 				} else {
-					lds_arrived3<0>(L[b], O[b], R[b]);
+					lds_arrived3<0>(L[b][0], O[b][0], R[b][0]);
+					lds_arrived3<0>(L[b][1], O[b][1], R[b][1]);
 				}
-				if (wv + 4 * i < NR) { // (the last wave stages one row fewer: its read of that slot is harmless)
-					float x[CPT + 2 * K];
+				f2 x[CPT + 2 * K];
 #pragma unroll
-					for (int e = 0; e < K; e++) {
-						x[e] = from_bits<float>(L[b][e]);
-						x[K + e] = from_bits<float>(O[b][e]);
-						x[K + CPT + e] = from_bits<float>(R[b][e]);
-					}
-					lift_fwd_regs<W, CPT + 2 * K>(x);
-					const u4 o = u4{to_bits(W::fwd_scale(0, x[K])), to_bits(W::fwd_scale(1, x[K + 1])),
-						to_bits(W::fwd_scale(0, x[K + 2])), to_bits(W::fwd_scale(1, x[K + 3]))};
-					lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16, o);
+				for (int e = 0; e < K; e++) {
+					x[e] = f2{from_bits<float>(L[b][0][e]), from_bits<float>(L[b][1][e])};
+					x[K + e] = f2{from_bits<float>(O[b][0][e]), from_bits<float>(O[b][1][e])};
+					x[K + CPT + e] = f2{from_bits<float>(R[b][0][e]), from_bits<float>(R[b][1][e])};
+				}
+				// lift_fwd_regs on both rows at once: x[j] += c_s * (x[j-1] + x[j+1]), product and sums rounded separately
+#pragma unroll
+				for (int st_ = 0; st_ < K; st_++)
+#pragma unroll
+					for (int j = st_ + 1; j <= CPT + 2 * K - 2 - st_; j += 2)
+						x[j] = x[j] + W::fc(st_) * (x[j - 1] + x[j + 1]);
+				const f2 e0 = x[K] * W::zeta(), o0 = x[K + 1] * (1.0f / W::zeta()), e1 = x[K + 2] * W::zeta(), o1 = x[K + 3] * (1.0f / W::zeta());
+#pragma unroll
+				for (int q = 0; q < 2; q++) {
+					const int i = 2 * ip + q;
+					if (wv + 4 * i < NR) // (the last wave stages one row fewer: its read of that slot is harmless)
+						lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16,
+							u4{to_bits(e0[q]), to_bits(o0[q]), to_bits(e1[q]), to_bits(o1[q])});
 				}
 			}
 		}

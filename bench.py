@@ -101,7 +101,8 @@ def cpu_baseline(size, levels):
     protocol of dwt_util_perf_cdf97_2_s (src/libdwt.c:21444-21476: minimum over N runs, M=1)
     on ONE size x size image, for (1 thread, all of this GPU's host cores) x (dense pitch,
     dwt_util_get_stride pitch) x (plain loop accel 0, the "fast SSE" setting accel 12 /
-    4 workers of examples/simple-perf/simple.c:15-16).  Bounded: ~1.5 s or 12 runs per row."""
+    4 workers of examples/simple-perf/simple.c:15-16).  Bounded: ~1.5 s or 12 runs per row, a single
+    run where one takes more than 2 s (about 20 s for the eight rows on the GPU box's host)."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -141,17 +142,22 @@ def cpu_baseline(size, levels):
                     lib.lib.dwt_util_set_num_threads(threads)
                 else:
                     lib.set_threads(threads)
-                best, runs, t_start = None, 0, time.perf_counter()
-                while runs < 13 and (runs < 3 or time.perf_counter() - t_start < 1.5):
+                best, runs, timed, t_start = None, 0, 0, time.perf_counter()
+                while runs < 13 and (timed < 2 or time.perf_counter() - t_start < 1.5):
                     buf[:, :size] = src
                     t0 = time.perf_counter()
                     lib.fwd("cdf97_2f_s", buf[:, :size], levels)
                     dt = time.perf_counter() - t0
-                    if runs > 0:  # the first run warms caches and the OpenMP pool
-                        best = dt if best is None else min(best, dt)
                     runs += 1
+                    # the first run warms caches and the OpenMP pool -- unless a run takes seconds (one
+                    # thread on the power-of-two pitch): then it is the sample, the leg stays bounded
+                    if runs > 1 or dt > 2.0:
+                        best = dt if best is None else min(best, dt)
+                        timed += 1
+                    if dt > 2.0:
+                        break
                 rows.append({"threads": threads, "pitch_bytes": pitch_elems * 4, "accel": accel, "workers": workers,
-                             "gsamples_per_s": round(size * size / best / 1e9, 3), "best_s": round(best, 4), "runs": runs - 1})
+                             "gsamples_per_s": round(size * size / best / 1e9, 3), "best_s": round(best, 4), "runs": timed})
     top = max(rows, key=lambda r: r["gsamples_per_s"])
     return {"value": top["gsamples_per_s"], "unit": "Gsamples/s", "cores": top["threads"], "kind": kind,
             "sample": f"1 image {size}x{size} float, {levels} levels, dwt_cdf97_2f_s in place, best single run per row "

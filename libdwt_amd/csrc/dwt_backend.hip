@@ -794,6 +794,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.vol.nt = value;
 	else if (!strcmp(name, "vol_fused"))
 		g.vol.fused = value;
+	else if (!strcmp(name, "vol_direct"))
+		g.vol.direct = value;
 	else if (!strcmp(name, "vol_swizzle"))
 		g.vol.swizzle = value;
 	else if (!strcmp(name, "vol_rows"))
@@ -847,6 +849,8 @@ int dwt_hip_get_option(const char *name)
 		return g.vol.nt;
 	if (!strcmp(name, "vol_fused"))
 		return g.vol.fused;
+	if (!strcmp(name, "vol_direct"))
+		return g.vol.direct;
 	return -1;
 }
 

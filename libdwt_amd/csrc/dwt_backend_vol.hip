@@ -13,8 +13,9 @@ extern "C" {
 // entry the reference's own 3-D perf test drives (volume_perftest_fwd97op_s, src/volume.c).
 // Level j reads a dense volume and writes a dense volume, so each level is ONE fused pass
 // (k_vol_fwd_fused) where that kernel applies and the two-pass path (xy sweep, z sweep through
-// the scratch volume) elsewhere; the even-even-even samples go to the next level densely, and the
-// results of the levels >= 1 are scattered into their lattices at the end (deepest first).
+// the scratch volume) elsewhere; the even-even-even samples go to the next level densely.  A fused
+// level >= 1 writes its result straight into its lattice of the destination (stride 2^j in x, y
+// and z); the two-pass levels keep a dense result that is scattered there at the end.
 int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
 {
 	if (check_inited())
@@ -60,6 +61,7 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 			return fail("volume too large for the launch grid");
 	float *S = nullptr;
 	long s_sy = 0, s_sz = 0;
+	bool in_place[kMaxLevels] = {}; // level wrote its lattice of dst itself
 	for (int j = 0; j < levels; j++) {
 		const Lvl &b = L[j];
 		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;
@@ -67,6 +69,14 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 		VolFusedArgs fa{b.in, b.sy, b.sz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
 		const bool can_fuse = fa.in != fa.out && fa.nx >= 2 && fa.ny >= 2 && fa.nz >= 2;
 		if (!g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(fa)) || (g.vol.fused >= 2 && can_fuse))) {
+			if (j >= 1 && g.vol.direct && g.vol.rows != 6 && (j == 1 || in_place[j - 1])) {
+				// straight into the level's lattice of the destination: no dense result, no scatter pass
+				fa.out = (float *)dst;
+				fa.out_sx = 1L << j;
+				fa.out_sy = vsy << j;
+				fa.out_sz = vsz << j;
+				in_place[j] = true;
+			}
 			prof_before(j);
 			hipError_t e = launch_vol_fwd_fused(fa, g.vol, g.stream);
 			prof_after(j);
@@ -94,9 +104,13 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 		if (e != hipSuccess)
 			return fail("3-D z pass launch failed: %s", hipGetErrorString(e));
 	}
-	for (int j = levels - 1; j >= 1; j--) {
-		const Lvl &c = L[j], &par = L[j - 1];
-		hipError_t e = launch_lattice_copy(c.out, 1, c.sy, c.sz, par.out, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
+	// the other levels >= 1 hold dense results: into their lattices of dst, shallow first (a level's
+	// even-even-even samples are the next level's, which overwrites them)
+	for (int j = 1; j < levels; j++) {
+		if (in_place[j])
+			continue;
+		const Lvl &c = L[j];
+		hipError_t e = launch_lattice_copy(c.out, 1, c.sy, c.sz, (float *)dst, 1L << j, vsy << j, vsz << j, c.lx, c.ly, c.lz, g.stream);
 		if (e != hipSuccess)
 			return fail("lattice scatter failed: %s", hipGetErrorString(e));
 	}

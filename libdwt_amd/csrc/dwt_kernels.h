@@ -82,6 +82,7 @@ struct VolTuning {
 	int tile_pairs = 0; // slice pairs per wave; 0 = choose from the volume depth
 	int nt = -1;        // bit 0 non-temporal stores, bit 1 non-temporal loads; -1 = measured default
 	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
+	int direct = 1;     // fused levels >= 1 write into their lattice of the destination (0: dense volume + scatter pass)
 	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes
 	int swizzle = 1;    // fused level: hand contiguous runs of tiles to one XCD
 	int rows = 8;       // fused level: output rows per wave, 8 (measured best) or 6 (two workgroups per CU)
@@ -105,6 +106,9 @@ struct VolFusedArgs {
 	float *lll; // optional dense copy of the even-even-even samples (next level's input)
 	long lll_sy, lll_sz;
 	int nx, ny, nz;
+	// x stride of `out` in samples: 1, or 2^j when level j writes straight into its lattice of the
+	// destination volume (out_sy / out_sz are then the destination's strides times 2^j)
+	long out_sx = 1;
 };
 bool vol_fused_applies(const VolFusedArgs &a);
 hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s);

@@ -224,7 +224,7 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 // the SIMD for 4 cycles; 557 M of them per launch = 0.95 ms per SIMD), not by latency.  Built,
 // measured and taken out again in round 2: the z state's deeper planes in LDS and the vertical
 // window in two halves (no accumulator-register moves, 249 registers): 2.24-2.28 ms, no gain.
-template <int NT, int RW>
+template <int NT, int RW, bool SX>
 __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
 {
 	using W = Cdf97S;
@@ -417,10 +417,23 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 			}
 			const int y = y0 + RW * wv + r;
 			if (it >= K && y < a.ny) {
-				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + c;
+				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + (SX ? c * a.out_sx : (long)c);
 				const bool hz = 2 * k + 1 < a.nz;
 				float *pl = a.lll && !(r & 1) ? a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1) : nullptr;
-				if (full) {
+				if (SX) {
+					// a level >= 1 writing into its lattice of the destination volume
+#pragma unroll
+					for (int e = 0; e < CPT; e++)
+						if (full || c + e < a.nx) {
+							p[e * a.out_sx] = o0[e];
+							if (hz)
+								p[a.out_sz + e * a.out_sx] = o1[e];
+							if (!full && pl && !(e & 1))
+								pl[e >> 1] = o0[e];
+						}
+					if (full && pl)
+						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+				} else if (full) {
 					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
 					if (hz)
 						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
@@ -456,18 +469,19 @@ bool vol_fused_applies(const VolFusedArgs &a)
 
 static bool vol_fused_vec_ok(const VolFusedArgs &a)
 {
-	return aligned16(a.in) && aligned16(a.out) && a.in_sy % 4 == 0 && a.in_sz % 4 == 0 && a.out_sy % 4 == 0 && a.out_sz % 4 == 0 &&
+	return aligned16(a.in) && a.in_sy % 4 == 0 && a.in_sz % 4 == 0 &&
+		(a.out_sx != 1 || (aligned16(a.out) && a.out_sy % 4 == 0 && a.out_sz % 4 == 0)) &&
 		(!a.lll || (((uintptr_t)a.lll & 7) == 0 && a.lll_sy % 2 == 0 && a.lll_sz % 2 == 0));
 }
 
-template <int NT, int RW>
+template <int NT, int RW, bool SX>
 static hipError_t vol_fused_launch(const VolFusedArgs &a, int tp, int ntx, int nty, int nzt, int swz, hipStream_t s)
 {
 	constexpr int NR = 4 * RW + 7;
 	const size_t lds = (size_t)NR * (256 + 8) * 4 + (size_t)NR * 256 * 4;
-	if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<NT, RW>, lds))
+	if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<NT, RW, SX>, lds))
 		return e;
-	k_vol_fwd_fused<NT, RW><<<dim3(ntx * nty * nzt), 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
+	k_vol_fwd_fused<NT, RW, SX><<<dim3(ntx * nty * nzt), 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
 	return hipGetLastError();
 }
 
@@ -491,11 +505,14 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 		return hipErrorInvalidValue;
 	const int swz = vt.swizzle;
 	const int nt = vt.nt == 7 ? 7 : (vt.nt < 0 || (vt.nt & 1)) ? 3 : 2;
+	// the strided-store variant (levels >= 1 into their lattice) exists for the default row count
+	if (a.out_sx != 1)
+		return rw != 8 ? hipErrorInvalidValue : nt == 2 ? vol_fused_launch<2, 8, true>(a, tp, ntx, nty, nzt, swz, s) : vol_fused_launch<3, 8, true>(a, tp, ntx, nty, nzt, swz, s);
 	if (rw == 8)
-		return nt == 7 ? vol_fused_launch<7, 8>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 8>(a, tp, ntx, nty, nzt, swz, s)
-		                                                                             : vol_fused_launch<2, 8>(a, tp, ntx, nty, nzt, swz, s);
-	return nt == 7 ? vol_fused_launch<7, 6>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 6>(a, tp, ntx, nty, nzt, swz, s)
-	                                                                             : vol_fused_launch<2, 6>(a, tp, ntx, nty, nzt, swz, s);
+		return nt == 7 ? vol_fused_launch<7, 8, false>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 8, false>(a, tp, ntx, nty, nzt, swz, s)
+		                                                                                    : vol_fused_launch<2, 8, false>(a, tp, ntx, nty, nzt, swz, s);
+	return nt == 7 ? vol_fused_launch<7, 6, false>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 6, false>(a, tp, ntx, nty, nzt, swz, s)
+	                                                                                    : vol_fused_launch<2, 6, false>(a, tp, ntx, nty, nzt, swz, s);
 }
 
 __global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ src, long s_sx, long s_sy, long s_sz,

@@ -62,15 +62,33 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 	float *S = nullptr;
 	long s_sy = 0, s_sz = 0;
 	bool in_place[kMaxLevels] = {}; // level wrote its lattice of dst itself
+	auto fuses = [&](int j) {
+		VolFusedArgs t{L[j].in, L[j].sy, L[j].sz, L[j].out, L[j].sy, L[j].sz, nullptr, 0, 0, L[j].lx, L[j].ly, L[j].lz};
+		const bool can = t.in != t.out && t.nx >= 2 && t.ny >= 2 && t.nz >= 2;
+		return !g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(t)) || (g.vol.fused >= 2 && can));
+	};
+	// levels 0 and 1 as a pair (whole 256-column tiles at both levels, 16-byte aligned rows)
+	const bool merged = levels >= 2 && g.vol.direct >= 2 && g.vol.rows != 6 && fuses(0) && fuses(1) && nx % 512 == 0 &&
+		(((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && vsy % 4 == 0 && vsz % 4 == 0;
 	for (int j = 0; j < levels; j++) {
 		const Lvl &b = L[j];
 		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;
 		const long lsy = j + 1 < levels ? L[j + 1].sy : 0, lsz = j + 1 < levels ? L[j + 1].sz : 0;
 		VolFusedArgs fa{b.in, b.sy, b.sz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
-		const bool can_fuse = fa.in != fa.out && fa.nx >= 2 && fa.ny >= 2 && fa.nz >= 2;
-		if (!g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(fa)) || (g.vol.fused >= 2 && can_fuse))) {
-			if (j >= 1 && g.vol.direct && g.vol.rows != 6 && (j == 1 || in_place[j - 1])) {
+		if (fuses(j)) {
+			if (j <= 1 && merged) {
+				// the rows with even y and even z are written once, by level 1 (level 0 parks their
+				// odd-x samples in level 1's otherwise unused dense result)
+				fa.mode = j == 0 ? 2 : 3;
+				fa.side = L[1].out; fa.side_sy = L[1].sy; fa.side_sz = L[1].sz;
+				if (j == 1) {
+					fa.out = (float *)dst;
+					fa.out_sy = vsy * 2; fa.out_sz = vsz * 2;
+					in_place[1] = true;
+				}
+			} else if (j >= 1 && g.vol.direct && g.vol.rows != 6 && (j == 1 || in_place[j - 1])) {
 				// straight into the level's lattice of the destination: no dense result, no scatter pass
+				fa.mode = 1;
 				fa.out = (float *)dst;
 				fa.out_sx = 1L << j;
 				fa.out_sy = vsy << j;
@@ -110,7 +128,7 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 		if (in_place[j])
 			continue;
 		const Lvl &c = L[j];
-		hipError_t e = launch_lattice_copy(c.out, 1, c.sy, c.sz, (float *)dst, 1L << j, vsy << j, vsz << j, c.lx, c.ly, c.lz, g.stream);
+		hipError_t e = launch_lattice_scatter(c.out, c.sy, c.sz, (float *)dst, 1L << j, vsy << j, vsz << j, c.lx, c.ly, c.lz, nx, g.stream);
 		if (e != hipSuccess)
 			return fail("lattice scatter failed: %s", hipGetErrorString(e));
 	}
@@ -193,7 +211,7 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 		const Lvl &c = L[j], &par = L[j - 1];
 		hipError_t e = pack
 			? launch_lattice_copy(par.p, 2, par.sy * 2, par.sz * 2, c.p, 1, c.sy, c.sz, c.lx, c.ly, c.lz, g.stream)
-			: launch_lattice_copy(c.p, 1, c.sy, c.sz, par.p, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, g.stream);
+			: launch_lattice_scatter(c.p, c.sy, c.sz, par.p, 2, par.sy * 2, par.sz * 2, c.lx, c.ly, c.lz, par.lx, g.stream);
 		if (e != hipSuccess)
 			return fail("lattice %s failed: %s", pack ? "pack" : "unpack", hipGetErrorString(e));
 		return 0;

@@ -82,7 +82,7 @@ struct VolTuning {
 	int tile_pairs = 0; // slice pairs per wave; 0 = choose from the volume depth
 	int nt = -1;        // bit 0 non-temporal stores, bit 1 non-temporal loads; -1 = measured default
 	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
-	int direct = 1;     // fused levels >= 1 write into their lattice of the destination (0: dense volume + scatter pass)
+	int direct = 2;     // fused levels >= 1 write into their lattice of the destination: 2 = level 1 merged with level 0's withheld rows where the sizes allow, 1 = strided stores, 0 = dense volume + scatter pass
 	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes
 	int swizzle = 1;    // fused level: hand contiguous runs of tiles to one XCD
 	int rows = 8;       // fused level: output rows per wave, 8 (measured best) or 6 (two workgroups per CU)
@@ -106,9 +106,14 @@ struct VolFusedArgs {
 	float *lll; // optional dense copy of the even-even-even samples (next level's input)
 	long lll_sy, lll_sz;
 	int nx, ny, nz;
-	// x stride of `out` in samples: 1, or 2^j when level j writes straight into its lattice of the
-	// destination volume (out_sy / out_sz are then the destination's strides times 2^j)
+	// multi-level store variants (see k_vol_fwd_fused): 1 = level j >= 1 into its lattice of the
+	// destination (out_sx = 2^j, out_sy / out_sz the destination's strides times 2^j); 2 = level 0
+	// withholding its even-y even-z rows (odd-x samples to `side`, laid out like `lll`); 3 = level 1
+	// writing those rows whole (out_sy / out_sz the destination's strides times 2; `side` read)
+	int mode = 0;
 	long out_sx = 1;
+	float *side = nullptr;
+	long side_sy = 0, side_sz = 0;
 };
 bool vol_fused_applies(const VolFusedArgs &a);
 hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s);
@@ -117,6 +122,10 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 // strides in ELEMENTS, including the x strides.
 hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
 	int nx, int ny, int nz, hipStream_t s);
+// the same for a dense source and a destination whose rows hold dst_nx samples: strides 2 and 4 as
+// a read-modify-write of whole 16-byte pieces where they fit the rows
+hipError_t launch_lattice_scatter(const float *src, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
+	int nx, int ny, int nz, int dst_nx, hipStream_t s);
 
 // One PHASE of the reference's phase-ordered in-place lifting (src/dwt-simple.c:2266-2350,
 // src/libdwt.c:17517-17594): lifting step s updates the coefficients lo[s]..hi[s] of its

@@ -224,7 +224,12 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 // the SIMD for 4 cycles; 557 M of them per launch = 0.95 ms per SIMD), not by latency.  Built,
 // measured and taken out again in round 2: the z state's deeper planes in LDS and the vertical
 // window in two halves (no accumulator-register moves, 249 registers): 2.24-2.28 ms, no gain.
-template <int NT, int RW, bool SX>
+// MODE (multi-level calls): 0 = dense result; 1 = a level >= 1 storing into its stride-2^j lattice
+// of the destination; 2 and 3 = levels 0 and 1 of a call whose rows with even y and even z are
+// written ONCE: level 0 (2) withholds them and parks their odd-x samples in `side`, level 1 (3)
+// writes them whole, its own samples interleaved with the parked ones (which it brings in by
+// LDS-DMA one iteration ahead: no registers, no exposed latency).
+template <int NT, int RW, int MODE>
 __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
 {
 	using W = Cdf97S;
@@ -259,6 +264,9 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 	char *ring = smem + (size_t)wv * RPW * RS * 4;
 	char *slab = smem + (size_t)NR * RS * 4;
 	const unsigned ring_off = lds_offset(ring), slab_off = lds_offset(slab);
+	// MODE 3: the parked rows of this wave's 2 RW output rows, 1 KiB each
+	char *parked = slab + (size_t)NR * TW * 4 + (size_t)wv * 2 * RW * TW * 4;
+	const unsigned parked_off = lds_offset(parked);
 	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
 	// tiles that overhang the volume (or unaligned volumes) are staged column by column
 	const bool full = vec_ok && c0 + TW <= a.nx;
@@ -360,6 +368,22 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 		// the staging rows are consumed: the next slice's DMA flies during the rest of the iteration
 		if (t + 1 < n_slices)
 			issue(t + 1);
+		if constexpr (MODE == 3) {
+			// the next iteration stores slices 2k, 2k+1: fetch the parked halves of those rows
+			const int it1 = (t + 1) >> 1, k1 = A + it1 - K;
+			if (!(t & 1) && it1 >= K) {
+#pragma unroll
+				for (int r = 0; r < RW; r++) {
+					const int y = y0 + RW * wv + r;
+					if (y < a.ny) {
+						const float *sp = a.side + (long)(2 * k1) * a.side_sz + (long)y * a.side_sy + c;
+						dma16<0>(sp, parked + (size_t)(2 * r) * TW * 4);
+						if (2 * k1 + 1 < a.nz)
+							dma16<0>(sp + a.side_sz, parked + (size_t)(2 * r + 1) * TW * 4);
+					}
+				}
+			}
+		}
 		wg_barrier_lds(); // the slab is complete
 
 		// vertical lift: slab rows RW wv .. RW wv + NV - 1 give this wave's RW output rows
@@ -417,10 +441,32 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 			}
 			const int y = y0 + RW * wv + r;
 			if (it >= K && y < a.ny) {
-				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + (SX ? c * a.out_sx : (long)c);
+				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + (MODE == 1 ? c * a.out_sx : MODE == 3 ? 2L * c : (long)c);
 				const bool hz = 2 * k + 1 < a.nz;
 				float *pl = a.lll && !(r & 1) ? a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1) : nullptr;
-				if (SX) {
+				if constexpr (MODE == 3) {
+					// (host: whole tiles only) own samples at even x, level 0's parked ones at odd x
+					u4 s0, s1;
+					lds_read2(parked_off + (unsigned)(2 * r) * TW * 4 + lane * 16, parked_off + (unsigned)(2 * r + 1) * TW * 4 + lane * 16, s0, s1);
+					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), s0[0], to_bits(o0[1]), s0[1]});
+					store_vec<kNtStore>((u4 *)p + 1, u4{to_bits(o0[2]), s0[2], to_bits(o0[3]), s0[3]});
+					if (hz) {
+						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), s1[0], to_bits(o1[1]), s1[1]});
+						store_vec<kNtStore>((u4 *)(p + a.out_sz) + 1, u4{to_bits(o1[2]), s1[2], to_bits(o1[3]), s1[3]});
+					}
+					if (pl)
+						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+				} else if constexpr (MODE == 2) {
+					// (host: whole tiles only) rows with even y in the even slice are level 1's to write
+					if (r & 1)
+						store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
+					else
+						*(u2 *)(a.side + (long)k * a.side_sz + (long)(y >> 1) * a.side_sy + (c >> 1)) = u2{to_bits(o0[1]), to_bits(o0[3])};
+					if (hz)
+						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
+					if (pl)
+						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+				} else if constexpr (MODE == 1) {
 					// a level >= 1 writing into its lattice of the destination volume
 #pragma unroll
 					for (int e = 0; e < CPT; e++)
@@ -470,18 +516,18 @@ bool vol_fused_applies(const VolFusedArgs &a)
 static bool vol_fused_vec_ok(const VolFusedArgs &a)
 {
 	return aligned16(a.in) && a.in_sy % 4 == 0 && a.in_sz % 4 == 0 &&
-		(a.out_sx != 1 || (aligned16(a.out) && a.out_sy % 4 == 0 && a.out_sz % 4 == 0)) &&
+		(a.mode == 1 || (aligned16(a.out) && a.out_sy % 4 == 0 && a.out_sz % 4 == 0)) &&
 		(!a.lll || (((uintptr_t)a.lll & 7) == 0 && a.lll_sy % 2 == 0 && a.lll_sz % 2 == 0));
 }
 
-template <int NT, int RW, bool SX>
+template <int NT, int RW, int MODE>
 static hipError_t vol_fused_launch(const VolFusedArgs &a, int tp, int ntx, int nty, int nzt, int swz, hipStream_t s)
 {
 	constexpr int NR = 4 * RW + 7;
-	const size_t lds = (size_t)NR * (256 + 8) * 4 + (size_t)NR * 256 * 4;
-	if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<NT, RW, SX>, lds))
+	const size_t lds = (size_t)NR * (256 + 8) * 4 + (size_t)NR * 256 * 4 + (MODE == 3 ? (size_t)4 * 2 * RW * 256 * 4 : 0);
+	if (hipError_t e = allow_lds((const void *)k_vol_fwd_fused<NT, RW, MODE>, lds))
 		return e;
-	k_vol_fwd_fused<NT, RW, SX><<<dim3(ntx * nty * nzt), 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
+	k_vol_fwd_fused<NT, RW, MODE><<<dim3(ntx * nty * nzt), 256, lds, s>>>(a, tp, vol_fused_vec_ok(a), ntx, nty, swz);
 	return hipGetLastError();
 }
 
@@ -505,14 +551,26 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 		return hipErrorInvalidValue;
 	const int swz = vt.swizzle;
 	const int nt = vt.nt == 7 ? 7 : (vt.nt < 0 || (vt.nt & 1)) ? 3 : 2;
-	// the strided-store variant (levels >= 1 into their lattice) exists for the default row count
-	if (a.out_sx != 1)
-		return rw != 8 ? hipErrorInvalidValue : nt == 2 ? vol_fused_launch<2, 8, true>(a, tp, ntx, nty, nzt, swz, s) : vol_fused_launch<3, 8, true>(a, tp, ntx, nty, nzt, swz, s);
+	// the multi-level store variants exist for the default row count
+	if (a.mode != 0) {
+		if (rw != 8 || a.mode < 0 || a.mode > 3)
+			return hipErrorInvalidValue;
+		if (a.mode >= 2 && (!vol_fused_vec_ok(a) || a.nx % 256 || !a.side || ((uintptr_t)a.side & 15) || a.side_sy % 4 || a.side_sz % 4))
+			return hipErrorInvalidValue;
+		switch (a.mode * 2 + (nt == 2 ? 0 : 1)) {
+		case 2: return vol_fused_launch<2, 8, 1>(a, tp, ntx, nty, nzt, swz, s);
+		case 3: return vol_fused_launch<3, 8, 1>(a, tp, ntx, nty, nzt, swz, s);
+		case 4: return vol_fused_launch<2, 8, 2>(a, tp, ntx, nty, nzt, swz, s);
+		case 5: return vol_fused_launch<3, 8, 2>(a, tp, ntx, nty, nzt, swz, s);
+		case 6: return vol_fused_launch<2, 8, 3>(a, tp, ntx, nty, nzt, swz, s);
+		default: return vol_fused_launch<3, 8, 3>(a, tp, ntx, nty, nzt, swz, s);
+		}
+	}
 	if (rw == 8)
-		return nt == 7 ? vol_fused_launch<7, 8, false>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 8, false>(a, tp, ntx, nty, nzt, swz, s)
-		                                                                                    : vol_fused_launch<2, 8, false>(a, tp, ntx, nty, nzt, swz, s);
-	return nt == 7 ? vol_fused_launch<7, 6, false>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 6, false>(a, tp, ntx, nty, nzt, swz, s)
-	                                                                                    : vol_fused_launch<2, 6, false>(a, tp, ntx, nty, nzt, swz, s);
+		return nt == 7 ? vol_fused_launch<7, 8, 0>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 8, 0>(a, tp, ntx, nty, nzt, swz, s)
+		                                                                                : vol_fused_launch<2, 8, 0>(a, tp, ntx, nty, nzt, swz, s);
+	return nt == 7 ? vol_fused_launch<7, 6, 0>(a, tp, ntx, nty, nzt, swz, s) : nt == 3 ? vol_fused_launch<3, 6, 0>(a, tp, ntx, nty, nzt, swz, s)
+	                                                                                : vol_fused_launch<2, 6, 0>(a, tp, ntx, nty, nzt, swz, s);
 }
 
 __global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ src, long s_sx, long s_sy, long s_sz,
@@ -525,6 +583,42 @@ __global__ __launch_bounds__(256) void k_lattice_copy(const float *__restrict__ 
 		dst[(long)z * d_sz + (long)y * d_sy + (long)x * d_sx] = src[(long)z * s_sz + (long)y * s_sy + (long)x * s_sx];
 }
 
+// Scatter of a dense volume into a stride-2 or stride-4 lattice as an explicit read-modify-write of
+// whole 16-byte pieces of the destination (a lattice store of 4 bytes is a masked write of a line
+// that left the caches long ago: measured 181 us for 256^3 into a stride-4 lattice against the
+// round trip of full pieces here).  One thread per piece: SX = 4 replaces its first sample, SX = 2
+// its first and third.
+template <int SX>
+__global__ __launch_bounds__(256) void k_lattice_merge(const float *__restrict__ src, long s_sy, long s_sz, float *__restrict__ dst, long d_sy, long d_sz,
+	int npieces, int nx, int ny, int nxb)
+{
+	constexpr int R = 8; // rows per thread: all loads first, then the stores
+	const int i = (blockIdx.x % nxb) * blockDim.x + threadIdx.x; // piece of the destination row
+	const int y0 = (blockIdx.x / nxb) * R, z = blockIdx.y;
+	if (i >= npieces)
+		return;
+	u4 *p = (u4 *)(dst + (long)z * d_sz + (long)y0 * d_sy) + i;
+	const float *q = src + (long)z * s_sz + (long)y0 * s_sy + i * (4 / SX);
+	const bool second = SX == 2 && i * 2 + 1 < nx;
+	u4 v[R];
+	float a[R], b[R];
+#pragma unroll
+	for (int r = 0; r < R; r++)
+		if (y0 + r < ny) {
+			v[r] = p[r * (d_sy / 4)];
+			a[r] = q[r * s_sy];
+			b[r] = second ? q[r * s_sy + 1] : 0.f;
+		}
+#pragma unroll
+	for (int r = 0; r < R; r++)
+		if (y0 + r < ny) {
+			v[r][0] = to_bits(a[r]);
+			if (second)
+				v[r][2] = to_bits(b[r]);
+			p[r * (d_sy / 4)] = v[r];
+		}
+}
+
 hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
 	int nx, int ny, int nz, hipStream_t s)
 {
@@ -534,6 +628,28 @@ hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz
 	dim3 grid(nxb * ny, nz);
 	k_lattice_copy<<<grid, 256, 0, s>>>(src, s_sx, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny, nxb);
 	return hipGetLastError();
+}
+
+// Dense volume -> lattice of a destination whose rows hold dst_nx samples: whole-piece merge where
+// every piece lies inside its row, the sample-wise copy elsewhere.
+hipError_t launch_lattice_scatter(const float *src, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
+	int nx, int ny, int nz, int dst_nx, hipStream_t s)
+{
+	if (nx < 1 || ny < 1 || nz < 1 || nz > 65535)
+		return hipErrorInvalidValue;
+	const int npieces = d_sx == 4 ? nx : (nx + 1) / 2;
+	if ((d_sx == 2 || d_sx == 4) && aligned16(dst) && d_sy % 4 == 0 && d_sz % 4 == 0 && (long)npieces * 4 <= dst_nx) {
+		const int nxb = (npieces + 255) / 256;
+		if ((long)nxb * ny > 0x7fffffffL)
+			return hipErrorInvalidValue;
+		dim3 grid(nxb * ((ny + 7) / 8), nz);
+		if (d_sx == 4)
+			k_lattice_merge<4><<<grid, 256, 0, s>>>(src, s_sy, s_sz, dst, d_sy, d_sz, npieces, nx, ny, nxb);
+		else
+			k_lattice_merge<2><<<grid, 256, 0, s>>>(src, s_sy, s_sz, dst, d_sy, d_sz, npieces, nx, ny, nxb);
+		return hipGetLastError();
+	}
+	return launch_lattice_copy(src, 1, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny, nz, s);
 }
 
 } // namespace dwt

@@ -80,11 +80,12 @@ def test_volume_vs_oracle(dwt, oracle, shape, levels):
     d.free()
 
 
-@pytest.mark.parametrize("fused", [1, 6, 0, -1], ids=["fused", "fused-6-rows", "two-pass", "fused-dense-results"])
+@pytest.mark.parametrize("fused", [1, 6, 0, -1, -2], ids=["fused", "fused-6-rows", "two-pass", "fused-dense-results", "fused-strided-stores"])
 @pytest.mark.parametrize("shape,levels", [((16, 16, 256), 1), ((37, 50, 256), 1), ((9, 7, 512), 1), ((64, 96, 256), 2),
                                           ((40, 33, 768), 1), ((128, 128, 512), 3), ((66, 130, 1024), 3), ((33, 65, 129), 2),
                                           ((2, 2, 256), 1), ((130, 3, 256), 1), ((20, 40, 300), 1), ((33, 35, 129), 1),
-                                          ((18, 70, 1000), 2), ((24, 24, 515), 1), ((200, 520, 600), 2), ((129, 1000, 513), 1)],
+                                          ((18, 70, 1000), 2), ((24, 24, 515), 1), ((200, 520, 600), 2), ((129, 1000, 513), 1),
+                                          ((70, 66, 512), 2), ((33, 47, 1024), 4), ((129, 31, 1536), 2)],
                          ids=lambda v: str(v))
 def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
     """dwt_hip_transform3d_op (cdf97_3f_op_sep_horizontal_s semantics): one fused x+y+z pass per
@@ -99,14 +100,15 @@ def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
     # fused: 2 = the one-pass kernel wherever it can run (small test volumes included), 1 = where it pays
     dwt.set_option("vol_fused", 2 if fused else 0)
     dwt.set_option("vol_rows", 6 if fused == 6 else 8)  # output rows per wave of the fused kernel
-    # levels >= 1: straight into their lattice of the destination (default), or dense + scatter pass
-    dwt.set_option("vol_direct", 0 if fused == -1 else 1)
+    # levels >= 1 into their lattice of the destination: 2 (default) = level 1 writes the rows it shares
+    # with level 0 whole (x sizes that are multiples of 512), 1 = strided stores, 0 = dense + scatter pass
+    dwt.set_option("vol_direct", 0 if fused == -1 else 1 if fused == -2 else 2)
     try:
         dwt.transform3d_op(src.ptr, dst.ptr, nx * 4, nx * ny * 4, nx, ny, nz, levels)
     finally:
         dwt.set_option("vol_fused", 1)
         dwt.set_option("vol_rows", 8)
-        dwt.set_option("vol_direct", 1)
+        dwt.set_option("vol_direct", 2)
     assert np.array_equal(bits(dst.get()), bits(want))
     assert np.array_equal(bits(src.get()), bits(vol)), "source volume modified"
     # the in-place inverse undoes it

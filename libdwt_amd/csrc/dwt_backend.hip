@@ -796,6 +796,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.vol.fused = value;
 	else if (!strcmp(name, "vol_direct"))
 		g.vol.direct = value;
+	else if (!strcmp(name, "vol_whole"))
+		g.vol.whole = value;
 	else if (!strcmp(name, "vol_swizzle"))
 		g.vol.swizzle = value;
 	else if (!strcmp(name, "vol_rows"))
@@ -851,6 +853,8 @@ int dwt_hip_get_option(const char *name)
 		return g.vol.fused;
 	if (!strcmp(name, "vol_direct"))
 		return g.vol.direct;
+	if (!strcmp(name, "vol_whole"))
+		return g.vol.whole;
 	return -1;
 }
 

@@ -228,7 +228,9 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 // of the destination; 2 and 3 = levels 0 and 1 of a call whose rows with even y and even z are
 // written ONCE: level 0 (2) withholds them and parks their odd-x samples in `side`, level 1 (3)
 // writes them whole, its own samples interleaved with the parked ones (which it brings in by
-// LDS-DMA one iteration ahead: no registers, no exposed latency).
+// LDS-DMA one iteration ahead: no registers, no exposed latency); 4 = 0 for volumes of whole,
+// aligned 256-column tiles (like 2 and 3: without the column-by-column staging and the bounded
+// stores of overhanging tiles the vertical / z phase needs 14 instead of 52 accumulator registers).
 template <int NT, int RW, int MODE>
 __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
 {
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 	const unsigned parked_off = lds_offset(parked);
 	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
 	// tiles that overhang the volume (or unaligned volumes) are staged column by column
-	const bool full = vec_ok && c0 + TW <= a.nx;
+	const bool full = MODE >= 2 || (vec_ok && c0 + TW <= a.nx);
 	// interior tiles fetch each 4-column halo as ONE aligned 16 B piece (two lanes) instead of four
 	// 4 B ones; tiles at the volume's x borders reflect column by column
 	const bool halo16 = full && c0 >= 4 && c0 + TW + 4 <= a.nx;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 						}
 					if (full && pl)
 						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
-				} else if (full) {
+				} else if (MODE == 4 || full) {
 					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
 					if (hz)
 						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
@@ -552,6 +554,11 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	const int swz = vt.swizzle;
 	const int nt = vt.nt == 7 ? 7 : (vt.nt < 0 || (vt.nt & 1)) ? 3 : 2;
 	// the multi-level store variants exist for the default row count
+	int mode = a.mode;
+	if (mode == 0 && rw == 8 && nt != 7 && vt.whole && vol_fused_vec_ok(a) && a.nx % 256 == 0)
+		mode = 4;
+	if (mode == 4)
+		return nt == 2 ? vol_fused_launch<2, 8, 4>(a, tp, ntx, nty, nzt, swz, s) : vol_fused_launch<3, 8, 4>(a, tp, ntx, nty, nzt, swz, s);
 	if (a.mode != 0) {
 		if (rw != 8 || a.mode < 0 || a.mode > 3)
 			return hipErrorInvalidValue;

@@ -103,12 +103,15 @@ def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
     # levels >= 1 into their lattice of the destination: 2 (default) = level 1 writes the rows it shares
     # with level 0 whole (x sizes that are multiples of 512), 1 = strided stores, 0 = dense + scatter pass
     dwt.set_option("vol_direct", 0 if fused == -1 else 1 if fused == -2 else 2)
+    # whole-tile variant of the kernel where the x size is a multiple of 256 (default) or the general one
+    dwt.set_option("vol_whole", 0 if fused == -1 else 1)
     try:
         dwt.transform3d_op(src.ptr, dst.ptr, nx * 4, nx * ny * 4, nx, ny, nz, levels)
     finally:
         dwt.set_option("vol_fused", 1)
         dwt.set_option("vol_rows", 8)
         dwt.set_option("vol_direct", 2)
+        dwt.set_option("vol_whole", 1)
     assert np.array_equal(bits(dst.get()), bits(want))
     assert np.array_equal(bits(src.get()), bits(vol)), "source volume modified"
     # the in-place inverse undoes it

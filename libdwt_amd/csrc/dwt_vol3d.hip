@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 					if (r & 1)
 						store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
 					else
-						*(u2 *)(a.side + (long)k * a.side_sz + (long)(y >> 1) * a.side_sy + (c >> 1)) = u2{to_bits(o0[1]), to_bits(o0[3])};
+						store_vec<kNtStore>((u2 *)(a.side + (long)k * a.side_sz + (long)(y >> 1) * a.side_sy + (c >> 1)), u2{to_bits(o0[1]), to_bits(o0[3])});
 					if (hz)
 						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
 					if (pl)
@@ -555,10 +555,12 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	const int nt = vt.nt == 7 ? 7 : (vt.nt < 0 || (vt.nt & 1)) ? 3 : 2;
 	// the multi-level store variants exist for the default row count
 	int mode = a.mode;
-	if (mode == 0 && rw == 8 && nt != 7 && vt.whole && vol_fused_vec_ok(a) && a.nx % 256 == 0)
+	if (mode == 0 && nt != 7 && vt.whole && vol_fused_vec_ok(a) && a.nx % 256 == 0)
 		mode = 4;
-	if (mode == 4)
+	if (mode == 4 && rw == 8)
 		return nt == 2 ? vol_fused_launch<2, 8, 4>(a, tp, ntx, nty, nzt, swz, s) : vol_fused_launch<3, 8, 4>(a, tp, ntx, nty, nzt, swz, s);
+	if (mode == 4)
+		return nt == 2 ? vol_fused_launch<2, 6, 4>(a, tp, ntx, nty, nzt, swz, s) : vol_fused_launch<3, 6, 4>(a, tp, ntx, nty, nzt, swz, s);
 	if (a.mode != 0) {
 		if (rw != 8 || a.mode < 0 || a.mode > 3)
 			return hipErrorInvalidValue;
@@ -609,13 +611,14 @@ __global__ __launch_bounds__(256) void k_lattice_merge(const float *__restrict__
 	const bool second = SX == 2 && i * 2 + 1 < nx;
 	u4 v[R];
 	float a[R], b[R];
+	// rows past the end load row y0 again (never stored): straight-line loads, eight in flight
 #pragma unroll
-	for (int r = 0; r < R; r++)
-		if (y0 + r < ny) {
-			v[r] = p[r * (d_sy / 4)];
-			a[r] = q[r * s_sy];
-			b[r] = second ? q[r * s_sy + 1] : 0.f;
-		}
+	for (int r = 0; r < R; r++) {
+		const long ro = y0 + r < ny ? r : 0;
+		v[r] = p[ro * (d_sy / 4)];
+		a[r] = q[ro * s_sy];
+		b[r] = q[ro * s_sy + (second ? 1 : 0)];
+	}
 #pragma unroll
 	for (int r = 0; r < R; r++)
 		if (y0 + r < ny) {

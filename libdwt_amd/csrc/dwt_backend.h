@@ -29,6 +29,8 @@ struct Ctx {
 	size_t ll_bytes[2] = {0, 0};
 	void *host_a = nullptr, *host_b = nullptr; // device images for host-pointer calls
 	size_t host_a_bytes = 0, host_b_bytes = 0;
+	void *vol_out = nullptr; // dense result volume of an in-place 3-D forward call (fused levels, then copied back)
+	size_t vol_out_bytes = 0;
 	void *pin = nullptr; // pinned host staging for host-pointer calls with awkward strides
 	size_t pin_bytes = 0;
 	// pipeline lanes for batches: image k runs all its levels on lane k % lanes, so the

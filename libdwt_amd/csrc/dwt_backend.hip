@@ -714,13 +714,13 @@ void dwt_hip_finish(void)
 	if (!g.inited)
 		return;
 	hipStreamSynchronize(g.stream);
-	void **bufs[] = {&g.stage_img, &g.ll[0], &g.ll[1], &g.host_a, &g.host_b};
+	void **bufs[] = {&g.stage_img, &g.ll[0], &g.ll[1], &g.host_a, &g.host_b, &g.vol_out};
 	for (void **b : bufs) {
 		if (*b)
 			hipFree(*b);
 		*b = nullptr;
 	}
-	g.stage_bytes = g.ll_bytes[0] = g.ll_bytes[1] = g.host_a_bytes = g.host_b_bytes = 0;
+	g.stage_bytes = g.ll_bytes[0] = g.ll_bytes[1] = g.host_a_bytes = g.host_b_bytes = g.vol_out_bytes = 0;
 	if (g.pin)
 		hipHostFree(g.pin);
 	g.pin = nullptr;
@@ -798,6 +798,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.vol.direct = value;
 	else if (!strcmp(name, "vol_whole"))
 		g.vol.whole = value;
+	else if (!strcmp(name, "vol_inplace_fused"))
+		g.vol.inplace_fused = value;
 	else if (!strcmp(name, "vol_swizzle"))
 		g.vol.swizzle = value;
 	else if (!strcmp(name, "vol_rows"))
@@ -855,6 +857,8 @@ int dwt_hip_get_option(const char *name)
 		return g.vol.direct;
 	if (!strcmp(name, "vol_whole"))
 		return g.vol.whole;
+	if (!strcmp(name, "vol_inplace_fused"))
+		return g.vol.inplace_fused;
 	return -1;
 }
 

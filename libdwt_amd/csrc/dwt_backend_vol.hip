@@ -4,41 +4,19 @@
 
 using namespace dwtb;
 
-#pragma GCC visibility push(default)
-extern "C" {
+constexpr int kMaxVolLevels = 24;
 
-
-// Forward 3-D transform, OUT OF PLACE: the layout and arithmetic of cdf97_3f_op_sep_horizontal_s
-// (src/volume-dwt.c:727-785: copy each x line to the destination, then lift x, y, z there), the
-// entry the reference's own 3-D perf test drives (volume_perftest_fwd97op_s, src/volume.c).
-// Level j reads a dense volume and writes a dense volume, so each level is ONE fused pass
-// (k_vol_fwd_fused) where that kernel applies and the two-pass path (xy sweep, z sweep through
-// the scratch volume) elsewhere; the even-even-even samples go to the next level densely.  A fused
-// level >= 1 writes its result straight into its lattice of the destination (stride 2^j in x, y
-// and z); the two-pass levels keep a dense result that is scattered there at the end.
-int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
+// The levels of a forward out-of-place call: src (strides ssy / ssz, in samples) -> dst (vsy / vsz).
+// Arguments are validated by the callers.
+static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long vsy, long vsz, int nx, int ny, int nz, int levels)
 {
-	if (check_inited())
-		return 1;
-	if (!src || !dst || !dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
-		return fail("dwt_hip_transform3d_op takes device pointers");
-	if (src == dst)
-		return fail("dwt_hip_transform3d_op is out of place; use dwt_hip_transform3d for in-place volumes");
-	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
-		return fail("bad volume strides");
-	constexpr int kMaxLevels = 24;
-	if (levels > kMaxLevels)
-		return fail("too many levels");
-	if (levels >= 1 && (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2))
-		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
-	const long vsy = (long)stride_y / 4, vsz = (long)stride_z / 4;
 	if (levels < 1) {
 		// no levels: the reference's copy stage alone
-		hipError_t e = launch_lattice_copy((const float *)src, 1, vsy, vsz, (float *)dst, 1, vsy, vsz, nx, ny, nz, g.stream);
+		hipError_t e = launch_lattice_copy(src, 1, ssy, ssz, dst, 1, vsy, vsz, nx, ny, nz, g.stream);
 		return e == hipSuccess ? 0 : fail("volume copy failed: %s", hipGetErrorString(e));
 	}
-	struct Lvl { const float *in; float *out; long sy, sz; int lx, ly, lz; } L[kMaxLevels];
-	L[0] = {(const float *)src, (float *)dst, vsy, vsz, nx, ny, nz};
+	struct Lvl { const float *in; float *out; long sy, sz; int lx, ly, lz; } L[kMaxVolLevels]; // sy, sz: of `out` (and of `in` for levels >= 1)
+	L[0] = {src, dst, vsy, vsz, nx, ny, nz};
 	size_t pool = 0;
 	for (int j = 1; j < levels; j++) {
 		L[j].lx = ceil_div_pow2(nx, j); L[j].ly = ceil_div_pow2(ny, j); L[j].lz = ceil_div_pow2(nz, j);
@@ -61,20 +39,20 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 			return fail("volume too large for the launch grid");
 	float *S = nullptr;
 	long s_sy = 0, s_sz = 0;
-	bool in_place[kMaxLevels] = {}; // level wrote its lattice of dst itself
+	bool in_place[kMaxVolLevels] = {}; // level wrote its lattice of dst itself
 	auto fuses = [&](int j) {
-		VolFusedArgs t{L[j].in, L[j].sy, L[j].sz, L[j].out, L[j].sy, L[j].sz, nullptr, 0, 0, L[j].lx, L[j].ly, L[j].lz};
+		VolFusedArgs t{L[j].in, j ? L[j].sy : ssy, j ? L[j].sz : ssz, L[j].out, L[j].sy, L[j].sz, nullptr, 0, 0, L[j].lx, L[j].ly, L[j].lz};
 		const bool can = t.in != t.out && t.nx >= 2 && t.ny >= 2 && t.nz >= 2;
 		return !g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(t)) || (g.vol.fused >= 2 && can));
 	};
 	// levels 0 and 1 as a pair (whole 256-column tiles at both levels, 16-byte aligned rows)
 	const bool merged = levels >= 2 && g.vol.direct >= 2 && g.vol.rows != 6 && fuses(0) && fuses(1) && nx % 512 == 0 &&
-		(((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && vsy % 4 == 0 && vsz % 4 == 0;
+		(((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && vsy % 4 == 0 && vsz % 4 == 0 && ssy % 4 == 0 && ssz % 4 == 0;
 	for (int j = 0; j < levels; j++) {
 		const Lvl &b = L[j];
 		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;
 		const long lsy = j + 1 < levels ? L[j + 1].sy : 0, lsz = j + 1 < levels ? L[j + 1].sz : 0;
-		VolFusedArgs fa{b.in, b.sy, b.sz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
+		VolFusedArgs fa{b.in, j ? b.sy : ssy, j ? b.sz : ssz, b.out, b.sy, b.sz, lll, lsy, lsz, b.lx, b.ly, b.lz};
 		if (fuses(j)) {
 			if (j <= 1 && merged) {
 				// the rows with even y and even z are written once, by level 1 (level 0 parks their
@@ -82,14 +60,14 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 				fa.mode = j == 0 ? 2 : 3;
 				fa.side = L[1].out; fa.side_sy = L[1].sy; fa.side_sz = L[1].sz;
 				if (j == 1) {
-					fa.out = (float *)dst;
+					fa.out = dst;
 					fa.out_sy = vsy * 2; fa.out_sz = vsz * 2;
 					in_place[1] = true;
 				}
 			} else if (j >= 1 && g.vol.direct && g.vol.rows != 6 && (j == 1 || in_place[j - 1])) {
 				// straight into the level's lattice of the destination: no dense result, no scatter pass
 				fa.mode = 1;
-				fa.out = (float *)dst;
+				fa.out = dst;
 				fa.out_sx = 1L << j;
 				fa.out_sy = vsy << j;
 				fa.out_sz = vsz << j;
@@ -111,7 +89,7 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 			S = (float *)g.stage_img;
 		}
 		FwdLevelArgs a;
-		a.in = b.in; a.in_pitch = b.sy; a.in_bstride = b.sz;
+		a.in = b.in; a.in_pitch = j ? b.sy : ssy; a.in_bstride = j ? b.sz : ssz;
 		a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
 		a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
 		a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
@@ -128,11 +106,41 @@ int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t s
 		if (in_place[j])
 			continue;
 		const Lvl &c = L[j];
-		hipError_t e = launch_lattice_scatter(c.out, c.sy, c.sz, (float *)dst, 1L << j, vsy << j, vsz << j, c.lx, c.ly, c.lz, nx, g.stream);
+		hipError_t e = launch_lattice_scatter(c.out, c.sy, c.sz, dst, 1L << j, vsy << j, vsz << j, c.lx, c.ly, c.lz, nx, g.stream);
 		if (e != hipSuccess)
 			return fail("lattice scatter failed: %s", hipGetErrorString(e));
 	}
 	return 0;
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+
+// Forward 3-D transform, OUT OF PLACE: the layout and arithmetic of cdf97_3f_op_sep_horizontal_s
+// (src/volume-dwt.c:727-785: copy each x line to the destination, then lift x, y, z there), the
+// entry the reference's own 3-D perf test drives (volume_perftest_fwd97op_s, src/volume.c).
+// Level j reads a dense volume and writes a dense volume, so each level is ONE fused pass
+// (k_vol_fwd_fused) where that kernel applies and the two-pass path (xy sweep, z sweep through
+// the scratch volume) elsewhere; the even-even-even samples go to the next level densely.  A fused
+// level >= 1 writes its result straight into its lattice of the destination (stride 2^j in x, y
+// and z); the two-pass levels keep a dense result that is scattered there at the end.
+int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
+{
+	if (check_inited())
+		return 1;
+	if (!src || !dst || !dwt_hip_is_device_pointer(src) || !dwt_hip_is_device_pointer(dst))
+		return fail("dwt_hip_transform3d_op takes device pointers");
+	if (src == dst)
+		return fail("dwt_hip_transform3d_op is out of place; use dwt_hip_transform3d for in-place volumes");
+	if ((stride_y & 3) || (stride_z & 3) || stride_y < (size_t)nx * 4 || stride_z < stride_y * (size_t)ny)
+		return fail("bad volume strides");
+	if (levels > kMaxVolLevels)
+		return fail("too many levels");
+	if (levels >= 1 && (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2))
+		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
+	const long vsy = (long)stride_y / 4, vsz = (long)stride_z / 4;
+	return vol_forward_op((const float *)src, vsy, vsz, (float *)dst, vsy, vsz, nx, ny, nz, levels);
 }
 
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z, int nx, int ny, int nz, int levels)
@@ -148,6 +156,45 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 	// every level needs at least 2 samples per axis (the reference asserts >= 5, dwt-simple.c:2172)
 	if (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2)
 		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
+	// Forward, where the fused one-pass level applies: the out-of-place levels into a dense result
+	// volume, then ONE copy back -- 8 + 8 B per voxel for level 0 like the two passes, but the
+	// deeper levels, their lattice packing and unpacking ride along for free and both halves run
+	// at better rates (1024^3: 3.1 against 3.3-3.4 ms for one level, 3.9 against 4.4-4.6 for three).
+	// The inverse has no one-pass kernel and stays on the two passes below.
+	if (!inverse && g.vol.inplace_fused && !g.force_generic && g.vol.fused >= 1) {
+		VolFusedArgs t{(const float *)vol, (long)stride_y / 4, (long)stride_z / 4, nullptr, 0, 0, nullptr, 0, 0, nx, ny, nz};
+		// pays from about 2 GiB on: below, the two passes run partly out of the 256 MiB Infinity Cache
+		// (512^3: 0.44 ms in two passes, 0.29 + 0.2 fused + copy)
+		const bool big = (size_t)nx * ny * nz >= ((size_t)1 << 29);
+		if (levels <= kMaxVolLevels && (g.vol.fused >= 2 || (big && vol_fused_applies(t)))) {
+			const long osy = align_up(nx, 4), osz = osy * ny;
+			if (grow(&g.vol_out, &g.vol_out_bytes, (size_t)osz * nz * 4))
+				return 1;
+			float *out = (float *)g.vol_out;
+			if (vol_forward_op((const float *)vol, (long)stride_y / 4, (long)stride_z / 4, out, osy, osz, nx, ny, nz, levels))
+				return 1;
+			// copy back: all rows at once when the slices of the caller's volume are contiguous rows,
+			// and as rows of 64 KiB when the volume is one contiguous block
+			const size_t row = (size_t)nx * 4, total = row * ny * nz;
+			const bool flat = stride_z == stride_y * (size_t)ny && (long)ny * nz <= 0x7fffffffL;
+			const bool block = flat && stride_y == row && (size_t)osy * 4 == row && total % 65536 == 0 && total / 65536 <= 0x7fffffffUL;
+			const int nrect = flat ? 1 : nz;
+			for (int k = 0; k < nrect; k++) {
+				CopyRects r{};
+				r.n = 1;
+				r.src[0] = (const char *)(out + (long)k * osz);
+				r.dst[0] = (char *)vol + (size_t)k * stride_z;
+				r.spitch[0] = block ? 65536 : osy * 4;
+				r.dpitch[0] = block ? 65536 : (long)stride_y;
+				r.wbytes[0] = block ? 65536 : (int)row;
+				r.h[0] = block ? (int)(total / 65536) : flat ? ny * nz : ny;
+				hipError_t e = launch_copy_rects(r, g.stream);
+				if (e != hipSuccess)
+					return fail("volume copy-back launch failed: %s", hipGetErrorString(e));
+			}
+			return 0;
+		}
+	}
 	// scratch: S (pass-to-pass buffer) and, for levels >= 1, dense copies P[j] of the
 	// level-j lattice (even-even-even samples of level j-1), all carved from one buffer
 	const long s_sy = align_up(nx, 4), s_sz = s_sy * ny;

@@ -499,12 +499,13 @@ __global__ __launch_bounds__(256) void k_copy_rects(CopyRects r)
 	const char *s = r.src[k] + (long)by * kRows * r.spitch[k] + x;
 	char *d = r.dst[k] + (long)by * kRows * r.dpitch[k] + x;
 	const int rows = min(kRows, r.h[k] - by * kRows);
+	// rows past the end load the last row again (never stored): straight-line loads, all eight in
+	// flight (with the loads under `if (i < rows)` the compiler built a 236-register kernel)
 	if constexpr (VEC == 16) {
 		u4 v[kRows];
 #pragma unroll
 		for (int i = 0; i < kRows; i++)
-			if (i < rows)
-				v[i] = __builtin_nontemporal_load((const u4 *)(s + (long)i * r.spitch[k]));
+			v[i] = __builtin_nontemporal_load((const u4 *)(s + (long)min(i, rows - 1) * r.spitch[k]));
 #pragma unroll
 		for (int i = 0; i < kRows; i++)
 			if (i < rows)
@@ -513,8 +514,7 @@ __global__ __launch_bounds__(256) void k_copy_rects(CopyRects r)
 		unsigned v[kRows];
 #pragma unroll
 		for (int i = 0; i < kRows; i++)
-			if (i < rows)
-				v[i] = *(const unsigned *)(s + (long)i * r.spitch[k]);
+			v[i] = *(const unsigned *)(s + (long)min(i, rows - 1) * r.spitch[k]);
 #pragma unroll
 		for (int i = 0; i < kRows; i++)
 			if (i < rows)

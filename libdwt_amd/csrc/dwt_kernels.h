@@ -82,6 +82,7 @@ struct VolTuning {
 	int tile_pairs = 0; // slice pairs per wave; 0 = choose from the volume depth
 	int nt = -1;        // bit 0 non-temporal stores, bit 1 non-temporal loads; -1 = measured default
 	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
+	int inplace_fused = 1; // in-place forward calls: fused levels into a result volume + one copy back (0: two passes per level)
 	int whole = 1;      // whole-tile variant of the fused kernel where the volume allows (0: the general one)
 	int direct = 2;     // fused levels >= 1 write into their lattice of the destination: 2 = level 1 merged with level 0's withheld rows where the sizes allow, 1 = strided stores, 0 = dense volume + scatter pass
 	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes

@@ -50,6 +50,49 @@ def oracle_multilevel(oracle, v, levels, inverse):
     return v
 
 
+@pytest.mark.parametrize("pad_y,pad_z", [(0, 0), (16, 0), (0, 2), (48, 3)], ids=["dense", "padded-rows", "padded-slices", "padded-both"])
+@pytest.mark.parametrize("shape,levels", [((40, 64, 256), 1), ((33, 65, 129), 2), ((66, 70, 512), 3), ((24, 40, 300), 1)], ids=lambda v: str(v))
+def test_in_place_forward_through_the_fused_levels(dwt, oracle, shape, levels, pad_y, pad_z):
+    """dwt_hip_transform3d forward where the one-pass level applies (forced here by vol_fused=2 so
+    that small volumes take it): the out-of-place levels into a result volume, one copy back; same
+    bits as the two passes per level, the padding between rows and slices untouched."""
+    nz, ny, nx = shape
+    sy, sz = nx * 4 + pad_y, 0
+    sz = sy * ny + pad_z * sy
+    rng = np.random.default_rng(sum(shape) * 7 + levels)
+    vol = rng.random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), levels, False)
+    raw = np.full(sz * nz, 0xA5, np.uint8)
+    view = np.lib.stride_tricks.as_strided(raw.view(np.float32), shape=shape, strides=(sz, sy, 4))
+    view[...] = vol
+    ptr = dwt.lib.dwt_hip_malloc(raw.nbytes)
+    assert dwt.lib.dwt_hip_memcpy_h2d(ptr, raw.ctypes.data, raw.nbytes) == 0
+    dwt.set_option("vol_fused", 2)
+    try:
+        dwt.transform3d(0, ptr, sy, sz, nx, ny, nz, levels)
+    finally:
+        dwt.set_option("vol_fused", 1)
+    back = np.empty_like(raw)
+    assert dwt.lib.dwt_hip_memcpy_d2h(back.ctypes.data, ptr, raw.nbytes) == 0
+    got = np.lib.stride_tricks.as_strided(back.view(np.float32), shape=shape, strides=(sz, sy, 4))
+    assert np.array_equal(bits(np.ascontiguousarray(got)), bits(want))
+    # nothing outside the samples was written
+    mask = np.ones(raw.shape, bool)
+    np.lib.stride_tricks.as_strided(mask, shape=(nz, ny, nx * 4), strides=(sz, sy, 1))[...] = False
+    assert np.all(back[mask] == 0xA5)
+    # and the two-pass in-place path agrees
+    assert dwt.lib.dwt_hip_memcpy_h2d(ptr, raw.ctypes.data, raw.nbytes) == 0
+    dwt.set_option("vol_inplace_fused", 0)
+    try:
+        dwt.transform3d(0, ptr, sy, sz, nx, ny, nz, levels)
+    finally:
+        dwt.set_option("vol_inplace_fused", 1)
+    back2 = np.empty_like(raw)
+    assert dwt.lib.dwt_hip_memcpy_d2h(back2.ctypes.data, ptr, raw.nbytes) == 0
+    assert np.array_equal(back, back2)
+    dwt.lib.dwt_hip_free(ptr)
+
+
 def test_golden_single_level(dwt):
     for meta, src, fwd, inv in golden_cases("cdf97_3d_s"):
         d = DevVol(dwt, src)

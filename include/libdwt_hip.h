@@ -67,7 +67,15 @@ void dwt_hip_sync(void);
 /* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).
  * Names: "generic" (1 = force the exact line-pass kernels), "cpt" (0/4/8),
  * "wave_horiz" (0/1), "ring" (8/16), "nt" and "nt_inv" (bit 0 nt stores, bit 1 nt loads),
- * "tile_pairs" (0 = auto), "waves" (1..4), "xcd_swizzle" (0/1). */
+ * "tile_pairs" (0 = auto), "waves" (1..4), "xcd_swizzle" (0/1), "fma", "fused_d".
+ * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two
+ * passes), "vol_whole" (1 = whole-tile kernel variant where the x size is a multiple of 256),
+ * "vol_direct" (levels >= 1 into their lattice of the destination: 2 = rows shared by levels 0
+ * and 1 written once, 1 = sample-wise stores, 0 = dense results + scatter passes), "vol_nt"
+ * (-1 = default: cacheable loads, non-temporal stores; bit 0 nt stores, bit 1 nt loads, bit 2
+ * halo columns exempt), "vol_rows" (8 / 6 output rows per wave), "vol_tile_pairs",
+ * "vol_swizzle", "vol_inplace_fused" (in-place forward calls of 2 GiB and more through the
+ * one-pass levels + one copy back).  Every setting gives the same bits. */
 int dwt_hip_set_option(const char *name, int value);
 int dwt_hip_get_option(const char *name);
 

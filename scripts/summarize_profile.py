@@ -43,7 +43,9 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for k, v in acc.items():
         pmc[k] = sum(v) / len(v)
 
-images = int(os.environ.get("IMAGES_PER_LAUNCH", "8"))
+# images per launch = grid.y of the level-0 launch (one blockIdx.y per image); env overrides
+gy = max(int(r["Grid_Size_Y"]) for r in sweeps if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == gmax)
+images = int(os.environ.get("IMAGES_PER_LAUNCH", gy))
 summary = {
     "tag": tag,
     "kernel": f"dwt::k_fwd_sweep<dwt::Cdf97S, 8, 16, 7> (level 0: {images} images of 8192x8192 float per launch)",

@@ -164,6 +164,43 @@ def test_out_of_place_forward_vs_oracle(dwt, oracle, shape, levels, fused):
     dst.free()
 
 
+@pytest.mark.parametrize("shape,levels", [((66, 70, 512), 3), ((40, 33, 1024), 2), ((30, 50, 300), 2)], ids=lambda v: str(v))
+def test_out_of_place_padded_strides(dwt, oracle, shape, levels):
+    """dwt_hip_transform3d_op on volumes whose rows and slices are padded (volume_t strides): the
+    fused levels, the merged rows of levels 0 / 1 and the lattice scatter all address through the
+    strides; the padding of the destination stays untouched."""
+    nz, ny, nx = shape
+    sy = nx * 4 + 80
+    sz = sy * (ny + 3)
+    rng = np.random.default_rng(sum(shape) * 11 + levels)
+    vol = rng.random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), levels, False)
+    raw = np.full(sz * nz, 0x5A, np.uint8)
+    np.lib.stride_tricks.as_strided(raw.view(np.float32), shape=shape, strides=(sz, sy, 4))[...] = vol
+    src = dwt.lib.dwt_hip_malloc(raw.nbytes)
+    dst = dwt.lib.dwt_hip_malloc(raw.nbytes)
+    fill = np.full(sz * nz, 0xC3, np.uint8)
+    assert dwt.lib.dwt_hip_memcpy_h2d(src, raw.ctypes.data, raw.nbytes) == 0
+    assert dwt.lib.dwt_hip_memcpy_h2d(dst, fill.ctypes.data, fill.nbytes) == 0
+    dwt.set_option("vol_fused", 2)
+    try:
+        dwt.transform3d_op(src, dst, sy, sz, nx, ny, nz, levels)
+    finally:
+        dwt.set_option("vol_fused", 1)
+    back = np.empty_like(raw)
+    assert dwt.lib.dwt_hip_memcpy_d2h(back.ctypes.data, dst, raw.nbytes) == 0
+    got = np.lib.stride_tricks.as_strided(back.view(np.float32), shape=shape, strides=(sz, sy, 4))
+    assert np.array_equal(bits(np.ascontiguousarray(got)), bits(want))
+    mask = np.ones(raw.shape, bool)
+    np.lib.stride_tricks.as_strided(mask, shape=(nz, ny, nx * 4), strides=(sz, sy, 1))[...] = False
+    assert np.all(back[mask] == 0xC3), "padding of the destination written"
+    same = np.empty_like(raw)
+    assert dwt.lib.dwt_hip_memcpy_d2h(same.ctypes.data, src, raw.nbytes) == 0
+    assert np.array_equal(same, raw), "source modified"
+    dwt.lib.dwt_hip_free(src)
+    dwt.lib.dwt_hip_free(dst)
+
+
 def test_out_of_place_zero_levels_and_errors(dwt):
     vol = np.random.default_rng(1).random((4, 5, 6), dtype=np.float32)
     src = DevVol(dwt, vol)

@@ -82,9 +82,10 @@ static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long
 		}
 		// two passes through the scratch volume
 		if (!S) {
-			s_sy = align_up(nx, 4);
-			s_sz = s_sy * ny;
-			if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
+			// sized for the first level that needs it (the deeper ones are smaller)
+			s_sy = align_up(b.lx, 4);
+			s_sz = s_sy * b.ly;
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * b.lz * 4))
 				return 1;
 			S = (float *)g.stage_img;
 		}

@@ -33,6 +33,33 @@ static __device__ __forceinline__ void dma4(const void *g, void *l)
 		(__attribute__((address_space(3))) void *)l, 4, 0, AUX);
 }
 
+// Row-wise buffer addressing: a descriptor per row (wave-uniform base, length in bytes) and a
+// per-lane byte offset.  The hardware drops stores and zero-fills loads whose offset is past the
+// row's end, so a tile that overhangs the image needs no per-lane branches.
+typedef __amdgpu_buffer_rsrc_t row_rsrc_t;
+static __device__ __forceinline__ row_rsrc_t row_rsrc(const void *base, unsigned bytes)
+{
+	return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+
+template <int AUX = 0>
+static __device__ __forceinline__ void dma16_row(row_rsrc_t r, unsigned byte_off, void *l)
+{
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, byte_off, 0, 0, AUX);
+}
+
+template <bool NT>
+static __device__ __forceinline__ void store16_row(row_rsrc_t r, unsigned byte_off, u4 v)
+{
+	__builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, NT ? 2 : 0);
+}
+
+template <bool NT>
+static __device__ __forceinline__ void store8_row(row_rsrc_t r, unsigned byte_off, u2 v)
+{
+	__builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, NT ? 2 : 0);
+}
+
 template <bool NT, class V>
 static __device__ __forceinline__ void store_vec(V *p, V v)
 {

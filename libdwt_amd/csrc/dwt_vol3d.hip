@@ -228,9 +228,11 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 // of the destination; 2 and 3 = levels 0 and 1 of a call whose rows with even y and even z are
 // written ONCE: level 0 (2) withholds them and parks their odd-x samples in `side`, level 1 (3)
 // writes them whole, its own samples interleaved with the parked ones (which it brings in by
-// LDS-DMA one iteration ahead: no registers, no exposed latency); 4 = 0 for volumes of whole,
-// aligned 256-column tiles (like 2 and 3: without the column-by-column staging and the bounded
-// stores of overhanging tiles the vertical / z phase needs 14 instead of 52 accumulator registers).
+// LDS-DMA one iteration ahead: no registers, no exposed latency); 4 = 0 for volumes with 16-byte
+// aligned rows and an x size that is a multiple of 4 (every lane's four columns are inside or
+// outside the volume together: without the column-by-column staging and the bounded stores of the
+// general kernel the vertical / z phase needs no accumulator registers; 2 and 3 likewise, for
+// whole 256-column tiles).
 template <int NT, int RW, int MODE>
 __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
 {
@@ -269,16 +271,13 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 	// MODE 3: the parked rows of this wave's 2 RW output rows, 1 KiB each
 	char *parked = slab + (size_t)NR * TW * 4 + (size_t)wv * 2 * RW * TW * 4;
 	const unsigned parked_off = lds_offset(parked);
-	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx);
 	// tiles that overhang the volume (or unaligned volumes) are staged column by column
 	const bool full = MODE >= 2 || (vec_ok && c0 + TW <= a.nx);
 	// interior tiles fetch each 4-column halo as ONE aligned 16 B piece (two lanes) instead of four
 	// 4 B ones; tiles at the volume's x borders reflect column by column
 	const bool halo16 = full && c0 >= 4 && c0 + TW + 4 <= a.nx;
-	int colmap[CPT];
-#pragma unroll
-	for (int i = 0; i < CPT; i++)
-		colmap[i] = reflect(c0 + i * 64 + lane, a.nx);
+	// (the reflected source columns of overhanging and border tiles are recomputed where they are
+	// used: kept in registers across the march they cost 40 accumulator registers)
 
 	auto issue = [&](int t) {
 		const float *sl = a.in + (long)reflect(2 * q0 - 1 + t, a.nz) * a.in_sz;
@@ -289,17 +288,25 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 				const float *grow = sl + (long)r * a.in_sy;
 				char *lrow = ring + (size_t)i * RS * 4;
 				if (full) {
-					dma16<kLdAux>(grow + c, lrow); // the DMA places lane i's 16 B at lrow + 16 i
+					// the DMA places lane i's 16 B at lrow + 16 i; in a tile that overhangs the volume
+					// (MODE >= 2, x size a multiple of 4) the lanes beyond the edge stay out and the four
+					// reflected columns next to the edge -- all a valid output can reach -- come one by one
+					if constexpr (MODE >= 2)
+						dma16_row<kLdAux>(row_rsrc(grow, (unsigned)a.nx * 4), (unsigned)c * 4, lrow);
+					else
+						dma16<kLdAux>(grow + c, lrow);
+					if (MODE >= 2 && c0 + TW > a.nx && lane < 4)
+						dma4<kLdAux>(grow + reflect(a.nx + lane, a.nx), lrow + (a.nx - c0) * 4);
 				} else {
 #pragma unroll
 					for (int e = 0; e < CPT; e++)
-						dma4<kLdAux>(grow + colmap[e], lrow + e * 256);
+						dma4<kLdAux>(grow + reflect(c0 + e * 64 + lane, a.nx), lrow + e * 256);
 				}
 				if (halo16) {
 					if (lane < 2)
 						dma16<kHaloAux>(grow + (lane == 0 ? c0 - 4 : c0 + TW), lrow + TW * 4);
 				} else if (lane < 8) {
-					dma4<kHaloAux>(grow + halo_col, lrow + TW * 4);
+					dma4<kHaloAux>(grow + reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.nx), lrow + TW * 4);
 				}
 			}
 		}
@@ -378,10 +385,10 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 				for (int r = 0; r < RW; r++) {
 					const int y = y0 + RW * wv + r;
 					if (y < a.ny) {
-						const float *sp = a.side + (long)(2 * k1) * a.side_sz + (long)y * a.side_sy + c;
-						dma16<0>(sp, parked + (size_t)(2 * r) * TW * 4);
+						const float *sp = a.side + (long)(2 * k1) * a.side_sz + (long)y * a.side_sy;
+						dma16_row<0>(row_rsrc(sp, (unsigned)a.nx * 4), (unsigned)c * 4, parked + (size_t)(2 * r) * TW * 4);
 						if (2 * k1 + 1 < a.nz)
-							dma16<0>(sp + a.side_sz, parked + (size_t)(2 * r + 1) * TW * 4);
+							dma16_row<0>(row_rsrc(sp + a.side_sz, (unsigned)a.nx * 4), (unsigned)c * 4, parked + (size_t)(2 * r + 1) * TW * 4);
 					}
 				}
 			}
@@ -446,28 +453,34 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + (MODE == 1 ? c * a.out_sx : MODE == 3 ? 2L * c : (long)c);
 				const bool hz = 2 * k + 1 < a.nz;
 				float *pl = a.lll && !(r & 1) ? a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1) : nullptr;
+				// MODE >= 2: rows as buffers -- the lanes beyond the edge of a tile that overhangs the
+				// volume are dropped by the hardware's bounds check, no per-lane branches
+				[[maybe_unused]] const float *row0 = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy;
+				[[maybe_unused]] const bool to_lll = a.lll && !(r & 1);
 				if constexpr (MODE == 3) {
-					// (host: whole tiles only) own samples at even x, level 0's parked ones at odd x
+					// own samples at even x, level 0's parked ones at odd x: a row of 2 nx samples
 					u4 s0, s1;
 					lds_read2(parked_off + (unsigned)(2 * r) * TW * 4 + lane * 16, parked_off + (unsigned)(2 * r + 1) * TW * 4 + lane * 16, s0, s1);
-					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), s0[0], to_bits(o0[1]), s0[1]});
-					store_vec<kNtStore>((u4 *)p + 1, u4{to_bits(o0[2]), s0[2], to_bits(o0[3]), s0[3]});
+					const row_rsrc_t d0 = row_rsrc(row0, (unsigned)a.nx * 8);
+					store16_row<kNtStore>(d0, (unsigned)c * 8, u4{to_bits(o0[0]), s0[0], to_bits(o0[1]), s0[1]});
+					store16_row<kNtStore>(d0, (unsigned)c * 8 + 16, u4{to_bits(o0[2]), s0[2], to_bits(o0[3]), s0[3]});
 					if (hz) {
-						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), s1[0], to_bits(o1[1]), s1[1]});
-						store_vec<kNtStore>((u4 *)(p + a.out_sz) + 1, u4{to_bits(o1[2]), s1[2], to_bits(o1[3]), s1[3]});
+						const row_rsrc_t d1 = row_rsrc(row0 + a.out_sz, (unsigned)a.nx * 8);
+						store16_row<kNtStore>(d1, (unsigned)c * 8, u4{to_bits(o1[0]), s1[0], to_bits(o1[1]), s1[1]});
+						store16_row<kNtStore>(d1, (unsigned)c * 8 + 16, u4{to_bits(o1[2]), s1[2], to_bits(o1[3]), s1[3]});
 					}
-					if (pl)
-						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+					if (to_lll)
+						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 				} else if constexpr (MODE == 2) {
-					// (host: whole tiles only) rows with even y in the even slice are level 1's to write
+					// rows with even y in the even slice are level 1's to write
 					if (r & 1)
-						store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
+						store16_row<kNtStore>(row_rsrc(row0, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
 					else
-						store_vec<kNtStore>((u2 *)(a.side + (long)k * a.side_sz + (long)(y >> 1) * a.side_sy + (c >> 1)), u2{to_bits(o0[1]), to_bits(o0[3])});
+						store8_row<kNtStore>(row_rsrc(a.side + (long)k * a.side_sz + (long)(y >> 1) * a.side_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[1]), to_bits(o0[3])});
 					if (hz)
-						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
-					if (pl)
-						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+						store16_row<kNtStore>(row_rsrc(row0 + a.out_sz, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
+					if (to_lll)
+						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 				} else if constexpr (MODE == 1) {
 					// a level >= 1 writing into its lattice of the destination volume
 #pragma unroll
@@ -482,11 +495,19 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 					if (full && pl)
 						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
 				} else if (MODE == 4 || full) {
-					store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
-					if (hz)
-						store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
-					if (pl)
-						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+					if constexpr (MODE == 4) {
+						store16_row<kNtStore>(row_rsrc(row0, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
+						if (hz)
+							store16_row<kNtStore>(row_rsrc(row0 + a.out_sz, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
+						if (to_lll)
+							store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
+					} else {
+						store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
+						if (hz)
+							store_vec<kNtStore>((u4 *)(p + a.out_sz), u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
+						if (pl)
+							*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+					}
 				} else {
 #pragma unroll
 					for (int e = 0; e < CPT; e++)
@@ -563,11 +584,11 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	int mode = a.mode;
 	if (mode < 0 || mode > 3)
 		return hipErrorInvalidValue;
-	if (mode == 0 && vt.whole && vol_fused_vec_ok(a) && a.nx % 256 == 0)
+	if (mode == 0 && vt.whole && vol_fused_vec_ok(a) && a.nx % 4 == 0)
 		mode = 4;
 	if (mode >= 1 && mode <= 3 && rw != 8) // the multi-level store variants exist for the default row count
 		return hipErrorInvalidValue;
-	if ((mode == 2 || mode == 3) && (!vol_fused_vec_ok(a) || a.nx % 256 || !a.side || ((uintptr_t)a.side & 15) || a.side_sy % 4 || a.side_sz % 4))
+	if ((mode == 2 || mode == 3) && (!vol_fused_vec_ok(a) || a.nx % 4 || !a.side || ((uintptr_t)a.side & 15) || a.side_sy % 4 || a.side_sz % 4))
 		return hipErrorInvalidValue;
 #define DWT_VOL_GO(NT_, RW_, MODE_) return vol_fused_launch<NT_, RW_, MODE_>(a, tp, ntx, nty, nzt, swz, s)
 	if (mode == 4 && rw == 8) {

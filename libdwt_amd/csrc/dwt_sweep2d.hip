@@ -185,13 +185,14 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	char *ring = smem + (size_t)wv * kRing * RS * 4;
 	const unsigned ring_off = lds_offset(ring);
 
-	const bool full = (c0 + TW <= a.W);
-	const bool main16 = full && g.in_vec_ok;
-	// source columns for the element-wise loader (partial / unaligned tiles)
-	int colmap[CPT];
-#pragma unroll
-	for (int i = 0; i < CPT; i++)
-		colmap[i] = reflect(c0 + i * 64 + lane, a.W);
+	// Rows are addressed as BUFFERS (a descriptor per row in scalar registers, per-lane byte
+	// offsets): the hardware checks every dword against the row's length, zero-fills loads and
+	// drops stores beyond it, and 16-byte accesses need only 4-byte alignment (probed:
+	// scripts/probes/buf_probe.hip).  So every tile -- overhanging the image or not, rows aligned
+	// or not -- takes the same 16-byte path; the up to four reflected columns right of the edge
+	// that a valid output can reach come by one 4-byte DMA per row.
+	const int n_edge = min(4, c0 + TW - a.W); // columns of this tile's main block right of the edge (<= 0: none)
+	const int edge_col = reflect(a.W + min(lane, 3), a.W);
 	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
 
 	int islot = 0, rslot = 0; // ring slots of the next rows to fill / to consume
@@ -203,15 +204,12 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 			const int r = tall ? reflect1(ri, a.H) : reflect(ri, a.H);
 			char *lrow = ring + (size_t)(islot + rr) * RS * 4;
 			const T *grow = in + (long)r * a.in_pitch;
-			if (main16) {
+			const row_rsrc_t rs = row_rsrc(grow, (unsigned)a.W * 4);
 #pragma unroll
-				for (int i = 0; i < CPT / 4; i++)
-					dma16<kLdAux>(grow + c0 + i * 256 + lane * 4, lrow + i * 1024);
-			} else {
-#pragma unroll
-				for (int i = 0; i < CPT; i++)
-					dma4<kLdAux>(grow + colmap[i], lrow + i * 256);
-			}
+			for (int i = 0; i < CPT / 4; i++)
+				dma16_row<kLdAux>(rs, (unsigned)(c0 + i * 256 + lane * 4) * 4, lrow + i * 1024);
+			if (lane < n_edge)
+				dma4<kLdAux>(grow + edge_col, lrow + (a.W - c0) * 4);
 			if (lane < 8)
 				dma4<kLdAux>(grow + halo_col, lrow + TW * 4);
 		}
@@ -323,82 +321,50 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 		if constexpr (IL) {
 			if (it >= K) {
 				const int k = A + it - K;
-				const int c = c0 + lane * CPT;
-				T *r0 = out_h + (long)(2 * k) * a.h_pitch + c;
-				T *r1 = r0 + a.h_pitch;
-				const bool hrow = 2 * k + 1 < a.H;
-				if (full && g.out_vec_ok) {
+				const unsigned cb = (unsigned)(c0 + lane * CPT) * 4; // byte offset in an interleaved row
+				const T *r0 = out_h + (long)(2 * k) * a.h_pitch;
+				const row_rsrc_t d0 = row_rsrc(r0, (unsigned)a.W * 4);
 #pragma unroll
-					for (int e = 0; e < CPT; e += 4) {
-						store_vec<kNtStore>((u4 *)(r0 + e), u4{to_bits(lo[e]), to_bits(lo[e + 1]), to_bits(lo[e + 2]), to_bits(lo[e + 3])});
-						if (hrow)
-							store_vec<kNtStore>((u4 *)(r1 + e), u4{to_bits(hi[e]), to_bits(hi[e + 1]), to_bits(hi[e + 2]), to_bits(hi[e + 3])});
-					}
-				} else {
+				for (int e = 0; e < CPT; e += 4)
+					store16_row<kNtStore>(d0, cb + e * 4, u4{to_bits(lo[e]), to_bits(lo[e + 1]), to_bits(lo[e + 2]), to_bits(lo[e + 3])});
+				if (2 * k + 1 < a.H) {
+					const row_rsrc_t d1 = row_rsrc(r0 + a.h_pitch, (unsigned)a.W * 4);
 #pragma unroll
-					for (int e = 0; e < CPT; e++)
-						if (c + e < a.W) {
-							r0[e] = lo[e];
-							if (hrow)
-								r1[e] = hi[e];
-						}
+					for (int e = 0; e < CPT; e += 4)
+						store16_row<kNtStore>(d1, cb + e * 4, u4{to_bits(hi[e]), to_bits(hi[e + 1]), to_bits(hi[e + 2]), to_bits(hi[e + 3])});
 				}
 				// multi-level: the next level's input (even row, even column) also goes
 				// out densely, so that no level has to gather a strided lattice
 				if (a.il_ll) {
-					T *ll = out_ll + (long)k * a.ll_pitch + (c >> 1);
-					if (full && g.ll_vec_ok) {
+					const row_rsrc_t dl = row_rsrc(out_ll + (long)k * a.ll_pitch, (unsigned)Wd * 4);
 #pragma unroll
-						for (int e = 0; e < CPT; e += 4)
-							store_vec<false>((u2 *)(ll + (e >> 1)), u2{to_bits(lo[e]), to_bits(lo[e + 2])});
-					} else {
-#pragma unroll
-						for (int e = 0; e < CPT; e += 2)
-							if (c + e < a.W)
-								ll[e >> 1] = lo[e];
-					}
+					for (int e = 0; e < CPT; e += 4)
+						store8_row<false>(dl, cb / 2 + e * 2, u2{to_bits(lo[e]), to_bits(lo[e + 2])});
 				}
 			}
 		} else
 		if (it >= K) {
+			// Mallat rows: [LL (Wd) | HL (W/2)] at row k, [LH | HH] at row Hd + k; each quarter row is a
+			// buffer of its own, so the lanes (and dwords) beyond its end are dropped
 			const int k = A + it - K;
-			const int cl = (c0 + lane * CPT) >> 1;
-			T *ll = out_ll + (long)k * a.ll_pitch + cl;
-			T *hl = out_h + (long)k * a.h_pitch + Wd + cl;
-			T *lh = out_h + (long)(Hd + k) * a.h_pitch + cl;
-			T *hh = lh + Wd;
+			const unsigned clb = (unsigned)((c0 + lane * CPT) >> 1) * 4;
+			const T *top = out_h + (long)k * a.h_pitch, *bot = out_h + (long)(Hd + k) * a.h_pitch;
+			const unsigned nlb = (unsigned)Wd * 4, nhb = (unsigned)(a.W >> 1) * 4;
+			const row_rsrc_t dll = row_rsrc(out_ll + (long)k * a.ll_pitch, nlb), dhl = row_rsrc(top + Wd, nhb);
 			const bool hrow = k < (a.H >> 1);
-			if (full && g.out_vec_ok) {
-				if constexpr (CPT == 8) {
-					store_vec<kNtStoreLL>((u4 *)ll, u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
-					store_vec<kNtStore>((u4 *)hl, u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])});
-					if (hrow) {
-						store_vec<kNtStore>((u4 *)lh, u4{to_bits(hi[0]), to_bits(hi[2]), to_bits(hi[4]), to_bits(hi[6])});
-						store_vec<kNtStore>((u4 *)hh, u4{to_bits(hi[1]), to_bits(hi[3]), to_bits(hi[5]), to_bits(hi[7])});
-					}
-				} else {
-					store_vec<kNtStoreLL>((u2 *)ll, u2{to_bits(lo[0]), to_bits(lo[2])});
-					store_vec<kNtStore>((u2 *)hl, u2{to_bits(lo[1]), to_bits(lo[3])});
-					if (hrow) {
-						store_vec<kNtStore>((u2 *)lh, u2{to_bits(hi[0]), to_bits(hi[2])});
-						store_vec<kNtStore>((u2 *)hh, u2{to_bits(hi[1]), to_bits(hi[3])});
-					}
+			if constexpr (CPT == 8) {
+				store16_row<kNtStoreLL>(dll, clb, u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
+				store16_row<kNtStore>(dhl, clb, u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])});
+				if (hrow) {
+					store16_row<kNtStore>(row_rsrc(bot, nlb), clb, u4{to_bits(hi[0]), to_bits(hi[2]), to_bits(hi[4]), to_bits(hi[6])});
+					store16_row<kNtStore>(row_rsrc(bot + Wd, nhb), clb, u4{to_bits(hi[1]), to_bits(hi[3]), to_bits(hi[5]), to_bits(hi[7])});
 				}
 			} else {
-				const int nl = Wd, nh = a.W >> 1;
-#pragma unroll
-				for (int v = 0; v < CPT; v += 2) {
-					const int ci = cl + (v >> 1);
-					if (ci < nl) {
-						ll[v >> 1] = lo[v];
-						if (hrow)
-							lh[v >> 1] = hi[v];
-					}
-					if (ci < nh) {
-						hl[v >> 1] = lo[v + 1];
-						if (hrow)
-							hh[v >> 1] = hi[v + 1];
-					}
+				store8_row<kNtStoreLL>(dll, clb, u2{to_bits(lo[0]), to_bits(lo[2])});
+				store8_row<kNtStore>(dhl, clb, u2{to_bits(lo[1]), to_bits(lo[3])});
+				if (hrow) {
+					store8_row<kNtStore>(row_rsrc(bot, nlb), clb, u2{to_bits(hi[0]), to_bits(hi[2])});
+					store8_row<kNtStore>(row_rsrc(bot + Wd, nhb), clb, u2{to_bits(hi[1]), to_bits(hi[3])});
 				}
 			}
 		}
@@ -462,17 +428,15 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	char *ring = smem + (size_t)wv * kRing * RS * 4;
 	const unsigned ring_off = lds_offset(ring);
 
-	const bool full = (c0 + TW <= a.W);
-	const bool main16 = full && g.in_vec_ok;
-	// element-wise loader: element e of a subband segment <-> subband column cl0+e,
-	// reflected through the interleaved index so that parity is preserved
-	int colmapL[CPT / 2], colmapH[CPT / 2];
-#pragma unroll
-	for (int i = 0; i < CPT / 2; i++) {
-		const int e = cl0 + i * 64 + lane;
-		colmapL[i] = reflect(2 * e, a.W) >> 1;
-		colmapH[i] = reflect(2 * e + 1, a.W) >> 1;
-	}
+	// Whole tiles fetch their subband segments as plain 16-byte DMAs (4-byte alignment is enough);
+	// the tile that holds the image's right edge addresses the segments as BUFFERS (bounds-checked
+	// per dword: zero fill beyond a segment's end, nothing read past the allocation) and fetches the
+	// two L and two H columns right of the edge -- all a valid output can reach -- by reflection.
+	const bool edge_tile = c0 + TW > a.W;
+	const int nL = Wd, nH = a.W >> 1; // valid columns of an L / H segment
+	// lanes 0,1: the reflected L columns nL, nL+1; lanes 2,3: the H columns nH, nH+1
+	const int edge_sub = (lane & 2) ? nH + (lane & 1) : nL + (lane & 1);
+	const int edge_col = reflect(2 * edge_sub + ((lane >> 1) & 1), a.W) >> 1;
 	// halo lanes 0..7 -> L halo, 8..15 -> H halo
 	const int hsub = (lane & 7) < 4 ? cl0 - 4 + (lane & 7) : cl0 + M + (lane & 3);
 	const int halo_col = reflect(2 * hsub + ((lane >> 3) & 1), a.W) >> 1;
@@ -498,14 +462,13 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 				// even rows come from in_ll, odd rows from in_h (reflection keeps the parity): the
 				// two may be different buffers (multi-level inverse: composed even rows)
 				const T *grow = (r & 1) ? in_h + (long)(r >> 1) * a.h_pitch : in_ll + (long)(r >> 1) * a.ll_pitch;
-				if (main16) {
+				{
+					const row_rsrc_t rs = row_rsrc(grow, (unsigned)a.W * 4);
 #pragma unroll
 					for (int i = 0; i < CPT / 4; i++)
-						dma16<kLdAux>(grow + c0 + i * 256 + lane * 4, lrow + i * 1024);
-				} else {
-#pragma unroll
-					for (int i = 0; i < CPT; i++)
-						dma4<kLdAux>(grow + colmapI[i], lrow + i * 256);
+						dma16_row<kLdAux>(rs, (unsigned)(c0 + i * 256 + lane * 4) * 4, lrow + i * 1024);
+					if (lane < min(4, c0 + TW - a.W))
+						dma4<kLdAux>(grow + reflect(a.W + min(lane, 3), a.W), lrow + (a.W - c0) * 4);
 				}
 				if (lane < 8)
 					dma4<kLdAux>(grow + halo_colI, lrow + TW * 4);
@@ -527,7 +490,7 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 				gh = gl + Wd;
 			}
 			char *lrow = ring + (size_t)((2 * it + rr) & (kRing - 1)) * RS * 4;
-			if (main16) {
+			if (!edge_tile) {
 				if constexpr (CPT == 8) {
 					dma16<kLdAux>(gl + cl0 + lane * 4, lrow);
 					dma16<kLdAux>(gh + cl0 + lane * 4, lrow + M * 4);
@@ -537,12 +500,21 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 					dma16<kLdAux>(gsel + cl0 + (lane & 31) * 4, lrow);
 				}
 			} else {
-#pragma unroll
-				for (int i = 0; i < CPT / 2; i++)
-					dma4<kLdAux>(gl + colmapL[i], lrow + i * 256);
-#pragma unroll
-				for (int i = 0; i < CPT / 2; i++)
-					dma4<kLdAux>(gh + colmapH[i], lrow + M * 4 + i * 256);
+				const row_rsrc_t rl = row_rsrc(gl, (unsigned)nL * 4), rh = row_rsrc(gh, (unsigned)nH * 4);
+				if constexpr (CPT == 8) {
+					dma16_row<kLdAux>(rl, (unsigned)(cl0 + lane * 4) * 4, lrow);
+					dma16_row<kLdAux>(rh, (unsigned)(cl0 + lane * 4) * 4, lrow + M * 4);
+				} else {
+					if (lane < 32)
+						dma16_row<kLdAux>(rl, (unsigned)(cl0 + lane * 4) * 4, lrow);
+					else
+						dma16_row<kLdAux>(rh, (unsigned)(cl0 + (lane & 31) * 4) * 4, lrow); // lane's slot is lrow + 16 lane = the H half
+				}
+				// reflected columns right of the edge that still lie in the tile's main block
+				if (lane < 2 && nL + lane < cl0 + M)
+					dma4<kLdAux>(gl + edge_col, lrow + (nL - cl0) * 4);
+				if (lane >= 2 && lane < 4 && nH + (lane & 1) < cl0 + M)
+					dma4<kLdAux>(gh + edge_col, lrow + M * 4 + (nH - cl0) * 4 - 8);
 			}
 			if (lane < 16)
 				dma4<kLdAux>((halo_is_h ? gh : gl) + halo_col, lrow + 2 * M * 4);
@@ -716,35 +688,19 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 			}
 		}
 
-		const int c = c0 + lane * CPT;
-		if (full && g.out_vec_ok) {
-			if (vo) {
-				T *o = out + (long)(2 * po + 1) * a.out_pitch + c;
+		// output rows as buffers: lanes and dwords beyond the row's end are dropped
+		const unsigned cb = (unsigned)(c0 + lane * CPT) * 4;
+		if (vo) {
+			const row_rsrc_t d = row_rsrc(out + (long)(2 * po + 1) * a.out_pitch, (unsigned)a.W * 4);
 #pragma unroll
-				for (int e = 0; e < CPT; e += 4)
-					store_vec<kNtStore>((u4 *)(o + e), u4{to_bits(orow[e]), to_bits(orow[e + 1]), to_bits(orow[e + 2]), to_bits(orow[e + 3])});
-			}
-			if (ve) {
-				T *o = out + (long)(2 * pe) * a.out_pitch + c;
+			for (int e = 0; e < CPT; e += 4)
+				store16_row<kNtStore>(d, cb + e * 4, u4{to_bits(orow[e]), to_bits(orow[e + 1]), to_bits(orow[e + 2]), to_bits(orow[e + 3])});
+		}
+		if (ve) {
+			const row_rsrc_t d = row_rsrc(out + (long)(2 * pe) * a.out_pitch, (unsigned)a.W * 4);
 #pragma unroll
-				for (int e = 0; e < CPT; e += 4)
-					store_vec<kNtStore>((u4 *)(o + e), u4{to_bits(erow[e]), to_bits(erow[e + 1]), to_bits(erow[e + 2]), to_bits(erow[e + 3])});
-			}
-		} else {
-			if (vo) {
-				T *o = out + (long)(2 * po + 1) * a.out_pitch + c;
-#pragma unroll
-				for (int e = 0; e < CPT; e++)
-					if (c + e < a.W)
-						o[e] = orow[e];
-			}
-			if (ve) {
-				T *o = out + (long)(2 * pe) * a.out_pitch + c;
-#pragma unroll
-				for (int e = 0; e < CPT; e++)
-					if (c + e < a.W)
-						o[e] = erow[e];
-			}
+			for (int e = 0; e < CPT; e += 4)
+				store16_row<kNtStore>(d, cb + e * 4, u4{to_bits(erow[e]), to_bits(erow[e + 1]), to_bits(erow[e + 2]), to_bits(erow[e + 3])});
 		}
 	}
 }

@@ -45,9 +45,8 @@ static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long
 		const bool can = t.in != t.out && t.nx >= 2 && t.ny >= 2 && t.nz >= 2;
 		return !g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(t)) || (g.vol.fused >= 2 && can));
 	};
-	// levels 0 and 1 as a pair (16-byte aligned rows and x sizes that are multiples of 4 at both levels)
-	const bool merged = levels >= 2 && g.vol.direct >= 2 && g.vol.rows != 6 && fuses(0) && fuses(1) && nx % 8 == 0 &&
-		(((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && vsy % 4 == 0 && vsz % 4 == 0 && ssy % 4 == 0 && ssz % 4 == 0;
+	// levels 0 and 1 as a pair (an even x size: level 1's merged rows are exactly twice its own)
+	const bool merged = levels >= 2 && g.vol.direct >= 2 && g.vol.whole && g.vol.rows != 6 && fuses(0) && fuses(1) && nx % 2 == 0;
 	for (int j = 0; j < levels; j++) {
 		const Lvl &b = L[j];
 		float *lll = j + 1 < levels ? (float *)L[j + 1].in : nullptr;

@@ -228,11 +228,10 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 // of the destination; 2 and 3 = levels 0 and 1 of a call whose rows with even y and even z are
 // written ONCE: level 0 (2) withholds them and parks their odd-x samples in `side`, level 1 (3)
 // writes them whole, its own samples interleaved with the parked ones (which it brings in by
-// LDS-DMA one iteration ahead: no registers, no exposed latency); 4 = 0 for volumes with 16-byte
-// aligned rows and an x size that is a multiple of 4 (every lane's four columns are inside or
-// outside the volume together: without the column-by-column staging and the bounded stores of the
-// general kernel the vertical / z phase needs no accumulator registers; 2 and 3 likewise, for
-// whole 256-column tiles).
+// LDS-DMA one iteration ahead: no registers, no exposed latency); 4 = 0 with every row addressed
+// as a buffer (per-dword hardware bounds check, 4-byte alignment suffices): without the
+// column-by-column staging and the bounded stores of the general kernel the vertical / z phase
+// needs no accumulator registers; 2 and 3 are built the same way.  0 remains as a cross-check.
 template <int NT, int RW, int MODE>
 __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFusedArgs a, int tile_pairs_z, int vec_ok, int ntx, int nty, int swz)
 {
@@ -289,13 +288,13 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 				char *lrow = ring + (size_t)i * RS * 4;
 				if (full) {
 					// the DMA places lane i's 16 B at lrow + 16 i; in a tile that overhangs the volume
-					// (MODE >= 2, x size a multiple of 4) the lanes beyond the edge stay out and the four
+					// (MODE >= 2) the dwords beyond the row's end are zero-filled by the bounds check and the four
 					// reflected columns next to the edge -- all a valid output can reach -- come one by one
 					if constexpr (MODE >= 2)
 						dma16_row<kLdAux>(row_rsrc(grow, (unsigned)a.nx * 4), (unsigned)c * 4, lrow);
 					else
 						dma16<kLdAux>(grow + c, lrow);
-					if (MODE >= 2 && c0 + TW > a.nx && lane < 4)
+					if (MODE >= 2 && lane < min(4, c0 + TW - a.nx))
 						dma4<kLdAux>(grow + reflect(a.nx + lane, a.nx), lrow + (a.nx - c0) * 4);
 				} else {
 #pragma unroll
@@ -470,17 +469,17 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 						store16_row<kNtStore>(d1, (unsigned)c * 8 + 16, u4{to_bits(o1[2]), s1[2], to_bits(o1[3]), s1[3]});
 					}
 					if (to_lll)
-						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
+						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)((a.nx + 1) >> 1) * 4), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 				} else if constexpr (MODE == 2) {
 					// rows with even y in the even slice are level 1's to write
 					if (r & 1)
 						store16_row<kNtStore>(row_rsrc(row0, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
 					else
-						store8_row<kNtStore>(row_rsrc(a.side + (long)k * a.side_sz + (long)(y >> 1) * a.side_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[1]), to_bits(o0[3])});
+						store8_row<kNtStore>(row_rsrc(a.side + (long)k * a.side_sz + (long)(y >> 1) * a.side_sy, (unsigned)(a.nx >> 1) * 4), (unsigned)c * 2, u2{to_bits(o0[1]), to_bits(o0[3])});
 					if (hz)
 						store16_row<kNtStore>(row_rsrc(row0 + a.out_sz, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
 					if (to_lll)
-						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
+						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)((a.nx + 1) >> 1) * 4), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 				} else if constexpr (MODE == 1) {
 					// a level >= 1 writing into its lattice of the destination volume
 #pragma unroll
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 						if (hz)
 							store16_row<kNtStore>(row_rsrc(row0 + a.out_sz, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o1[0]), to_bits(o1[1]), to_bits(o1[2]), to_bits(o1[3])});
 						if (to_lll)
-							store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)a.nx * 2), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
+							store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)((a.nx + 1) >> 1) * 4), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 					} else {
 						store_vec<kNtStore>((u4 *)p, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});
 						if (hz)
@@ -584,11 +583,11 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	int mode = a.mode;
 	if (mode < 0 || mode > 3)
 		return hipErrorInvalidValue;
-	if (mode == 0 && vt.whole && vol_fused_vec_ok(a) && a.nx % 4 == 0)
+	if (mode == 0 && vt.whole)
 		mode = 4;
 	if (mode >= 1 && mode <= 3 && rw != 8) // the multi-level store variants exist for the default row count
 		return hipErrorInvalidValue;
-	if ((mode == 2 || mode == 3) && (!vol_fused_vec_ok(a) || a.nx % 4 || !a.side || ((uintptr_t)a.side & 15) || a.side_sy % 4 || a.side_sz % 4))
+	if ((mode == 2 || mode == 3) && !a.side)
 		return hipErrorInvalidValue;
 #define DWT_VOL_GO(NT_, RW_, MODE_) return vol_fused_launch<NT_, RW_, MODE_>(a, tp, ntx, nty, nzt, swz, s)
 	if (mode == 4 && rw == 8) {

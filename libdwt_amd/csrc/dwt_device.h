@@ -49,6 +49,12 @@ static __device__ __forceinline__ void dma16_row(row_rsrc_t r, unsigned byte_off
 }
 
 template <bool NT>
+static __device__ __forceinline__ u4 load16_row(row_rsrc_t r, unsigned byte_off)
+{
+	return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, NT ? 2 : 0);
+}
+
+template <bool NT>
 static __device__ __forceinline__ void store16_row(row_rsrc_t r, unsigned byte_off, u4 v)
 {
 	__builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, NT ? 2 : 0);

@@ -33,45 +33,27 @@ __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, lon
 	const int B = min(A + tile_pairs, Zd);
 	const int n_iter = (B - A) + K;
 	const int q0 = A - K / 2;
-	const bool vec = vec_ok && (c + 256 * (NV - 1) + 4 <= nx);
-	const float *src = in + (long)y * in_sy + c;
-	float *dst = out + (long)y * out_sy + c;
+	// rows as buffers (per-dword hardware bounds check, 4-byte alignment suffices): the segments
+	// that overhang the volume load zeros and drop their stores, no per-lane branches
+	const float *src = in + (long)y * in_sy;
+	float *dst = out + (long)y * out_sy;
+	const unsigned cb = (unsigned)c * 4, nb_row = (unsigned)nx * 4;
 
 	auto load = [&](int slice, float (&v)[CPT]) {
-		const float *p = src + (long)reflect(slice, nz) * in_sz;
-		if (vec) {
+		const row_rsrc_t rs = row_rsrc(src + (long)reflect(slice, nz) * in_sz, nb_row);
 #pragma unroll
-			for (int g = 0; g < NV; g++) {
-				const u4 t = (NT & 2) ? __builtin_nontemporal_load((const u4 *)(p + 256 * g)) : *(const u4 *)(p + 256 * g);
+		for (int g = 0; g < NV; g++) {
+			const u4 t = load16_row<(NT & 2) != 0>(rs, cb + 1024 * g);
 #pragma unroll
-				for (int e = 0; e < 4; e++)
-					v[4 * g + e] = from_bits<float>(t[e]);
-			}
-		} else {
-#pragma unroll
-			for (int e = 0; e < CPT; e++) {
-				const int x = c + 256 * (e >> 2) + (e & 3);
-				v[e] = (x < nx) ? p[256 * (e >> 2) + (e & 3)] : 0.f;
-			}
+			for (int e = 0; e < 4; e++)
+				v[4 * g + e] = from_bits<float>(t[e]);
 		}
 	};
 	auto store = [&](int slice, const float (&v)[CPT]) {
-		float *p = dst + (long)slice * out_sz;
-		if (vec) {
+		const row_rsrc_t rd = row_rsrc(dst + (long)slice * out_sz, nb_row);
 #pragma unroll
-			for (int g = 0; g < NV; g++) {
-				const u4 t = u4{to_bits(v[4 * g]), to_bits(v[4 * g + 1]), to_bits(v[4 * g + 2]), to_bits(v[4 * g + 3])};
-				if (NT & 1)
-					__builtin_nontemporal_store(t, (u4 *)(p + 256 * g));
-				else
-					*(u4 *)(p + 256 * g) = t;
-			}
-		} else {
-#pragma unroll
-			for (int e = 0; e < CPT; e++)
-				if (c + 256 * (e >> 2) + (e & 3) < nx)
-					p[256 * (e >> 2) + (e & 3)] = v[e];
-		}
+		for (int g = 0; g < NV; g++)
+			store16_row<(NT & 1) != 0>(rd, cb + 1024 * g, u4{to_bits(v[4 * g]), to_bits(v[4 * g + 1]), to_bits(v[4 * g + 2]), to_bits(v[4 * g + 3])});
 	};
 
 	float st[K][CPT];
@@ -135,18 +117,10 @@ __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, lon
 				// forward multi-level: the next level's input (even x, even y, even z = LLL)
 				// also goes out densely, so that no lattice gather is needed
 				if (lll && !(y & 1)) {
-					float *p = lll + (long)k * lll_sz + (long)(y >> 1) * lll_sy + (c >> 1);
+					const row_rsrc_t rl = row_rsrc(lll + (long)k * lll_sz + (long)(y >> 1) * lll_sy, (unsigned)((nx + 1) >> 1) * 4);
 #pragma unroll
-					for (int g = 0; g < NV; g++) {
-						if (vec) {
-							*(u2 *)(p + 128 * g) = u2{to_bits(o0[4 * g]), to_bits(o0[4 * g + 2])};
-						} else {
-							if (c + 256 * g < nx)
-								p[128 * g] = o0[4 * g];
-							if (c + 256 * g + 2 < nx)
-								p[128 * g + 1] = o0[4 * g + 2];
-						}
-					}
+					for (int g = 0; g < NV; g++)
+						store8_row<false>(rl, cb / 2 + 512 * g, u2{to_bits(o0[4 * g]), to_bits(o0[4 * g + 2])});
 				}
 			}
 		} else {

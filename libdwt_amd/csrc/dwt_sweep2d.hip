@@ -125,8 +125,7 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 // 2. fused tile sweeps
 // ---------------------------------------------------------------------------------
 struct SweepGeom {
-	int tile_pairs, ntx, swz, in_vec_ok, out_vec_ok;
-	int ll_vec_ok = 0; // interleaved layout with a dense LL copy: that copy takes 8 B stores
+	int tile_pairs, ntx, swz;
 	int wave_horiz; // 1: the waves of a workgroup take horizontally adjacent tiles
 };
 
@@ -444,12 +443,8 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 
 	// pointers to the four subbands' row starts are formed per source row
 	// interleaved input: source columns of the element-wise loader and of the halo
-	int colmapI[IL ? CPT : 1];
 	int halo_colI = 0;
 	if constexpr (IL) {
-#pragma unroll
-		for (int i = 0; i < CPT; i++)
-			colmapI[i] = reflect(c0 + i * 64 + lane, a.W);
 		halo_colI = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
 	}
 	auto issue = [&](int it) {
@@ -800,12 +795,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
 	g.wave_horiz = 0;
-	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
-	g.in_vec_ok = aligned16(a.in) && (a.in_pitch % 4 == 0) && (a.in_bstride % 4 == 0);
-	const int ov = cpt / 2; // elements per vector store
-	g.out_vec_ok = ((uintptr_t)a.out_ll % (4 * ov) == 0) && ((uintptr_t)a.out_h % (4 * ov) == 0) &&
-		(a.ll_pitch % ov == 0) && (a.h_pitch % ov == 0) && (a.ll_bstride % ov == 0) && (a.h_bstride % ov == 0) &&
-		(Wd % ov == 0);
+	const int Hd = (a.H + 1) / 2;
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
 	// Ring depth (measured, scripts/sweep.py): when a launch has several rounds of tiles
@@ -827,8 +817,6 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 		// 3-D path: float 9/7 only; always 4 columns per lane so that each row leaves the
 		// wave as ONE contiguous 16 B/lane store (two strided stores per row cost 40 %)
 		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
-			g.out_vec_ok = aligned16(a.out_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0);
-			g.ll_vec_ok = a.il_ll && ((uintptr_t)a.out_ll % 8 == 0) && (a.ll_pitch % 2 == 0) && (a.ll_bstride % 2 == 0);
 			if (tt.ring == 16)
 				return fwd_launch<W, 4, 16, 3, true>(a, g, grid, waves, s);
 			return fwd_launch<W, 4, 8, 3, true>(a, g, grid, waves, s);
@@ -872,10 +860,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch, true);
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
-	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
-	g.in_vec_ok = aligned16(a.in_ll) && aligned16(a.in_h) && (a.ll_pitch % 4 == 0) && (a.h_pitch % 4 == 0) &&
-		(a.ll_bstride % 4 == 0) && (a.h_bstride % 4 == 0) && (Wd % 4 == 0);
-	g.out_vec_ok = aligned16(a.out) && (a.out_pitch % 4 == 0) && (a.out_bstride % 4 == 0);
+	const int Hd = (a.H + 1) / 2;
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
 	int ring = t.ring_inv == 16 ? 16 : 8;
@@ -887,8 +872,6 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
 		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
-			g.in_vec_ok = aligned16(a.in_h) && (a.h_pitch % 4 == 0) && (a.h_bstride % 4 == 0) &&
-				aligned16(a.in_ll) && (a.ll_pitch % 4 == 0) && (a.ll_bstride % 4 == 0);
 			return cpt == 8 ? inv_launch<W, 8, 8, 0, true>(a, g, grid, waves, s) : inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
 		} else {
 			return hipErrorInvalidValue;

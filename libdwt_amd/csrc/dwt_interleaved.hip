@@ -481,8 +481,7 @@ __global__ __launch_bounds__(256) void k_compare(const char *__restrict__ p1, co
 // level 0: HL, LH|HH and, when level 0 is the last level, LL).  The runtime's own 2-D copy
 // (__amd_rocclr_copyBufferRectAligned) moves such rectangles at ~3.3 TB/s; this streams 16 B per
 // lane, non-temporal both ways (the bytes are not read again by a kernel), 4 KiB x 8 rows per
-// workgroup.  Falls back to 4 B per lane when a rectangle is not 16-byte aligned.
-template <int VEC>
+// workgroup, any 4-byte alignment.
 __global__ __launch_bounds__(256) void k_copy_rects(CopyRects r)
 {
 	int b = blockIdx.x, k = 0;
@@ -490,66 +489,50 @@ __global__ __launch_bounds__(256) void k_copy_rects(CopyRects r)
 		k++;
 	b -= r.first_block[k];
 	constexpr int kRows = 8;
-	const int seg = 256 * VEC; // bytes per workgroup row segment
+	constexpr int seg = 256 * 16; // bytes per workgroup row segment
 	const int nbx = (r.wbytes[k] + seg - 1) / seg;
 	const int bx = b % nbx, by = b / nbx;
-	const long x = (long)bx * seg + (long)threadIdx.x * VEC;
-	if (x >= r.wbytes[k])
-		return;
-	const char *s = r.src[k] + (long)by * kRows * r.spitch[k] + x;
-	char *d = r.dst[k] + (long)by * kRows * r.dpitch[k] + x;
+	const unsigned x = (unsigned)bx * seg + threadIdx.x * 16;
+	const char *s = r.src[k] + (long)by * kRows * r.spitch[k];
+	char *d = r.dst[k] + (long)by * kRows * r.dpitch[k];
 	const int rows = min(kRows, r.h[k] - by * kRows);
-	// rows past the end load the last row again (never stored): straight-line loads, all eight in
-	// flight (with the loads under `if (i < rows)` the compiler built a 236-register kernel)
-	if constexpr (VEC == 16) {
-		u4 v[kRows];
+	// rows as buffers: 16 B per lane whatever the alignment, the dwords past a row's end are
+	// zero-filled / dropped by the bounds check.  Rows past the rectangle's end load the last row
+	// again (never stored): straight-line loads, all eight in flight (with the loads under
+	// `if (i < rows)` the compiler built a 236-register kernel).
+	u4 v[kRows];
 #pragma unroll
-		for (int i = 0; i < kRows; i++)
-			v[i] = __builtin_nontemporal_load((const u4 *)(s + (long)min(i, rows - 1) * r.spitch[k]));
+	for (int i = 0; i < kRows; i++)
+		v[i] = load16_row<true>(row_rsrc(s + (long)min(i, rows - 1) * r.spitch[k], (unsigned)r.wbytes[k]), x);
 #pragma unroll
-		for (int i = 0; i < kRows; i++)
-			if (i < rows)
-				__builtin_nontemporal_store(v[i], (u4 *)(d + (long)i * r.dpitch[k]));
-	} else {
-		unsigned v[kRows];
-#pragma unroll
-		for (int i = 0; i < kRows; i++)
-			v[i] = *(const unsigned *)(s + (long)min(i, rows - 1) * r.spitch[k]);
-#pragma unroll
-		for (int i = 0; i < kRows; i++)
-			if (i < rows)
-				*(unsigned *)(d + (long)i * r.dpitch[k]) = v[i];
-	}
+	for (int i = 0; i < kRows; i++)
+		if (i < rows)
+			store16_row<true>(row_rsrc(d + (long)i * r.dpitch[k], (unsigned)r.wbytes[k]), x, v[i]);
 }
 
 hipError_t launch_copy_rects(CopyRects r, hipStream_t s)
 {
-	bool vec = true;
 	int n = 0;
 	for (int k = 0; k < r.n; k++) {
 		if (r.wbytes[k] <= 0 || r.h[k] <= 0)
 			continue;
 		r.src[n] = r.src[k]; r.dst[n] = r.dst[k]; r.spitch[n] = r.spitch[k]; r.dpitch[n] = r.dpitch[k];
 		r.wbytes[n] = r.wbytes[k]; r.h[n] = r.h[k];
-		vec = vec && aligned16(r.src[n]) && aligned16(r.dst[n]) && (r.spitch[n] % 16 == 0) && (r.dpitch[n] % 16 == 0) && (r.wbytes[n] % 16 == 0);
-		if (r.wbytes[n] % 4)
+		if (r.wbytes[n] % 4 || ((uintptr_t)r.src[n] | (uintptr_t)r.dst[n] | (uintptr_t)r.spitch[n] | (uintptr_t)r.dpitch[n]) % 4)
 			return hipErrorInvalidValue;
 		n++;
 	}
 	r.n = n;
 	if (n == 0)
 		return hipSuccess;
-	const int seg = 256 * (vec ? 16 : 4);
+	const int seg = 256 * 16;
 	int total = 0;
 	for (int k = 0; k < n; k++) {
 		r.first_block[k] = total;
 		total += ((r.wbytes[k] + seg - 1) / seg) * ((r.h[k] + 7) / 8);
 	}
 	r.first_block[n] = total;
-	if (vec)
-		k_copy_rects<16><<<total, 256, 0, s>>>(r);
-	else
-		k_copy_rects<4><<<total, 256, 0, s>>>(r);
+	k_copy_rects<<<total, 256, 0, s>>>(r);
 	return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ void dwt_hip_sync(void);
  * "wave_horiz" (0/1), "ring" (8/16), "nt" and "nt_inv" (bit 0 nt stores, bit 1 nt loads),
  * "tile_pairs" (0 = auto), "waves" (1..4), "xcd_swizzle" (0/1), "fma", "fused_d".
  * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two
- * passes), "vol_whole" (1 = whole-tile kernel variant where the x size is a multiple of 256),
+ * passes), "vol_whole" (1 = the buffer-addressed kernel variant, 0 = the general one as a cross-check),
  * "vol_direct" (levels >= 1 into their lattice of the destination: 2 = rows shared by levels 0
  * and 1 written once, 1 = sample-wise stores, 0 = dense results + scatter passes), "vol_nt"
  * (-1 = default: cacheable loads, non-temporal stores; bit 0 nt stores, bit 1 nt loads, bit 2
@@ -114,8 +114,8 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 
 /* The same forward transform OUT OF PLACE (src != dst, both device pointers, same strides):
  * cdf97_3f_op_sep_horizontal_s (src/volume-dwt.c:727-785), the entry the reference's 3-D
- * perf test drives.  Each level is one fused x+y+z pass where the fused kernel applies
- * (x size a multiple of 256), two passes otherwise. */
+ * perf test drives.  Each level is one fused x+y+z pass where that pays (volumes of about
+ * 448^3 and more, at least 128 samples wide; any size and 4-byte alignment), two passes otherwise. */
 int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z,
 	int size_x, int size_y, int size_z, int levels);
 

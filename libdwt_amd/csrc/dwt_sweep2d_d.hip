@@ -37,7 +37,7 @@ static __device__ __forceinline__ void lds_read6(unsigned a0, unsigned a1, unsig
 }
 
 struct SweepGeomD {
-	int tile_pairs, ntx, swz, in_vec_ok, out_vec_ok, wave_horiz;
+	int tile_pairs, ntx, swz, wave_horiz;
 };
 
 } // namespace
@@ -80,14 +80,11 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 
 	char *ring = smem + (size_t)wv * RING * RSB;
 	const unsigned ring_off = lds_offset(ring);
-	const bool full = (c0 + TW <= a.W);
-	const bool main16 = full && g.in_vec_ok;
-	// element-wise loader (partial / unaligned tiles): a 4 B DMA instruction moves one word of each
-	// of 32 doubles -- lane l brings word l&1 of column c0 + 32 i + (l >> 1)
-	int colmap[8];
-#pragma unroll
-	for (int i = 0; i < 8; i++)
-		colmap[i] = reflect(c0 + i * 32 + (lane >> 1), a.W);
+	// rows as buffers (see k_fwd_sweep): 16-byte DMAs and stores for every tile, the dwords beyond a
+	// row's end zero-filled / dropped by the hardware; the up to four reflected columns right of
+	// the image's edge come as 4-byte DMAs (lane l: word l & 1 of column W + (l >> 1))
+	const int n_edge = 2 * min(4, c0 + TW - a.W); // lanes of that DMA (<= 0: none)
+	const int edge_col = reflect(a.W + min(lane >> 1, 3), a.W);
 	// halo: lanes 0..7 the four columns left of the tile, 8..15 the four to its right (two words each)
 	const int halo_col = reflect(lane < 8 ? c0 - 4 + (lane >> 1) : c0 + TW + ((lane >> 1) & 3), a.W);
 	const int word = lane & 1;
@@ -101,14 +98,13 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 			const int r = tall ? reflect1(ri, a.H) : reflect(ri, a.H);
 			char *lrow = ring + (size_t)(islot + rr) * RSB;
 			const T *grow = in + (long)r * a.in_pitch;
-			if (main16) {
-				dma16<2>(grow + c0 + lane * 2, lrow);
-				dma16<2>(grow + c0 + 128 + lane * 2, lrow + 1024);
-			} else {
-#pragma unroll
-				for (int i = 0; i < 8; i++)
-					dma4<2>((const char *)(grow + colmap[i]) + 4 * word, lrow + i * 256);
+			{
+				const row_rsrc_t rs = row_rsrc(grow, (unsigned)a.W * 8);
+				dma16_row<2>(rs, (unsigned)c0 * 8 + lane * 16, lrow);
+				dma16_row<2>(rs, (unsigned)(c0 + 128) * 8 + lane * 16, lrow + 1024);
 			}
+			if (lane < n_edge)
+				dma4<2>((const char *)(grow + edge_col) + 4 * word, lrow + (a.W - c0) * 8);
 			if (lane < 16)
 				dma4<2>((const char *)(grow + halo_col) + 4 * word, lrow + TW * 8);
 		}
@@ -188,35 +184,15 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 		}
 		if (it >= K) {
 			const int k = A + it - K;
-			const int cl = (c0 + lane * CPT) >> 1;
-			T *ll = out_ll + (long)k * a.ll_pitch + cl;
-			T *hl = out_h + (long)k * a.h_pitch + Wd + cl;
-			T *lh = out_h + (long)(Hd + k) * a.h_pitch + cl;
-			T *hh = lh + Wd;
-			const bool hrow = k < (a.H >> 1);
-			if (full && g.out_vec_ok) {
-				*(u4 *)ll = pack2(lo[0], lo[2]); // the next level reads it: temporal
-				__builtin_nontemporal_store(pack2(lo[1], lo[3]), (u4 *)hl);
-				if (hrow) {
-					__builtin_nontemporal_store(pack2(hi[0], hi[2]), (u4 *)lh);
-					__builtin_nontemporal_store(pack2(hi[1], hi[3]), (u4 *)hh);
-				}
-			} else {
-				const int nl = Wd, nh = a.W >> 1;
-#pragma unroll
-				for (int v = 0; v < CPT; v += 2) {
-					const int ci = cl + (v >> 1);
-					if (ci < nl) {
-						ll[v >> 1] = lo[v];
-						if (hrow)
-							lh[v >> 1] = hi[v];
-					}
-					if (ci < nh) {
-						hl[v >> 1] = lo[v + 1];
-						if (hrow)
-							hh[v >> 1] = hi[v + 1];
-					}
-				}
+			// each quarter row of the Mallat layout is a buffer of its own
+			const unsigned clb = (unsigned)((c0 + lane * CPT) >> 1) * 8;
+			const T *top = out_h + (long)k * a.h_pitch, *bot = out_h + (long)(Hd + k) * a.h_pitch;
+			const unsigned nlb = (unsigned)Wd * 8, nhb = (unsigned)(a.W >> 1) * 8;
+			store16_row<false>(row_rsrc(out_ll + (long)k * a.ll_pitch, nlb), clb, pack2(lo[0], lo[2])); // the next level reads it: temporal
+			store16_row<true>(row_rsrc(top + Wd, nhb), clb, pack2(lo[1], lo[3]));
+			if (k < (a.H >> 1)) {
+				store16_row<true>(row_rsrc(bot, nlb), clb, pack2(hi[0], hi[2]));
+				store16_row<true>(row_rsrc(bot + Wd, nhb), clb, pack2(hi[1], hi[3]));
 			}
 		}
 	}
@@ -239,7 +215,7 @@ static hipError_t fwd_level_d_t(const FwdLevelArgs &a, const SweepTuning &t, hip
 		return hipErrorInvalidValue;
 	constexpr int TW = 256;
 	SweepGeomD g;
-	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
+	const int Hd = (a.H + 1) / 2;
 	g.ntx = (a.W + TW - 1) / TW;
 	// tile heights as the float sweep picks them for the same number of BYTES per row
 	int tp = t.tile_pairs > 0 ? t.tile_pairs : 64;
@@ -252,9 +228,6 @@ static hipError_t fwd_level_d_t(const FwdLevelArgs &a, const SweepTuning &t, hip
 	}
 	g.tile_pairs = tp;
 	g.swz = t.xcd_swizzle;
-	g.in_vec_ok = aligned16(a.in) && (a.in_pitch % 2 == 0) && (a.in_bstride % 2 == 0);
-	g.out_vec_ok = aligned16(a.out_ll) && aligned16(a.out_h) && (a.ll_pitch % 2 == 0) && (a.h_pitch % 2 == 0) &&
-		(a.ll_bstride % 2 == 0) && (a.h_bstride % 2 == 0) && (Wd % 2 == 0);
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + tp - 1) / tp;
 	const int ring = (t.ring == 8 || t.ring == 16) ? t.ring : ((g.ntx >= waves && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8);
@@ -319,18 +292,15 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 
 	char *ring = smem + (size_t)wv * RING * RSB;
 	const unsigned ring_off = lds_offset(ring);
-	const bool full = (c0 + TW <= a.W);
-	const bool main16 = full && g.in_vec_ok;
 	const int word = lane & 1;
-	// element-wise loader: a 4 B DMA brings one word of each of 32 doubles; subband column e of a
-	// segment is reflected through the interleaved index, so that parity is preserved
-	int colmapL[2], colmapH[2];
-#pragma unroll
-	for (int i = 0; i < 2; i++) {
-		const int e = cl0 + i * 32 + (lane >> 1);
-		colmapL[i] = reflect(2 * e, a.W) >> 1;
-		colmapH[i] = reflect(2 * e + 1, a.W) >> 1;
-	}
+	// Whole tiles fetch their two subband segments as one plain 16-byte DMA; the tile that holds the
+	// image's right edge addresses them as buffers (see k_inv_sweep) and fetches the two L and two
+	// H columns right of the edge by reflection: lanes 0..3 the words of L columns nL, nL + 1,
+	// lanes 4..7 those of H columns nH, nH + 1.
+	const bool edge_tile = c0 + TW > a.W;
+	const int nL = Wd, nH = a.W >> 1;
+	const int edge_sub = (lane & 4) ? nH + ((lane >> 1) & 1) : nL + ((lane >> 1) & 1);
+	const int edge_col = reflect(2 * edge_sub + ((lane >> 2) & 1), a.W) >> 1;
 	// halo: lanes 0..15 the L halo block (8 doubles), 16..31 the H halo block
 	const int hd = (lane >> 1) & 7, hs = (lane >> 4) & 1;
 	const int hsub = hd < 4 ? cl0 - 4 + hd : cl0 + M + (hd - 4);
@@ -351,17 +321,19 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 				gh = gl + Wd;
 			}
 			char *lrow = ring + (size_t)((2 * it + rr) & (RING - 1)) * RSB;
-			if (main16) {
+			if (!edge_tile) {
 				// lanes 0..31 fetch the L segment, 32..63 the H segment (16 B = 2 doubles each)
 				const T *gsel = lane < 32 ? gl : gh;
 				dma16<0>(gsel + cl0 + (lane & 31) * 2, lrow);
 			} else {
-#pragma unroll
-				for (int i = 0; i < 2; i++)
-					dma4<0>((const char *)(gl + colmapL[i]) + 4 * word, lrow + i * 256);
-#pragma unroll
-				for (int i = 0; i < 2; i++)
-					dma4<0>((const char *)(gh + colmapH[i]) + 4 * word, lrow + M * 8 + i * 256);
+				if (lane < 32)
+					dma16_row<0>(row_rsrc(gl, (unsigned)nL * 8), (unsigned)cl0 * 8 + lane * 16, lrow);
+				else
+					dma16_row<0>(row_rsrc(gh, (unsigned)nH * 8), (unsigned)cl0 * 8 + (lane & 31) * 16, lrow); // lane's slot lrow + 16 lane = the H half
+				if (lane < 4 && nL + (lane >> 1) < cl0 + M)
+					dma4<0>((const char *)(gl + edge_col) + 4 * word, lrow + (nL - cl0) * 8);
+				if (lane >= 4 && lane < 8 && nH + ((lane >> 1) & 1) < cl0 + M)
+					dma4<0>((const char *)(gh + edge_col) + 4 * word, lrow + M * 8 + (nH - cl0) * 8 - 16);
 			}
 			if (lane < 32)
 				dma4<0>((const char *)((hs ? gh : gl) + halo_col) + 4 * word, lrow + 2 * M * 8);
@@ -461,22 +433,11 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 		const int po = (K == 4) ? p - 2 : p - 1;
 		const bool ve = pe >= A && pe < B;
 		const bool vo = po >= A && po < B && (2 * po + 1 < a.H);
-		const int c = c0 + lane * CPT;
-		if (full && g.out_vec_ok) {
-			if (vo)
-				__builtin_nontemporal_store(pack2(odd_row[0], odd_row[1]), (u4 *)(out + (long)(2 * po + 1) * a.out_pitch + c));
-			if (ve)
-				__builtin_nontemporal_store(pack2(even_row[0], even_row[1]), (u4 *)(out + (long)(2 * pe) * a.out_pitch + c));
-		} else {
-#pragma unroll
-			for (int e = 0; e < CPT; e++)
-				if (c + e < a.W) {
-					if (vo)
-						out[(long)(2 * po + 1) * a.out_pitch + c + e] = odd_row[e];
-					if (ve)
-						out[(long)(2 * pe) * a.out_pitch + c + e] = even_row[e];
-				}
-		}
+		const unsigned cb = (unsigned)(c0 + lane * CPT) * 8;
+		if (vo)
+			store16_row<true>(row_rsrc(out + (long)(2 * po + 1) * a.out_pitch, (unsigned)a.W * 8), cb, pack2(odd_row[0], odd_row[1]));
+		if (ve)
+			store16_row<true>(row_rsrc(out + (long)(2 * pe) * a.out_pitch, (unsigned)a.W * 8), cb, pack2(even_row[0], even_row[1]));
 	}
 }
 
@@ -497,7 +458,7 @@ static hipError_t inv_level_d_t(const InvLevelArgs &a, const SweepTuning &t, hip
 		return hipErrorInvalidValue;
 	constexpr int TW = 128;
 	SweepGeomD g;
-	const int Wd = (a.W + 1) / 2, Hd = (a.H + 1) / 2;
+	const int Hd = (a.H + 1) / 2;
 	g.ntx = (a.W + TW - 1) / TW;
 	int tp = t.tile_pairs > 0 ? t.tile_pairs : 32;
 	if (t.tile_pairs <= 0) {
@@ -509,9 +470,6 @@ static hipError_t inv_level_d_t(const InvLevelArgs &a, const SweepTuning &t, hip
 	}
 	g.tile_pairs = tp;
 	g.swz = t.xcd_swizzle;
-	g.in_vec_ok = aligned16(a.in_ll) && aligned16(a.in_h) && (a.ll_pitch % 2 == 0) && (a.h_pitch % 2 == 0) &&
-		(a.ll_bstride % 2 == 0) && (a.h_bstride % 2 == 0) && (Wd % 2 == 0);
-	g.out_vec_ok = aligned16(a.out) && (a.out_pitch % 2 == 0) && (a.out_bstride % 2 == 0);
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + tp - 1) / tp;
 	g.wave_horiz = t.wave_horiz_inv > 0;

@@ -603,46 +603,44 @@ print("graph OK")
 
 @pytest.mark.parametrize("w,h,pitch_elems", [(999, 777, 1003), (1000, 500, 1001), (4100, 300, 4101), (515, 64, 517), (8188, 40, 8189)],
                          ids=lambda v: str(v))
-@pytest.mark.parametrize("wavelet", ["cdf97_s", "cdf53_i"])
-def test_device_images_with_unaligned_pitch(dwt, oracle, wavelet, w, h, pitch_elems):
-    """Device images whose rows are only 4-byte aligned (row pitch no multiple of 16 bytes) and odd
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i", "cdf97_d"])
+def test_device_images_with_unaligned_pitch(dwt, oracle, wname, w, h, pitch_elems):
+    """Device images whose rows are only element-aligned (row pitch no multiple of 16 bytes) and odd
     widths: the sweeps address rows as buffers with a per-dword bounds check, so these take the same
     16-byte path as aligned images; bit-exact, the padding between rows untouched."""
-    isint = wavelet.endswith("_i")
-    dt = np.int32 if isint else np.float32
+    ff, fi, dt = NAMES[wname]
+    es = np.dtype(dt).itemsize
+    ut = np.uint32 if es == 4 else np.uint64
+    fill = ut(0x7B7B7B7B7B7B7B7B & ((1 << (8 * es)) - 1))
     rng = np.random.default_rng(w * 7 + h)
-    img = rng.integers(-32768, 32767, (h, w)).astype(np.int32) if isint else rng.random((h, w), dtype=np.float32)
+    img = rng.integers(-32768, 32767, (h, w)).astype(np.int32) if dt == np.int32 else rng.random((h, w)).astype(dt)
     J = 4
     want = img.copy()
-    fwd_name = "cdf53_2f_i" if isint else "cdf97_2f_s"
-    inv_name = "cdf53_2i_i" if isint else "cdf97_2i_s"
-    oracle.fwd(fwd_name, want, J)
-    pad = np.full((h, pitch_elems), 0x7B7B7B7B, np.uint32)
-    pad[:, :w] = img.view(np.uint32)
-    src = dwt.DeviceImage(h, w, 4, pitch_elems * 4).upload(pad)
-    dst = dwt.DeviceImage(h, w, 4, pitch_elems * 4).upload(np.full((h, pitch_elems), 0x7B7B7B7B, np.uint32))
-    f2 = dwt.dwt_cdf53_2f_i if isint else dwt.dwt_cdf97_2f_s
-    i2 = dwt.dwt_cdf53_2i_i if isint else dwt.dwt_cdf97_2i_s
-    # in place
-    f2(src.ptr, pitch_elems * 4, 4, w, h, w, h, J)
-    got = src.download(np.uint32)
-    assert np.array_equal(got[:, :w], want.view(np.uint32))
-    assert np.all(got[:, w:] == 0x7B7B7B7B), "row padding written"
-    i2(src.ptr, pitch_elems * 4, 4, w, h, w, h, J)
-    back = src.download(np.uint32)
+    oracle.fwd(ff, want, J)
     rec = want.copy()
-    oracle.inv(inv_name, rec, J)
-    assert np.array_equal(back[:, :w], rec.view(np.uint32))
-    assert np.all(back[:, w:] == 0x7B7B7B7B)
-    # out of place (float entries only have the _s2 form)
-    if not isint:
+    oracle.inv(fi, rec, J)
+    pad = np.full((h, pitch_elems), fill, ut)
+    pad[:, :w] = img.view(ut)
+    src = dwt.DeviceImage(h, w, es, pitch_elems * es).upload(pad)
+    # in place
+    dwt.FORWARD[wname](src.ptr, pitch_elems * es, es, w, h, w, h, J)
+    got = src.download(ut)
+    assert np.array_equal(got[:, :w], want.view(ut))
+    assert np.all(got[:, w:] == fill), "row padding written"
+    dwt.INVERSE[wname](src.ptr, pitch_elems * es, es, w, h, w, h, J)
+    back = src.download(ut)
+    assert np.array_equal(back[:, :w], rec.view(ut))
+    assert np.all(back[:, w:] == fill)
+    # out of place (the float 9/7 entries have the _s2 form)
+    if wname == "cdf97_s":
+        dst = dwt.DeviceImage(h, w, es, pitch_elems * es).upload(np.full((h, pitch_elems), fill, ut))
         src.upload(pad)
-        dwt.dwt_cdf97_2f_s2(src.ptr, dst.ptr, pitch_elems * 4, 4, w, h, w, h, J)
-        got = dst.download(np.uint32)
-        assert np.array_equal(got[:, :w], want.view(np.uint32))
-        assert np.all(got[:, w:] == 0x7B7B7B7B)
+        dwt.dwt_cdf97_2f_s2(src.ptr, dst.ptr, pitch_elems * es, es, w, h, w, h, J)
+        got = dst.download(ut)
+        assert np.array_equal(got[:, :w], want.view(ut))
+        assert np.all(got[:, w:] == fill)
+        dst.free()
     src.free()
-    dst.free()
 
 
 def test_hip_graph_capture_replay():

@@ -9,7 +9,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <utility>
 #include <vector>
 

@@ -7,6 +7,7 @@
 set -u
 TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="bench.py --steps 5 --warmup 2 --no-cpu --no-single ${BENCH_ARGS:-}"

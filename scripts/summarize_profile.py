@@ -6,18 +6,24 @@ profiles/<tag>_pmc_level0.json (per-launch counters of the dominant kernel with 
 gfx950 FETCH_SIZE correction applied) and a short profiles/<tag>_summary.md."""
 import csv, glob, json, os, sys, collections
 
+def newest(pattern):
+    """the most recent match (a profile directory may hold the files of earlier runs)"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 src, tag = sys.argv[1], sys.argv[2]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(out, exist_ok=True)
 
-stats = list(csv.DictReader(open(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0])))
+stats = list(csv.DictReader(open(newest(f"{src}/trace/*/*_kernel_stats.csv")[0])))
 keep = [r for r in stats if "dwt::" in r["Name"]]
 with open(f"{out}/{tag}_kernel_stats.csv", "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
     w.writeheader()
     w.writerows(keep)
 
-trace = list(csv.DictReader(open(glob.glob(f"{src}/trace/*/*_kernel_trace.csv")[0])))
+trace = list(csv.DictReader(open(newest(f"{src}/trace/*/*_kernel_trace.csv")[0])))
 sweeps = [r for r in trace if "k_fwd_sweep" in r["Kernel_Name"]]
 gmax = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in sweeps)
 l0 = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sweeps if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == gmax]
@@ -29,7 +35,7 @@ for r in sweeps:
 
 pmc = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+    fs = newest(f"{src}/{d}/*/*_counter_collection.csv")
     if not fs:
         continue
     rows = [r for r in csv.DictReader(open(fs[0])) if "k_fwd_sweep" in r["Kernel_Name"]]

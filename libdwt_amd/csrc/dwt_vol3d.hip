@@ -14,7 +14,7 @@ namespace dwt {
 // the far end re-reads slices the sweep has already produced.
 template <bool INV, int CPT, int NT>
 __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, long in_sy, long in_sz,
-	float *__restrict__ out, long out_sy, long out_sz, int nx, int ny, int nz, int tile_pairs, int vec_ok,
+	float *__restrict__ out, long out_sy, long out_sz, int nx, int ny, int nz, int tile_pairs,
 	float *__restrict__ lll, long lll_sy, long lll_sz)
 {
 	using W = Cdf97S;
@@ -135,13 +135,13 @@ __global__ __launch_bounds__(256) void k_vol_z(const float *__restrict__ in, lon
 
 template <bool INV, int CPT>
 static void vol_z_nt(int nt, dim3 grid, int threads, hipStream_t s, const float *in, long in_sy, long in_sz, float *out,
-	long out_sy, long out_sz, int nx, int ny, int nz, int tp, int vec_ok, float *lll, long lll_sy, long lll_sz)
+	long out_sy, long out_sz, int nx, int ny, int nz, int tp, float *lll, long lll_sy, long lll_sz)
 {
 	switch ((nt < 0 ? 0 : nt) & 3) {
-	case 0: k_vol_z<INV, CPT, 0><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
-	case 1: k_vol_z<INV, CPT, 1><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
-	case 2: k_vol_z<INV, CPT, 2><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
-	default: k_vol_z<INV, CPT, 3><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz); break;
+	case 0: k_vol_z<INV, CPT, 0><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz); break;
+	case 1: k_vol_z<INV, CPT, 1><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz); break;
+	case 2: k_vol_z<INV, CPT, 2><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz); break;
+	default: k_vol_z<INV, CPT, 3><<<grid, threads, 0, s>>>(in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz); break;
 	}
 }
 
@@ -164,17 +164,16 @@ hipError_t launch_vol_z(bool inverse, const float *in, long in_sy, long in_sz, f
 		return hipErrorInvalidValue;
 	const int waves = ntx >= 4 ? 4 : ntx;
 	dim3 grid((ntx + waves - 1) / waves, ny, nzt);
-	const int vec_ok = aligned16(in) && aligned16(out) && in_sy % 4 == 0 && in_sz % 4 == 0 && out_sy % 4 == 0 && out_sz % 4 == 0;
 	if (inverse) {
 		if (cpt == 8)
-			vol_z_nt<true, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+			vol_z_nt<true, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz);
 		else
-			vol_z_nt<true, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+			vol_z_nt<true, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz);
 	} else {
 		if (cpt == 8)
-			vol_z_nt<false, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+			vol_z_nt<false, 8>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz);
 		else
-			vol_z_nt<false, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, vec_ok, lll, lll_sy, lll_sz);
+			vol_z_nt<false, 4>(vt.nt, grid, 64 * waves, s, in, in_sy, in_sz, out, out_sy, out_sz, nx, ny, nz, tp, lll, lll_sy, lll_sz);
 	}
 	return hipGetLastError();
 }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 	char *parked = slab + (size_t)NR * TW * 4 + (size_t)wv * 2 * RW * TW * 4;
 	const unsigned parked_off = lds_offset(parked);
 	// tiles that overhang the volume (or unaligned volumes) are staged column by column
-	const bool full = MODE >= 2 || (vec_ok && c0 + TW <= a.nx);
+	const bool full = MODE >= 1 || (vec_ok && c0 + TW <= a.nx);
 	// interior tiles fetch each 4-column halo as ONE aligned 16 B piece (two lanes) instead of four
 	// 4 B ones; tiles at the volume's x borders reflect column by column
 	const bool halo16 = full && c0 >= 4 && c0 + TW + 4 <= a.nx;
@@ -261,13 +261,13 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 				char *lrow = ring + (size_t)i * RS * 4;
 				if (full) {
 					// the DMA places lane i's 16 B at lrow + 16 i; in a tile that overhangs the volume
-					// (MODE >= 2) the dwords beyond the row's end are zero-filled by the bounds check and the four
+					// (MODE >= 1) the dwords beyond the row's end are zero-filled by the bounds check and the four
 					// reflected columns next to the edge -- all a valid output can reach -- come one by one
-					if constexpr (MODE >= 2)
+					if constexpr (MODE >= 1)
 						dma16_row<kLdAux>(row_rsrc(grow, (unsigned)a.nx * 4), (unsigned)c * 4, lrow);
 					else
 						dma16<kLdAux>(grow + c, lrow);
-					if (MODE >= 2 && lane < min(4, c0 + TW - a.nx))
+					if (MODE >= 1 && lane < min(4, c0 + TW - a.nx))
 						dma4<kLdAux>(grow + reflect(a.nx + lane, a.nx), lrow + (a.nx - c0) * 4);
 				} else {
 #pragma unroll
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 				float *p = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy + (MODE == 1 ? c * a.out_sx : MODE == 3 ? 2L * c : (long)c);
 				const bool hz = 2 * k + 1 < a.nz;
 				float *pl = a.lll && !(r & 1) ? a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy + (c >> 1) : nullptr;
-				// MODE >= 2: rows as buffers -- the lanes beyond the edge of a tile that overhangs the
+				// MODE >= 1: rows as buffers -- the lanes beyond the edge of a tile that overhangs the
 				// volume are dropped by the hardware's bounds check, no per-lane branches
 				[[maybe_unused]] const float *row0 = a.out + (long)(2 * k) * a.out_sz + (long)y * a.out_sy;
 				[[maybe_unused]] const bool to_lll = a.lll && !(r & 1);
@@ -454,18 +454,19 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 					if (to_lll)
 						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)((a.nx + 1) >> 1) * 4), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 				} else if constexpr (MODE == 1) {
-					// a level >= 1 writing into its lattice of the destination volume
+					// a level >= 1 writing into its lattice of the destination volume: sample x of this
+					// level sits at x * out_sx of the destination row; one dword store per sample, the
+					// row's last lattice sample bounds the buffer
+					const unsigned nb = ((unsigned)(a.nx - 1) * (unsigned)a.out_sx + 1) * 4, sx4 = (unsigned)a.out_sx * 4;
+					const row_rsrc_t d0 = row_rsrc(row0, nb), d1 = row_rsrc(row0 + a.out_sz, nb);
 #pragma unroll
-					for (int e = 0; e < CPT; e++)
-						if (full || c + e < a.nx) {
-							p[e * a.out_sx] = o0[e];
-							if (hz)
-								p[a.out_sz + e * a.out_sx] = o1[e];
-							if (!full && pl && !(e & 1))
-								pl[e >> 1] = o0[e];
-						}
-					if (full && pl)
-						*(u2 *)pl = u2{to_bits(o0[0]), to_bits(o0[2])};
+					for (int e = 0; e < CPT; e++) {
+						__builtin_amdgcn_raw_buffer_store_b32(to_bits(o0[e]), d0, (unsigned)c * sx4, e * sx4, 0);
+						if (hz)
+							__builtin_amdgcn_raw_buffer_store_b32(to_bits(o1[e]), d1, (unsigned)c * sx4, e * sx4, 0);
+					}
+					if (to_lll)
+						store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)((a.nx + 1) >> 1) * 4), (unsigned)c * 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 				} else if (MODE == 4 || full) {
 					if constexpr (MODE == 4) {
 						store16_row<kNtStore>(row_rsrc(row0, (unsigned)a.nx * 4), (unsigned)c * 4, u4{to_bits(o0[0]), to_bits(o0[1]), to_bits(o0[2]), to_bits(o0[3])});

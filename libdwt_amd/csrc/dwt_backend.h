@@ -62,6 +62,7 @@ struct Ctx {
 	VolTuning vol;
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
+	int inplace_overlap = 0; // 1: the copy-back (forward) / copy-aside (inverse) of an in-place call on a side stream beside the deeper levels (measured 8-10 us slower than in line)
 	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
 	// profiling
 	int prof_on = 0;

@@ -534,10 +534,10 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				// copy the staged subbands to their place: right half, bottom-left, and the LL
 				// quadrant too when it was written here.  On the side stream: the deeper levels
 				// only touch the top-left quadrant and run meanwhile.
-				if (side_fork())
+				if (g.inplace_overlap && side_fork())
 					return 1;
 				const Rect rc[3] = {{Wd, 0, Wd, 0, Wo - Wd, Ho}, {0, Hd, 0, Hd, Wd, Ho - Hd}, {0, 0, 0, 0, last ? Wd : 0, Hd}};
-				if (copy_rects_on(g.side, dst, hdst, rc, 3))
+				if (copy_rects_on(g.inplace_overlap ? g.side : g.stream, dst, hdst, rc, 3))
 					return 1;
 			}
 			ll_in = ll_out;
@@ -626,7 +626,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 		bool all_fused = true;
 		for (int j = 1; j <= J; j++)
 			all_fused = all_fused && fused_ok(j);
-		if (all_fused) {
+		if (all_fused && g.inplace_overlap) {
 			const int Ws = ge.Wo(1), Hs = ge.Ho(1), Wo = ge.Wo(0), Ho = ge.Ho(0);
 			if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 				return 1;
@@ -902,6 +902,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fma = value;
 	else if (!strcmp(name, "fused_d"))
 		g.fused_d = value;
+	else if (!strcmp(name, "inplace_overlap"))
+		g.inplace_overlap = value;
 	else if (!strcmp(name, "vol_cpt"))
 		g.vol.cpt = value;
 	else if (!strcmp(name, "vol_tile_pairs"))
@@ -961,6 +963,8 @@ int dwt_hip_get_option(const char *name)
 		return g.fma;
 	if (!strcmp(name, "fused_d"))
 		return g.fused_d;
+	if (!strcmp(name, "inplace_overlap"))
+		return g.inplace_overlap;
 	if (!strcmp(name, "vol_cpt"))
 		return g.vol.cpt;
 	if (!strcmp(name, "vol_tile_pairs"))

@@ -368,6 +368,39 @@ def test_config4_batch(dwt, oracle):
     dwt.lib.dwt_hip_free(dst)
 
 
+def test_host_channel_calls_from_several_threads(dwt, oracle):
+    """Host-pointer calls on channels of interleaved images from three threads at once: the strided
+    repacking runs on the library's row pool, whose jobs take turns; every result is the oracle's."""
+    import threading
+
+    errors = []
+
+    def work(i):
+        try:
+            dwt.set_device(0)
+            rng = np.random.default_rng(500 + i)
+            h, w, c = 700 + 64 * i, 900, 3
+            for rep in range(3):
+                img = rng.random((h, w, c), dtype=np.float32)
+                want = img.copy()
+                ch = (i + rep) % c
+                j = oracle.call_channel("cdf97_2f_s", want, ch, 3)
+                got = img.copy()
+                assert dwt.dwt_cdf97_2f_s(got.ctypes.data + 4 * ch, got.strides[0], got.strides[1], w, h, w, h, 3) == j
+                if not np.array_equal(bits(got), bits(want)):
+                    errors.append((i, rep))
+            dwt.dwt_util_finish()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def test_double_precision_batch(dwt, oracle):
     """The batched entry takes the double-precision wavelets too (fused double sweeps)."""
     n, nb = 768, 3

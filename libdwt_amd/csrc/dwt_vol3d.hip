@@ -534,12 +534,33 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	const int rw = vt.rows == 6 ? 6 : 8;
 	const int Zd = (a.nz + 1) / 2;
 	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 4 * rw - 1) / (4 * rw);
-	// z lines are split until the workgroup slots (two per CU) are filled, but not below 32
-	// slice pairs per march: the 8-slice warm-up is 12 % there (512^3: 32 pairs 0.31 ms, 16
-	// pairs 0.37, 64 pairs -- half the CUs idle -- 0.55)
+	int mode = a.mode;
+	if (mode < 0 || mode > 3)
+		return hipErrorInvalidValue;
+	if (mode == 0 && vt.whole)
+		mode = 4;
+	// Length of a workgroup's march along z.  The chip has `slots` places for workgroups (two per CU
+	// for the lean variants, one for the merged level 1 with its parked rows and for the general
+	// kernel); every march pays a 4-pair warm-up; a launch that fits the slots is one round, a
+	// larger one runs N / slots rounds plus a ragged tail; and a workgroup that has its CU to itself
+	// marches faster.  Pick the length with the least (rounds) x (pairs + 4).  Measured (one level,
+	// ms): 512^3 16 pairs 0.25 / 32 pairs 0.29 / 64 pairs 0.48; 640^3 0.53 / 0.61; 768^3 64 pairs
+	// 0.80 / 32 pairs 0.83 / 128 pairs 0.94; 896^3 32 pairs 1.39 / 128 pairs 1.45 / 64 pairs 1.50;
+	// 1024^3 128 pairs 1.66 / 64 pairs 1.67 / 32 pairs 1.71 / 16 pairs 1.83.
+	const double slots = (mode == 2 || mode == 4) ? 512 : 256;
 	int tp = 128;
-	while (tp > 32 && (long)ntx * nty * ((Zd + tp - 1) / tp) < 512)
-		tp >>= 1;
+	{
+		double best = -1;
+		for (int cand = 128; cand >= 16; cand >>= 1) {
+			const double n = (double)ntx * nty * ((Zd + cand - 1) / cand);
+			const double rounds = n <= slots ? (n <= slots / 2 ? 0.6 : 1.0) : n / slots + 0.35;
+			const double cost = rounds * (cand + 4);
+			if (best < 0 || cost < best) {
+				best = cost;
+				tp = cand;
+			}
+		}
+	}
 	if (vt.tile_pairs >= 4)
 		tp = vt.tile_pairs;
 	const int nzt = (Zd + tp - 1) / tp;
@@ -554,11 +575,6 @@ hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipS
 	// 3; the whole-tile one also 0, 2 and 7 for measurements.
 	const int want = vt.nt < 0 ? 1 : (vt.nt & 7);
 	const bool nt_loads = want == 3 || want == 2 || want == 7;
-	int mode = a.mode;
-	if (mode < 0 || mode > 3)
-		return hipErrorInvalidValue;
-	if (mode == 0 && vt.whole)
-		mode = 4;
 	if (mode >= 1 && mode <= 3 && rw != 8) // the multi-level store variants exist for the default row count
 		return hipErrorInvalidValue;
 	if ((mode == 2 || mode == 3) && !a.side)

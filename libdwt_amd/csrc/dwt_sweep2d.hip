@@ -389,9 +389,15 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	[[maybe_unused]] constexpr bool kNtStoreLL = kNtStore && !(NT & 4);
 	constexpr int TW = 64 * CPT;
 	constexpr int M = TW / 2;
-	constexpr int HC = CPT / 2;          // subband columns per lane
 	constexpr int RS = 2 * M + 16;
-	constexpr int NARR = CPT + 2 * K - 1; // interleaved samples c-K+1 .. c+CPT+K-1
+	// Mallat input, 8 columns per lane: a lane owns TWO groups of 4 columns, 256 columns apart, so that
+	// each output row leaves the wave as two contiguous 1 KiB stores (8 adjacent columns per lane
+	// made every store instruction write half of each 64-byte line: 136 against 109 us for level 0
+	// of one 8192^2 image) while the subband segments it reads are 1 KiB instead of 512 B
+	constexpr int G = (!IL && CPT == 8) ? 2 : 1; // column groups per lane
+	constexpr int CG = CPT / G;                  // columns per group
+	constexpr int NARR = CG + 2 * K - 1;         // interleaved samples c-K+1 .. c+CG+K-1 of a group
+	constexpr int HC = CG / 2;                   // subband columns per lane and group
 	constexpr int kDmaMain = IL ? CPT / 4 : (CPT == 8 ? 2 : 1);
 	constexpr int kDmaPerIter = 2 * (kDmaMain + 1);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -516,15 +522,17 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 		}
 	};
 
-	// vertical state: NV columns per lane (CPT when rows are undone first, NARR
-	// when columns are undone first and the horizontal halo must be carried)
-	constexpr int NV = W::kInvColsFirst ? NARR : CPT;
-	T st[K][NV];
+	// vertical state: per group CG columns when rows are undone first, NARR when columns are
+	// undone first and the horizontal halo must be carried
+	constexpr int NVG = W::kInvColsFirst ? NARR : CG;
+	T st[K][G][NVG];
 #pragma unroll
 	for (int s = 0; s < K; s++)
 #pragma unroll
-		for (int v = 0; v < NV; v++)
-			st[s][v] = 0;
+		for (int gi = 0; gi < G; gi++)
+#pragma unroll
+			for (int v = 0; v < NVG; v++)
+				st[s][gi][v] = 0;
 
 	for (int it = 0; it < kAhead && it < n_iter; it++)
 		issue(it);
@@ -538,8 +546,8 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 		}
 		const int p = p0 + it;
 
-		// gather the interleaved samples c-K+1 .. c+CPT+K-1 of both source rows
-		T x[2][NARR];
+		// gather the interleaved samples c-K+1 .. c+CG+K-1 of both source rows, per column group
+		T x[2][G][NARR];
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
 			const unsigned base = ring_off + (unsigned)((2 * it + rr) & (kRing - 1)) * RS * 4;
@@ -565,33 +573,20 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 				for (int j = 0; j < NARR; j++) {
 					const int rel = j - K + 1;
 					const T v = rel < 0 ? from_bits<T>(L4[(4 + rel) & 3]) : rel < CPT ? ownv[rel < CPT ? (rel < 0 ? 0 : rel) : 0] : from_bits<T>(R4[(rel - CPT) & 3]);
-					x[rr][j] = W::inv_scale(rel & 1, v);
+					x[rr][0][j] = W::inv_scale(rel & 1, v);
 				}
 				continue;
 			}
 			const unsigned hbase = base + 2 * M * 4;
-			// subband values L[cl-2 .. cl+HC+2), H[cl-2 .. cl+HC+2) as l[], h[]
-			T l[HC + 4], h[HC + 4];
-			if constexpr (CPT == 8) {
-				const unsigned ownL = base + lane * 16, ownH = base + M * 4 + lane * 16;
-				const unsigned laL = lane == 0 ? hbase : ownL - 16, raL = lane == 63 ? hbase + 16 : ownL + 16;
-				const unsigned laH = lane == 0 ? hbase + 32 : ownH - 16, raH = lane == 63 ? hbase + 48 : ownH + 16;
-				u4 a0, a1, a2, b0, b1, b2;
-				lds_read3(laL, ownL, raL, a0, a1, a2);
-				lds_read3(laH, ownH, raH, b0, b1, b2);
-				l[0] = from_bits<T>(a0[2]); l[1] = from_bits<T>(a0[3]);
-				h[0] = from_bits<T>(b0[2]); h[1] = from_bits<T>(b0[3]);
 #pragma unroll
-				for (int e = 0; e < 4; e++) {
-					l[2 + e] = from_bits<T>(a1[e]);
-					h[2 + e] = from_bits<T>(b1[e]);
-				}
-				l[6] = from_bits<T>(a2[0]); l[7] = from_bits<T>(a2[1]);
-				h[6] = from_bits<T>(b2[0]); h[7] = from_bits<T>(b2[1]);
-			} else {
-				const unsigned ownL = base + lane * 8, ownH = base + M * 4 + lane * 8;
-				const unsigned laL = lane == 0 ? hbase + 8 : ownL - 8, raL = lane == 63 ? hbase + 16 : ownL + 8;
-				const unsigned laH = lane == 0 ? hbase + 40 : ownH - 8, raH = lane == 63 ? hbase + 48 : ownH + 8;
+			for (int gi = 0; gi < G; gi++) {
+				// the lane's place among the 64 G groups of 2 subband columns across the tile
+				const int vl = 64 * gi + lane;
+				// subband values L[cl-2 .. cl+4), H[cl-2 .. cl+4) as l[], h[]
+				T l[HC + 4], h[HC + 4];
+				const unsigned ownL = base + vl * 8, ownH = base + M * 4 + vl * 8;
+				const unsigned laL = vl == 0 ? hbase + 8 : ownL - 8, raL = vl == 64 * G - 1 ? hbase + 16 : ownL + 8;
+				const unsigned laH = vl == 0 ? hbase + 40 : ownH - 8, raH = vl == 64 * G - 1 ? hbase + 48 : ownH + 8;
 				u2 a0, a1, a2, b0, b1, b2;
 				lds_read2x3(laL, ownL, raL, a0, a1, a2);
 				lds_read2x3(laH, ownH, raH, b0, b1, b2);
@@ -600,64 +595,69 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 					l[e] = from_bits<T>(a0[e]); l[2 + e] = from_bits<T>(a1[e]); l[4 + e] = from_bits<T>(a2[e]);
 					h[e] = from_bits<T>(b0[e]); h[2 + e] = from_bits<T>(b1[e]); h[4 + e] = from_bits<T>(b2[e]);
 				}
-			}
-			// x[j] <-> interleaved sample c-K+1+j (x[0] odd).  Sample i: even -> L[i/2],
-			// odd -> H[i/2]; relative to cl: L index (i-c)/2 -> l[2 + ...].
+				// x[j] <-> interleaved sample c-K+1+j (x[0] odd).  Sample i: even -> L[i/2],
+				// odd -> H[i/2]; relative to cl: L index (i-c)/2 -> l[2 + ...].
 #pragma unroll
-			for (int j = 0; j < NARR; j++) {
-				const int rel = j - K + 1; // sample index relative to c (c even)
-				if (rel & 1)
-					x[rr][j] = W::inv_scale(1, h[2 + ((rel - 1) >> 1)]);
-				else
-					x[rr][j] = W::inv_scale(0, l[2 + (rel >> 1)]);
+				for (int j = 0; j < NARR; j++) {
+					const int rel = j - K + 1; // sample index relative to c (c even)
+					if (rel & 1)
+						x[rr][gi][j] = W::inv_scale(1, h[2 + ((rel - 1) >> 1)]);
+					else
+						x[rr][gi][j] = W::inv_scale(0, l[2 + (rel >> 1)]);
+				}
 			}
 		}
 
-		T val[2][NV]; // val[0] = L row p, val[1] = H row p as the vertical pass sees them
-		if constexpr (!W::kInvColsFirst) {
+		T val[2][G][NVG]; // val[0] = L row p, val[1] = H row p as the vertical pass sees them
 #pragma unroll
-			for (int rr = 0; rr < 2; rr++) {
-				lift_inv_regs<W, NARR>(x[rr]);
-				// after the horizontal inverse the row is plain samples again; the
-				// vertical pass descales by ROW parity
+		for (int gi = 0; gi < G; gi++) {
+			if constexpr (!W::kInvColsFirst) {
 #pragma unroll
-				for (int v = 0; v < CPT; v++)
-					val[rr][v] = W::inv_scale(rr, x[rr][K - 1 + v]);
+				for (int rr = 0; rr < 2; rr++) {
+					lift_inv_regs<W, NARR>(x[rr][gi]);
+					// after the horizontal inverse the row is plain samples again; the
+					// vertical pass descales by ROW parity
+#pragma unroll
+					for (int v = 0; v < CG; v++)
+						val[rr][gi][v] = W::inv_scale(rr, x[rr][gi][K - 1 + v]);
+				}
+			} else {
+#pragma unroll
+				for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+					for (int v = 0; v < NVG; v++)
+						val[rr][gi][v] = x[rr][gi][v]; // int 5/3: no scaling anywhere
 			}
-		} else {
-#pragma unroll
-			for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-				for (int v = 0; v < NV; v++)
-					val[rr][v] = x[rr][v]; // int 5/3: no scaling anywhere
 		}
 
 		// vertical inverse, streaming.  K == 4: at step p the rows 2p-3 (odd) and
 		// 2p-2 (even) are final; K == 2: rows 2p-1 and 2p.
-		T odd_row[NV], even_row[NV];
+		T odd_row[G][NVG], even_row[G][NVG];
 #pragma unroll
-		for (int v = 0; v < NV; v++) {
-			const T s2 = val[0][v], d2 = val[1][v];
+		for (int gi = 0; gi < G; gi++)
+#pragma unroll
+		for (int v = 0; v < NVG; v++) {
+			const T s2 = val[0][gi][v], d2 = val[1][gi][v];
 			if constexpr (K == 4) {
 				// st: [0] d2[p-1], [1] s1[p-1], [2] d1[p-2], [3] e[p-2]
-				const T s1n = W::inv_step(0, s2, st[0][v], d2);            // s1[p]
-				const T d1n = W::inv_step(1, st[0][v], st[1][v], s1n);     // d1[p-1]
-				const T en = W::inv_step(2, st[1][v], st[2][v], d1n);      // e[p-1]
-				const T on = W::inv_step(3, st[2][v], st[3][v], en);       // o[p-2]
-				odd_row[v] = on;
-				even_row[v] = en;
-				st[0][v] = d2;
-				st[1][v] = s1n;
-				st[2][v] = d1n;
-				st[3][v] = en;
+				const T s1n = W::inv_step(0, s2, st[0][gi][v], d2);               // s1[p]
+				const T d1n = W::inv_step(1, st[0][gi][v], st[1][gi][v], s1n);    // d1[p-1]
+				const T en = W::inv_step(2, st[1][gi][v], st[2][gi][v], d1n);     // e[p-1]
+				const T on = W::inv_step(3, st[2][gi][v], st[3][gi][v], en);      // o[p-2]
+				odd_row[gi][v] = on;
+				even_row[gi][v] = en;
+				st[0][gi][v] = d2;
+				st[1][gi][v] = s1n;
+				st[2][gi][v] = d1n;
+				st[3][gi][v] = en;
 			} else {
 				// st: [0] d[p-1], [1] e[p-1]
-				const T en = W::inv_step(0, s2, st[0][v], d2);             // e[p]
-				const T on = W::inv_step(1, st[0][v], st[1][v], en);       // o[p-1]
-				odd_row[v] = on;
-				even_row[v] = en;
-				st[0][v] = d2;
-				st[1][v] = en;
+				const T en = W::inv_step(0, s2, st[0][gi][v], d2);                // e[p]
+				const T on = W::inv_step(1, st[0][gi][v], st[1][gi][v], en);      // o[p-1]
+				odd_row[gi][v] = on;
+				even_row[gi][v] = en;
+				st[0][gi][v] = d2;
+				st[1][gi][v] = en;
 			}
 		}
 		// output rows and their validity inside this tile
@@ -666,36 +666,40 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 		const bool ve = pe >= A && pe < B;
 		const bool vo = po >= A && po < B && (2 * po + 1 < a.H);
 
-		T orow[CPT], erow[CPT];
-		if constexpr (W::kInvColsFirst) {
-			lift_inv_regs<W, NARR>(odd_row);
-			lift_inv_regs<W, NARR>(even_row);
+		T orow[G][CG], erow[G][CG];
 #pragma unroll
-			for (int v = 0; v < CPT; v++) {
-				orow[v] = odd_row[K - 1 + v];
-				erow[v] = even_row[K - 1 + v];
-			}
-		} else {
+		for (int gi = 0; gi < G; gi++) {
+			if constexpr (W::kInvColsFirst) {
+				lift_inv_regs<W, NARR>(odd_row[gi]);
+				lift_inv_regs<W, NARR>(even_row[gi]);
 #pragma unroll
-			for (int v = 0; v < CPT; v++) {
-				orow[v] = odd_row[v];
-				erow[v] = even_row[v];
+				for (int v = 0; v < CG; v++) {
+					orow[gi][v] = odd_row[gi][K - 1 + v];
+					erow[gi][v] = even_row[gi][K - 1 + v];
+				}
+			} else {
+#pragma unroll
+				for (int v = 0; v < CG; v++) {
+					orow[gi][v] = odd_row[gi][v];
+					erow[gi][v] = even_row[gi][v];
+				}
 			}
 		}
 
-		// output rows as buffers: lanes and dwords beyond the row's end are dropped
-		const unsigned cb = (unsigned)(c0 + lane * CPT) * 4;
-		if (vo) {
-			const row_rsrc_t d = row_rsrc(out + (long)(2 * po + 1) * a.out_pitch, (unsigned)a.W * 4);
+		// output rows as buffers: lanes and dwords beyond the row's end are dropped.  A lane's
+		// columns: c0 + lane CG (+ 256 for the second group), 16 bytes each
 #pragma unroll
-			for (int e = 0; e < CPT; e += 4)
-				store16_row<kNtStore>(d, cb + e * 4, u4{to_bits(orow[e]), to_bits(orow[e + 1]), to_bits(orow[e + 2]), to_bits(orow[e + 3])});
-		}
-		if (ve) {
-			const row_rsrc_t d = row_rsrc(out + (long)(2 * pe) * a.out_pitch, (unsigned)a.W * 4);
+		for (int gi = 0; gi < G; gi++) {
 #pragma unroll
-			for (int e = 0; e < CPT; e += 4)
-				store16_row<kNtStore>(d, cb + e * 4, u4{to_bits(erow[e]), to_bits(erow[e + 1]), to_bits(erow[e + 2]), to_bits(erow[e + 3])});
+			for (int e = 0; e < CG; e += 4) {
+				const unsigned cb = (unsigned)(c0 + 64 * CG * gi + lane * CG + e) * 4;
+				if (vo)
+					store16_row<kNtStore>(row_rsrc(out + (long)(2 * po + 1) * a.out_pitch, (unsigned)a.W * 4), cb,
+						u4{to_bits(orow[gi][e]), to_bits(orow[gi][e + 1]), to_bits(orow[gi][e + 2]), to_bits(orow[gi][e + 3])});
+				if (ve)
+					store16_row<kNtStore>(row_rsrc(out + (long)(2 * pe) * a.out_pitch, (unsigned)a.W * 4), cb,
+						u4{to_bits(erow[gi][e]), to_bits(erow[gi][e + 1]), to_bits(erow[gi][e + 2]), to_bits(erow[gi][e + 3])});
+			}
 		}
 	}
 }

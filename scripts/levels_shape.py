@@ -12,7 +12,8 @@ dwt.dwt_util_init(); dwt.use_torch_stream()
 for kv in [x for x in (sys.argv[5] if len(sys.argv) > 5 else "").split(",") if x]:
     k, v = kv.split("="); dwt.set_option(k, int(v))
 x = torch.rand((nb, h, w), device="cuda"); y = torch.empty_like(x)
-fn = lambda: dwt.transform2d_batch("cdf97_s", 0, x, y, w * h * 4, nb, w * 4, w, h, J)
+inv = int(os.environ.get("INVERSE", 0))
+fn = lambda: dwt.transform2d_batch("cdf97_s", inv, x, y, w * h * 4, nb, w * 4, w, h, J)
 for _ in range(3): fn()
 dwt.prof_enable(2)
 for _ in range(10): fn()

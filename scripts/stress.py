@@ -92,7 +92,7 @@ while time.time() < t_end:
         desc = f"host {wav} {h_}x{w_} pitch {pitch_b} B J={J} d1={d1}"
     else:
         h_, w_ = rand_dim(), rand_dim()
-        pitch = w_ + int(rng.integers(0, 3)) * 4
+        pitch = w_ + int(rng.integers(0, 8))  # any element-aligned pitch: the sweeps need no 16-byte alignment
         J = int(rng.integers(-1, 7)); d1 = int(rng.integers(0, 2))
         if kind == "mallat":
             wav = str(rng.choice(["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"]))

@@ -201,6 +201,29 @@ def test_out_of_place_padded_strides(dwt, oracle, shape, levels):
     dwt.lib.dwt_hip_free(dst)
 
 
+@pytest.mark.parametrize("tile_pairs", [4, 16, 64, 128])
+def test_march_length_does_not_change_the_bits(dwt, oracle, tile_pairs):
+    """The fused kernel's march length along z (option vol_tile_pairs; chosen by a model in
+    production) only changes the schedule: z chunks of any length give the oracle's bits."""
+    shape = (150, 40, 512)
+    rng = np.random.default_rng(99)
+    vol = rng.random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), 2, False)
+    src = DevVol(dwt, vol)
+    dst = DevVol(dwt, np.zeros(shape, np.float32))
+    nz, ny, nx = shape
+    dwt.set_option("vol_fused", 2)
+    dwt.set_option("vol_tile_pairs", tile_pairs)
+    try:
+        dwt.transform3d_op(src.ptr, dst.ptr, nx * 4, nx * ny * 4, nx, ny, nz, 2)
+    finally:
+        dwt.set_option("vol_fused", 1)
+        dwt.set_option("vol_tile_pairs", 0)
+    assert np.array_equal(bits(dst.get()), bits(want))
+    src.free()
+    dst.free()
+
+
 def test_out_of_place_zero_levels_and_errors(dwt):
     vol = np.random.default_rng(1).random((4, 5, 6), dtype=np.float32)
     src = DevVol(dwt, vol)

@@ -10,7 +10,7 @@ nb, n, J = int(os.environ.get("IMAGES", 8)), 8192, 5
 inv = int(os.environ.get("INVERSE", 0))
 dwt.dwt_util_init(); dwt.use_torch_stream()
 x = torch.rand((nb, n, n), device="cuda"); y = torch.empty_like(x)
-DEF = dict(pipeline=0, tile_pairs=0, ring=0, cpt=0, ring_inv=0, waves=4, wave_horiz_inv=-1)
+DEF = dict(pipeline=0, tile_pairs=0, ring=0, cpt=0, ring_inv=0, waves=4, wave_horiz_inv=-1, nt=7)
 for v in sys.argv[1:] or [""]:
     opts = dict(DEF)
     for kv in [t for t in v.split(",") if t]:

@@ -55,41 +55,238 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
-    """Start `n` rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in
-    their environment), relay rank 0's JSON line, return non-zero if any rank failed."""
+def _log_dir():
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        return d
+    except OSError:
+        import tempfile
+
+        return tempfile.gettempdir()
+
+
+def launch_ranks(n, argv, timeout_s=420.0, grace_s=10.0):
+    """Start `n` rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+    environment) and relay rank 0's JSON line.  The parent watches ALL children: when any of
+    them exits non-zero the others get `grace_s` seconds and are then terminated (exactly the
+    processes started here, by pid); after `timeout_s` everything still running is terminated.
+    Whatever happened, the last complete JSON line rank 0 printed is relayed; the exit code is
+    non-zero only when there is none.  Every rank's stderr (and stdout of ranks >= 1) goes to
+    gpurun_out/bench_rank<r>.log."""
+    import threading
+
     port = _free_port()
-    procs = []
+    logdir = _log_dir()
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        log = open(os.path.join(logdir, f"bench_rank{r}.log"), "w")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    # rank 0's stdout is the result; drain it while the ranks run
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
+                                      stdout=subprocess.PIPE if r == 0 else log, stderr=log, text=True))
+    lines = []
+
+    def drain():  # rank 0's stdout is the result; read it while the ranks run
+        for ln in procs[0].stdout:
+            if ln.startswith("{") and ln.rstrip().endswith("}"):
+                lines.append(ln.rstrip())
+            else:
+                logs[0].write(ln)
+
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    t_end = time.time() + timeout_s
+    failed_at, why = None, None
+    while True:
+        codes = [p.poll() for p in procs]  # poll EVERY child (any() would stop at the first one running)
+        if all(c is not None for c in codes):
+            break
+        now = time.time()
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = now
+            why = f"a rank exited with an error (exit codes so far {codes})"
+        if now >= t_end:
+            why = f"no completion within {timeout_s:.0f} s"
+            break
+        if failed_at is not None and now - failed_at >= grace_s:
+            break
+        time.sleep(0.2)
+    for p in procs:  # whoever is still there: SIGTERM, then SIGKILL -- only the pids started above
+        if p.poll() is None:
+            p.terminate()
+    t_kill = time.time() + 5
+    for p in procs:
         try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
+            p.wait(timeout=max(0.1, t_kill - time.time()))
         except subprocess.TimeoutExpired:
-            p.kill()  # exactly the child we started
+            p.kill()
             p.wait()
-        rc = rc or p.returncode
-    line = None
-    for ln in (out0 or "").splitlines():
-        if ln.startswith("{"):
-            line = ln
-    if line:
-        print(line)
-    else:
-        sys.stderr.write(out0 or "")
-    if rc or not line:
-        sys.stderr.write(f"bench.py: a rank failed (exit codes {[p.returncode for p in procs]})\n")
-        return rc or 1
-    return 0
+    reader.join(timeout=5)
+    for log in logs:
+        log.close()
+    codes = [p.returncode for p in procs]
+    if lines:
+        print(lines[-1], flush=True)
+    if why or any(codes):
+        sys.stderr.write(f"bench.py: {why or 'a rank failed'}; exit codes {codes}; per-rank logs in {logdir}/bench_rank*.log\n")
+        for r in range(n):
+            try:
+                tail = open(os.path.join(logdir, f"bench_rank{r}.log")).read()[-1500:]
+            except OSError:
+                tail = ""
+            if tail.strip():
+                sys.stderr.write(f"--- rank {r} ---\n{tail}\n")
+    return 0 if lines else next((c for c in codes if c and c > 0), 1)
+
+
+# ---------------------------------------------------------------------------------------
+# Nothing below may lose the line: side measurements run under a deadline, one line is printed
+# ---------------------------------------------------------------------------------------
+STATE = {"line": None, "printed": False, "transform_done": False}
+
+
+def guarded(fn, timeout_s, device_index=None):
+    """Run fn() on a daemon thread; ("ok", result) | ("error", text) | ("timeout", None).  A
+    collective that never completes cannot be cancelled: the caller then prints what it has and
+    leaves with os._exit, the thread is abandoned."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            if device_index is not None:
+                import torch
+
+                torch.cuda.set_device(device_index)  # a new thread starts on device 0
+            box["ok"] = fn()
+        except BaseException as e:  # noqa: BLE001 -- reported, never raised into the bench
+            box["error"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return "timeout", None
+    if "error" in box:
+        return "error", box["error"]
+    return "ok", box.get("ok")
+
+
+def emit(out):
+    """The ONE JSON line of the run (rank 0)."""
+    if not STATE["printed"]:
+        STATE["printed"] = True
+        print(json.dumps(out), flush=True)
+
+
+def start_deadline(rank, seconds):
+    """Whole-run watchdog of a rank: at the deadline rank 0 prints the transform line if it has one
+    (flagged), and the process leaves without waiting for anything."""
+    import threading
+
+    def fire():
+        if rank == 0 and STATE["line"] is not None and not STATE["printed"]:
+            line = dict(STATE["line"])
+            line["watchdog"] = f"run deadline of {seconds:.0f} s reached; side measurements dropped"
+            emit(line)
+        sys.stdout.flush()
+        os._exit(0 if (STATE["printed"] or (rank != 0 and STATE["transform_done"])) else 4)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def finish(rank, out, split_fn, split_timeout, teardown, device_index=None):
+    """`out` (rank 0) is the complete transform line.  The side measurement (the batch split over
+    RCCL) runs under its own deadline; then rank 0 prints the line -- with the split's numbers, or
+    with why there are none -- and the rank leaves."""
+    STATE["transform_done"] = True
+    if rank == 0:
+        STATE["line"] = out
+    hung = False
+    if split_fn is not None:
+        status, res = guarded(split_fn, split_timeout, device_index)
+        if status == "ok":
+            split = res
+        elif status == "error":
+            split = {"error": res}
+        else:
+            hung = True
+            split = {"error": f"no completion within {split_timeout:.0f} s (point-to-point transfer hung); "
+                              "the transform's numbers are unaffected"}
+        if rank == 0 and split is not None:
+            out["batch_split"] = split
+    if rank == 0:
+        emit(out)
+    if hung:
+        os._exit(0)  # a wedged collective cannot be torn down; the line is out
+    status, _ = guarded(teardown, 30, device_index)
+    if status != "ok":
+        sys.stdout.flush()
+        os._exit(0)
+
+
+class Plane:
+    """Barrier and max-over-ranks of the timing, on RCCL (device tensors) when it is healthy and
+    on gloo (host tensors) otherwise -- the transform itself has no collective."""
+
+    def __init__(self, torch, dist, dev, on_device):
+        self.torch, self.dist, self.on_device = torch, dist, on_device
+        self.dev = dev if on_device else torch.device("cpu")
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        t = self.torch.zeros(1, dtype=self.torch.float32, device=self.dev)
+        self.dist.all_reduce(t)
+        t.item()
+
+    def max(self, seconds):
+        if self.dist is None:
+            return float(seconds)
+        t = self.torch.tensor([float(seconds)], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def open_group(torch, dist, dev, dev_index, shared, pg_timeout):
+    """One process per GPU: a default group with gloo for host tensors and RCCL ("nccl" on ROCm)
+    for device tensors.  RCCL's first collective runs under a deadline on a side stream; if it
+    fails or hangs the timing's barrier / max fall back to gloo and the line says so."""
+    import datetime
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    to = datetime.timedelta(seconds=pg_timeout)
+    if shared:
+        dist.init_process_group("gloo", timeout=to)
+        return Plane(torch, dist, dev, False), "gloo (ranks share a device)"
+    dist.init_process_group("cpu:gloo,cuda:nccl", timeout=to)
+
+    def first_collective():
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t)
+            side.synchronize()
+            return float(t.item())
+
+    status, res = guarded(first_collective, min(pg_timeout, 150), dev_index)
+    ok = status == "ok" and res == float(dist.get_world_size())
+    # every rank must take the same branch: agree over gloo
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return Plane(torch, dist, dev, True), "rccl"
+    reason = res if status == "error" else ("first all_reduce hung" if status == "timeout" else "another rank failed")
+    return Plane(torch, dist, dev, False), f"gloo (RCCL unusable: {reason})"
 
 
 # ---------------------------------------------------------------------------------------
@@ -225,11 +422,12 @@ def single_image_stats(torch, dwt, src, dst, n, J):
     return out
 
 
-def batch_split_times(torch, dist, src, total, n, rank, world, dev):
+def batch_split_times(torch, plane, src, total, n, rank, world, dev):
     """Scatter the whole batch from rank 0 and gather it back (libdwt_amd.batch, grouped
     point-to-point over RCCL/xGMI): the cost of a batch that starts and ends on one GPU."""
     from libdwt_amd import batch as B
 
+    dist = plane.dist
     lo, hi = B.shard_range(total, rank, world)
     full = None
     if rank == 0:
@@ -238,25 +436,22 @@ def batch_split_times(torch, dist, src, total, n, rank, world, dev):
     res = {}
     for rep in range(2):  # the first pass opens the RCCL point-to-point channels
         torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+        plane.barrier()
         t0 = time.perf_counter()
         local = B.scatter_images(full, total, (n, n), torch.float32, dev)
         torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+        plane.barrier()
         t1 = time.perf_counter()
         back = B.gather_images(local, total)
         torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+        plane.barrier()
         t2 = time.perf_counter()
         res = {"scatter_ms": (t1 - t0) * 1e3, "gather_ms": (t2 - t1) * 1e3}
         del local, back
     moved = (total - (hi - lo if rank == 0 else 0)) * n * n * 4
-    t = torch.tensor([res["scatter_ms"], res["gather_ms"]], dtype=torch.float64, device=dev)
+    t = torch.tensor([res["scatter_ms"], res["gather_ms"]], dtype=torch.float64, device=plane.dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    moved_t = torch.tensor([float(moved)], dtype=torch.float64, device=dev)
+    moved_t = torch.tensor([float(moved)], dtype=torch.float64, device=plane.dev)
     dist.broadcast(moved_t, 0)
     sc, ga = float(t[0]), float(t[1])
     b = float(moved_t[0])
@@ -265,13 +460,13 @@ def batch_split_times(torch, dist, src, total, n, rank, world, dev):
             "how": "rank 0 -> all ranks and back, grouped isend/irecv (batch_isend_irecv), root-egress bound"}
 
 
-def other_workload(args, dwt, torch, dist, world, rank, dev, coll_dev):
+def other_workload(args, dwt, torch, plane, world, rank, dev):
     """The other BASELINE.json configs through the same contract (one JSON line, whole-job rate,
     barrier + synchronize on both sides, max over ranks): config3 = int CDF 5/3 4096^2 3 levels
     forward + inverse, 16 images per GPU; config4 = float 9/7 forward 4096^2 5 levels, a fixed
     batch of 256 images sharded b*N//B (strong scaling); config5 = float 9/7 forward 3-D 1024^3
-    3 levels, out of place, one volume per GPU."""
-    from libdwt_amd.batch import max_over_ranks, shard_range
+    3 levels, out of place, one volume per GPU.  Returns the line (rank 0) or None."""
+    from libdwt_amd.batch import shard_range
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -289,7 +484,7 @@ def other_workload(args, dwt, torch, dist, world, rank, dev, coll_dev):
         alg = 2 * algorithmic_bytes(n, n, J) * nb
         metric = "Gsamples/s CDF 5/3 2-D int forward+inverse, 4096^2 3-level"
         name = f"CDF 5/3 forward + inverse 2-D int32, {n}x{n}, {J} levels, {nb} device-resident images per step per GPU"
-        check = lambda: bool(torch.equal(back, src))
+        check = lambda: {"round_trip_exact": bool(torch.equal(back, src))}
     elif w == "config4":
         n, J, total = 4096, 5, 256
         lo, hi = shard_range(total, rank, world)
@@ -304,7 +499,16 @@ def other_workload(args, dwt, torch, dist, world, rank, dev, coll_dev):
         metric = "Gsamples/s CDF 9/7 2-D fwd float, batch of 256 x 4096^2 5-level"
         name = (f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, fixed batch of {total} device-resident images "
                 f"sharded b*N//B over {world} GPU(s) ({nb} on rank 0)")
-        check = lambda: None
+        def check():
+            # in-run sanity: the first and the last image of this rank's shard, transformed ALONE through
+            # the libdwt.h entry dwt_cdf97_2f_s2, must give the batch's bits
+            one = torch.empty((n, n), dtype=torch.float32, device=dev)
+            same = True
+            for k in sorted({0, nb - 1}):
+                dwt.dwt_cdf97_2f_s2(src[k], one, n * 4, 4, n, n, n, n, J)
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(one.view(torch.int32), dst[k].view(torch.int32)))
+            return {"batch_equals_single_image_entry": same}
     else:
         n, J = 1024, 3
         src = torch.rand((n, n, n), generator=gen, device=dev, dtype=torch.float32)
@@ -315,13 +519,21 @@ def other_workload(args, dwt, torch, dist, world, rank, dev, coll_dev):
         alg = sum(8 * ((n >> j) ** 3) for j in range(J))
         metric = "Gvoxels/s CDF 9/7 3-D fwd float, 1024^3 3-level"
         name = f"CDF 9/7 forward 3-D float, {n}^3, {J} levels, out of place (cdf97_3f_op semantics), one volume per step per GPU"
-        check = lambda: None
+        def check():
+            # in-run sanity: a constant volume has no detail -- every coefficient with an odd index on
+            # any axis is ~0 and the deepest approximation is the constant times 2^(3J/2)
+            c = torch.full((64, 64, 256), 3.0, dtype=torch.float32, device=dev)
+            o = torch.empty_like(c)
+            dwt.transform3d_op(c, o, 256 * 4, 256 * 64 * 4, 256, 64, 64, 1)
+            torch.cuda.synchronize()
+            lll = o[0::2, 0::2, 0::2]
+            det = float(o[1::2].abs().max())
+            return {"constant_volume_ok": bool(det < 1e-5 and float((lll - 3.0 * 2 ** 1.5).abs().max()) < 1e-4)}
 
     def barrier():
         torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+        plane.barrier()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -330,19 +542,25 @@ def other_workload(args, dwt, torch, dist, world, rank, dev, coll_dev):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, device=coll_dev)
-    ok = check()
-    if rank == 0:
-        ach = alg * args.steps / elapsed / 1e9
-        print(json.dumps({
-            "metric": metric, "value": round(units * args.steps / elapsed / 1e9, 3), "unit": unit, "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": name, "parallelism": f"batch-sharded x{world}", "round_trip_exact": ok},
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "whole step (all levels) on rank 0: algorithmic bytes / step time"},
-        }))
+    elapsed = plane.max(elapsed)
+    try:
+        checks = check()
+    except Exception as e:  # noqa: BLE001
+        checks = {"check_error": f"{type(e).__name__}: {e}"}
+    if rank != 0:
+        return None
+    ach = alg * args.steps / elapsed / 1e9
+    cfg = {"workload": name, "parallelism": f"batch-sharded x{world}"}
+    cfg.update(checks)
+    return {
+        "metric": metric, "value": round(units * args.steps / elapsed / 1e9, 3), "unit": unit, "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": cfg,
+        "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "whole step (all levels) on rank 0: algorithmic bytes / step time"},
+    }
 
 
 def run_rank(args):
@@ -352,6 +570,7 @@ def run_rank(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it as `python bench.py --gpus N` "
                          f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    start_deadline(rank, max(30.0, args.timeout - 15.0))
 
     import torch
     import torch.distributed as dist
@@ -368,18 +587,19 @@ def run_rank(args):
     torch.cuda.set_device(dev_index)
     os.environ["DWT_HIP_DEVICE"] = str(dev_index)
     dev = torch.device("cuda", dev_index)
+    control = "single process"
+    plane = Plane(torch, None, dev, False)
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            # RCCL on ROCm, bound to this rank's GPU; barrier, max-reduce and the batch split only
-            dist.init_process_group("nccl", device_id=dev)
-    coll_dev = torch.device("cpu") if shared else dev
+        # barrier, max-reduce and the batch split only; RCCL bound to this rank's GPU
+        plane, control = open_group(torch, dist, dev, dev_index, shared, args.pg_timeout)
+
+    def teardown():
+        if use_dist:
+            plane.barrier()
+            dist.destroy_process_group()
 
     import libdwt_amd as dwt
-    from libdwt_amd.batch import max_over_ranks, shard_range
+    from libdwt_amd.batch import shard_range
 
     dwt.dwt_util_init()
     for kv in args.opt:
@@ -389,9 +609,10 @@ def run_rank(args):
     dwt.set_stream(stream.cuda_stream)
 
     if args.workload != "headline":
-        other_workload(args, dwt, torch, dist if use_dist else None, world, rank, dev, coll_dev)
-        if use_dist:
-            dist.destroy_process_group()
+        out = other_workload(args, dwt, torch, plane, world, rank, dev)
+        if out is not None and use_dist:
+            out["control_plane"] = control
+        finish(rank, out, None, 0, teardown, dev_index)
         return
 
     n, J, total = args.size, args.levels, args.images
@@ -417,9 +638,8 @@ def run_rank(args):
 
     def barrier():
         torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+        plane.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -437,7 +657,7 @@ def run_rank(args):
     dwt.prof_enable(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
 
-    elapsed = max_over_ranks(elapsed, device=coll_dev)
+    elapsed = plane.max(elapsed)
 
     samples = total * n * n * args.steps
     value = samples / elapsed / 1e9
@@ -449,16 +669,7 @@ def run_rank(args):
     l0_ms = k_ms / max(k_launches, 1)
     achieved = l0_bytes / (l0_ms * 1e-3) / 1e9 if k_launches else None
 
-    split = None
-    if use_dist and not args.no_split and not args.inplace:
-        try:
-            if shared:
-                split = {"skipped": "ranks share a device (gloo rehearsal); the RCCL batch split needs one GPU per rank"}
-            else:
-                split = batch_split_times(torch, dist, src, total, n, rank, world, dev)
-        except Exception as e:  # never lose the transform's line to the side measurement
-            split = {"error": f"{type(e).__name__}: {e}"}
-
+    out = None
     if rank == 0:
         traffic, traffic_src = _profile_traffic(l0_bytes, n)
         out = {
@@ -490,42 +701,80 @@ def run_rank(args):
                          "kernel": "k_fwd_sweep<Cdf97S> level 0",
                          "bytes_per_launch": l0_bytes, "avg_launch_ms": round(l0_ms, 5), "launches": k_launches},
         }
+        if use_dist:
+            out["control_plane"] = control
         if shared:
             out["devices_shared"] = True
-        if split is not None:
-            out["batch_split"] = split
+        STATE["line"] = dict(out)  # from here on the watchdog has something to print
         if not args.no_single and not args.inplace:
             try:
                 out["single_image"] = single_image_stats(torch, dwt, src, dst, n, J)
-            except Exception as e:
+            except Exception as e:  # noqa: BLE001
                 out["single_image"] = {"error": f"{type(e).__name__}: {e}"}
+            STATE["line"] = dict(out)
         if world == 1 and not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, J)
             except Exception as e:  # the checker is optional equipment of the bench
                 out["cpu_baseline"] = {"value": None, "unit": "Gsamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    # the side measurement comes LAST and under its own deadline: the scatter / gather of the whole
+    # batch over RCCL (never inside `value`); its first execution on real ranks may be the driver's
+    split_fn = None
+    if use_dist and not args.no_split and not args.inplace:
+        if shared:
+            split_fn = lambda: {"skipped": "ranks share a device (gloo rehearsal); the RCCL batch split needs one GPU per rank"}
+        elif not plane.on_device:
+            split_fn = lambda: {"skipped": f"control plane is {control}"}
+        else:
+            split_fn = lambda: batch_split_times(torch, plane, src, total, n, rank, world, dev)
+    finish(rank, out, split_fn, args.split_timeout, teardown, dev_index)
 
 
-def launcher_selftest():
-    """CPU rehearsal of the N-rank plumbing (tests/test_bench_launcher.py): the ranks form a
-    gloo group, exercise barrier + max-over-ranks, and rank 0 prints a line.  No GPU."""
-    import torch  # noqa: F401
+def launcher_selftest(args):
+    """CPU rehearsal of the N-rank plumbing (tests/test_bench_launcher.py): the ranks form a gloo
+    group and go through the SAME barrier / max-over-ranks / guarded side measurement / one-line /
+    teardown code as the GPU run; the side measurement is a real scatter + gather of a small batch
+    (libdwt_amd.batch over gloo).  No GPU.  BENCH_FAULT injects the failures the launcher and the
+    guards exist for: "exit:R" (rank R dies before the rendezvous), "hang_split:R" (rank R never
+    returns from the side measurement), "hang_transform:R" (rank R hangs before there is a line)."""
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    fault, _, frank = os.environ.get("BENCH_FAULT", "").partition(":")
+    hit = fault and int(frank or -1) == rank
+    if hit and fault == "exit":
+        sys.stderr.write(f"rank {rank}: injected failure before the rendezvous\n")
+        sys.exit(3)
+    start_deadline(rank, max(5.0, args.timeout - 5.0))
+    import datetime
+
+    import torch
     import torch.distributed as dist
 
-    from libdwt_amd.batch import max_over_ranks, shard_range
+    from libdwt_amd import batch as B
 
-    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
-    dist.init_process_group("gloo")
-    t = max_over_ranks(1.0 + rank)
-    lo, hi = shard_range(64, rank, world)
-    dist.barrier()
-    if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": world, "max_over_ranks": t, "images_rank0": hi - lo}))
-    dist.destroy_process_group()
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.pg_timeout))
+    plane = Plane(torch, dist, torch.device("cpu"), False)
+    plane.barrier()
+    if hit and fault == "hang_transform":
+        time.sleep(3600)
+    t = plane.max(1.0 + rank)
+    lo, hi = B.shard_range(64, rank, world)
+    out = {"selftest": True, "n_gpus": world, "max_over_ranks": t, "images_rank0": hi - lo} if rank == 0 else None
+
+    def split():
+        if hit and fault == "hang_split":
+            time.sleep(3600)
+        full = torch.arange(8 * 4 * 4, dtype=torch.float32).reshape(8, 4, 4) if rank == 0 else None
+        local = B.scatter_images(full, 8, (4, 4), torch.float32, torch.device("cpu"))
+        back = B.gather_images(local * 2, 8)
+        plane.barrier()
+        return {"round_trip_ok": bool(torch.equal(back, full * 2)) if rank == 0 else None}
+
+    def teardown():
+        plane.barrier()
+        dist.destroy_process_group()
+
+    finish(rank, out, split, args.split_timeout, teardown)
 
 
 def main():
@@ -541,6 +790,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-image entry timings")
     ap.add_argument("--no-split", action="store_true", help="skip the RCCL scatter/gather timing (N > 1)")
+    ap.add_argument("--timeout", type=float, default=420.0,
+                    help="whole-run deadline in seconds: the launcher terminates its ranks, a rank prints what it has and leaves")
+    ap.add_argument("--split-timeout", type=float, default=90.0, help="deadline of the RCCL batch-split side measurement")
+    ap.add_argument("--pg-timeout", type=float, default=180.0, help="process-group rendezvous / collective timeout")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")
     ap.add_argument("--workload", default="headline", choices=["headline", "config3", "config4", "config5"],
                     help="headline = BASELINE.json's metric (default); config3/4/5 = the other BASELINE configs, same JSON contract")
@@ -551,11 +804,11 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: start the rank processes (this parent never touches the GPU)
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.timeout))
     if args.selftest_launcher:
         if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
             raise SystemExit("bench.py: --gpus does not match WORLD_SIZE")
-        return launcher_selftest()
+        return launcher_selftest(args)
     run_rank(args)
 
 

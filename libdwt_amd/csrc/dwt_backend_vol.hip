@@ -40,8 +40,14 @@ static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long
 	float *S = nullptr;
 	long s_sy = 0, s_sz = 0;
 	bool in_place[kMaxVolLevels] = {}; // level wrote its lattice of dst itself
+	// in place (src == dst, the caller has checked that the one-pass in-place level applies): level 0
+	// runs over a snapshot of its tile halos (dwt_vol3d_ip.hip); the deeper levels read dense scratch
+	// volumes and write into their lattices of the volume as in an out-of-place call
+	const bool in_place_call = src == dst;
 	auto fuses = [&](int j) {
 		VolFusedArgs t{L[j].in, j ? L[j].sy : ssy, j ? L[j].sz : ssz, L[j].out, L[j].sy, L[j].sz, nullptr, 0, 0, L[j].lx, L[j].ly, L[j].lz};
+		if (j == 0 && in_place_call)
+			return true;
 		const bool can = t.in != t.out && t.nx >= 2 && t.ny >= 2 && t.nz >= 2;
 		return !g.force_generic && ((g.vol.fused == 1 && vol_fused_applies(t)) || (g.vol.fused >= 2 && can));
 	};
@@ -73,7 +79,14 @@ static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long
 				in_place[j] = true;
 			}
 			prof_before(j);
-			hipError_t e = launch_vol_fwd_fused(fa, g.vol, g.stream);
+			hipError_t e;
+			if (j == 0 && in_place_call) {
+				if (grow(&g.vol_out, &g.vol_out_bytes, vol_level_ip_scratch(fa, g.vol)))
+					return 1;
+				e = launch_vol_level_ip(false, fa, (float *)g.vol_out, g.vol, g.stream);
+			} else {
+				e = launch_vol_fwd_fused(fa, g.vol, g.stream);
+			}
 			prof_after(j);
 			if (e != hipSuccess)
 				return fail("fused 3-D level launch failed: %s", hipGetErrorString(e));
@@ -156,12 +169,22 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 	// every level needs at least 2 samples per axis (the reference asserts >= 5, dwt-simple.c:2172)
 	if (ceil_div_pow2(nx, levels - 1) < 2 || ceil_div_pow2(ny, levels - 1) < 2 || ceil_div_pow2(nz, levels - 1) < 2)
 		return fail("volume %dx%dx%d is too small for %d levels", nx, ny, nz, levels);
-	// Forward, where the fused one-pass level applies: the out-of-place levels into a dense result
-	// volume, then ONE copy back -- 8 + 8 B per voxel for level 0 like the two passes, but the
-	// deeper levels, their lattice packing and unpacking ride along for free and both halves run
-	// at better rates (1024^3: 3.1 against 3.3-3.4 ms for one level, 3.9 against 4.4-4.6 for three).
-	// The inverse has no one-pass kernel and stays on the two passes below.
-	if (!inverse && g.vol.inplace_fused && !g.force_generic && g.vol.fused >= 1) {
+	// One fused pass per level IN PLACE, over a snapshot of the tile halos (dwt_vol3d_ip.hip; round 3):
+	// ~10.5 B per voxel instead of 16.  Forward: level 0 in place, the deeper levels as in an
+	// out-of-place call (dense scratch inputs, results into their lattices of the volume).
+	const long vsy0 = (long)stride_y / 4, vsz0 = (long)stride_z / 4;
+	auto ip_level = [&](const float *p, long sy, long sz, int lx, int ly, int lz) {
+		VolFusedArgs t{p, sy, sz, (float *)p, sy, sz, nullptr, 0, 0, lx, ly, lz};
+		return g.vol.inplace_fused == 1 && !g.force_generic && g.vol.fused >= 1 &&
+			(g.vol.fused >= 2 ? vol_level_ip_can(t) : vol_level_ip_applies(t));
+	};
+	if (!inverse && levels <= kMaxVolLevels && ip_level((const float *)vol, vsy0, vsz0, nx, ny, nz))
+		return vol_forward_op((const float *)vol, vsy0, vsz0, (float *)vol, vsy0, vsz0, nx, ny, nz, levels);
+	// Round 2's forward route (option vol_inplace_fused = 2): the out-of-place levels into a dense
+	// result volume, then ONE copy back -- 8 + 8 B per voxel for level 0 like the two passes, but the
+	// deeper levels, their lattice packing and unpacking ride along and both halves run at better
+	// rates (1024^3: 3.1 against 3.3-3.4 ms for one level, 3.9 against 4.4-4.6 for three).
+	if (!inverse && g.vol.inplace_fused == 2 && !g.force_generic && g.vol.fused >= 1) {
 		VolFusedArgs t{(const float *)vol, (long)stride_y / 4, (long)stride_z / 4, nullptr, 0, 0, nullptr, 0, 0, nx, ny, nz};
 		// pays from about 2 GiB on: below, the two passes run partly out of the 256 MiB Infinity Cache
 		// (512^3: 0.44 ms in two passes, 0.29 + 0.2 fused + copy)
@@ -198,9 +221,7 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 	// scratch: S (pass-to-pass buffer) and, for levels >= 1, dense copies P[j] of the
 	// level-j lattice (even-even-even samples of level j-1), all carved from one buffer
 	const long s_sy = align_up(nx, 4), s_sz = s_sy * ny;
-	if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * nz * 4))
-		return 1;
-	float *S = (float *)g.stage_img;
+	float *S = nullptr; // sized below for the largest level that takes the two passes (none does when every level runs in one)
 	constexpr int kMaxLevels = 24;
 	if (levels > kMaxLevels)
 		return fail("too many levels");
@@ -225,10 +246,28 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 	for (int j = 0; j < levels; j++)
 		if (L[j].lz > 65535 || L[j].ly > 65535)
 			return fail("volume too large for the launch grid");
+	for (int j = 0; j < levels; j++)
+		if (!inverse || !ip_level(L[j].p, L[j].sy, L[j].sz, L[j].lx, L[j].ly, L[j].lz)) {
+			// S keeps level 0's strides for every level: slice z of level j at z * s_sz
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)s_sz * L[j].lz * 4))
+				return 1;
+			S = (float *)g.stage_img;
+			break;
+		}
 
 	auto one_level = [&](const Lvl &b, const Lvl *next) -> int {
 		// x then y fused per slice, then z (src/volume-dwt.c:677-725; inverse :1115-1163)
 		hipError_t e;
+		if (inverse && ip_level(b.p, b.sy, b.sz, b.lx, b.ly, b.lz)) {
+			// one pass, in place (the volume itself for level 0, the dense copy of its lattice above)
+			VolFusedArgs fa{b.p, b.sy, b.sz, b.p, b.sy, b.sz, nullptr, 0, 0, b.lx, b.ly, b.lz};
+			if (grow(&g.vol_out, &g.vol_out_bytes, vol_level_ip_scratch(fa, g.vol)))
+				return 1;
+			e = launch_vol_level_ip(true, fa, (float *)g.vol_out, g.vol, g.stream);
+			if (e != hipSuccess)
+				return fail("in-place fused 3-D level launch failed: %s", hipGetErrorString(e));
+			return 0;
+		}
 		if (!inverse) {
 			FwdLevelArgs a;
 			a.in = b.p; a.in_pitch = b.sy; a.in_bstride = b.sz;

@@ -82,7 +82,8 @@ struct VolTuning {
 	int tile_pairs = 0; // slice pairs per wave; 0 = choose from the volume depth
 	int nt = -1;        // bit 0 non-temporal stores, bit 1 non-temporal loads; -1 = measured default
 	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
-	int inplace_fused = 1; // in-place forward calls: fused levels into a result volume + one copy back (0: two passes per level)
+	int inplace_fused = 1; // in-place calls: 1 = one fused pass per level in place over a snapshot of the tile halos (forward and inverse),
+	                       // 2 = forward: out-of-place fused levels into a result volume + one copy back (round 2), 0 = two passes per level
 	int whole = 1;      // whole-tile variant of the fused kernel where the volume allows (0: the general one)
 	int direct = 2;     // fused levels >= 1 write into their lattice of the destination: 2 = level 1 merged with level 0's withheld rows where the sizes allow, 1 = strided stores, 0 = dense volume + scatter pass
 	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes
@@ -119,6 +120,25 @@ struct VolFusedArgs {
 };
 bool vol_fused_applies(const VolFusedArgs &a);
 hipError_t launch_vol_fwd_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s);
+
+// One 3-D level in ONE pass and IN PLACE (in == out, same strides), forward or inverse
+// (dwt_vol3d_ip.hip): a snapshot of the SHELL -- the rows, columns and slices a tile of the fused
+// kernel reads but does not own, about a quarter of the volume -- is taken into `scratch`
+// (vol_level_ip_scratch bytes), then the fused kernel reads tile interiors from the volume and halos
+// from the shell.  mode 0 (dense rows) or, forward only, 2 (see VolFusedArgs); `lll` as above.
+struct VolShell {
+	float *rs; // rows: [nz][7 (tile rows - 1)][nx]
+	long rs_sy, rs_sz;
+	float *cs; // columns: [nz][ny][8 (tile columns - 1)]
+	long cs_sy, cs_sz;
+	float *zs; // slices: [9 (marches - 1) + 5][ny][nx]
+	long zs_sy, zs_sz;
+	int tile_pairs_z, nzt; // slice pairs per march, marches along z
+};
+bool vol_level_ip_can(const VolFusedArgs &a);     // the kernel can run (any size from 2 x 2 x 8)
+bool vol_level_ip_applies(const VolFusedArgs &a); // ... and pays
+size_t vol_level_ip_scratch(const VolFusedArgs &a, const VolTuning &vt);
+hipError_t launch_vol_level_ip(bool inverse, const VolFusedArgs &a, float *scratch, const VolTuning &vt, hipStream_t s);
 
 // Strided 3-D copy (lattice pack/unpack for the levels >= 1 of the 3-D path);
 // strides in ELEMENTS, including the x strides.

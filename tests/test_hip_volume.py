@@ -234,3 +234,69 @@ def test_out_of_place_zero_levels_and_errors(dwt):
         dwt.transform3d_op(src.ptr, src.ptr, 24, 120, 6, 5, 4, 1)
     src.free()
     dst.free()
+
+
+IP_SHAPES = [((40, 64, 256), 1), ((33, 65, 129), 2), ((66, 70, 512), 3), ((24, 40, 300), 1), ((9, 33, 257), 1),
+             ((17, 35, 260), 1), ((8, 2, 515), 1), ((41, 97, 770), 2), ((50, 31, 1030), 1), ((26, 36, 2), 1),
+             ((130, 5, 64), 1), ((19, 129, 259), 1), ((64, 64, 64), 3), ((21, 34, 513), 2)]
+
+
+@pytest.mark.parametrize("tile_pairs", [0, 4, 7, 16], ids=lambda v: f"march{v}")
+@pytest.mark.parametrize("shape,levels", IP_SHAPES, ids=lambda v: str(v))
+def test_one_pass_in_place_levels(dwt, oracle, shape, levels, tile_pairs):
+    """dwt_hip_transform3d with the one-pass in-place level forced on small volumes (vol_fused = 2):
+    tiles read their own part from the volume they are overwriting and their halo rows, columns and
+    march-boundary slices from the shell snapshot.  Shapes cover several tile rows / columns, tiles
+    that overhang the volume by 1 .. 255 columns and 1 .. 31 rows, odd depths, and marches of 4, 7 and
+    16 slice pairs (so that the slice shell and the far-end reflection are exercised).  Forward and
+    inverse, every level: the oracle's bits."""
+    nz, ny, nx = shape
+    rng = np.random.default_rng(sum(shape) * 5 + levels)
+    vol = rng.random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), levels, False)
+    d = DevVol(dwt, vol)
+    dwt.set_option("vol_fused", 2)
+    dwt.set_option("vol_tile_pairs", tile_pairs)
+    try:
+        d.run(0, levels)
+        got = d.get()
+        assert np.array_equal(bits(got), bits(want)), "forward"
+        d.run(1, levels)
+        rec = d.get()
+    finally:
+        dwt.set_option("vol_fused", 1)
+        dwt.set_option("vol_tile_pairs", 0)
+    want_rec = oracle_multilevel(oracle, want.copy(), levels, True)
+    assert np.array_equal(bits(rec), bits(want_rec)), "inverse"
+    assert np.abs(rec - vol).max() < 1e-4
+    d.free()
+
+
+def test_one_pass_in_place_padded_strides(dwt, oracle):
+    """The in-place levels address through volume_t strides: padding between rows and slices stays
+    untouched, forward and inverse."""
+    shape, levels = (37, 70, 520), 2
+    nz, ny, nx = shape
+    sy = nx * 4 + 48
+    sz = sy * (ny + 2)
+    rng = np.random.default_rng(77)
+    vol = rng.random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), levels, False)
+    raw = np.full(sz * nz, 0xA5, np.uint8)
+    np.lib.stride_tricks.as_strided(raw.view(np.float32), shape=shape, strides=(sz, sy, 4))[...] = vol
+    ptr = dwt.lib.dwt_hip_malloc(raw.nbytes)
+    assert dwt.lib.dwt_hip_memcpy_h2d(ptr, raw.ctypes.data, raw.nbytes) == 0
+    mask = np.ones(raw.shape, bool)
+    np.lib.stride_tricks.as_strided(mask, shape=(nz, ny, nx * 4), strides=(sz, sy, 1))[...] = False
+    dwt.set_option("vol_fused", 2)
+    try:
+        for inverse, ref in ((0, want), (1, oracle_multilevel(oracle, want.copy(), levels, True))):
+            dwt.transform3d(inverse, ptr, sy, sz, nx, ny, nz, levels)
+            back = np.empty_like(raw)
+            assert dwt.lib.dwt_hip_memcpy_d2h(back.ctypes.data, ptr, raw.nbytes) == 0
+            got = np.lib.stride_tricks.as_strided(back.view(np.float32), shape=shape, strides=(sz, sy, 4))
+            assert np.array_equal(bits(np.ascontiguousarray(got)), bits(ref)), "inverse" if inverse else "forward"
+            assert np.all(back[mask] == 0xA5), "padding written"
+    finally:
+        dwt.set_option("vol_fused", 1)
+    dwt.lib.dwt_hip_free(ptr)

@@ -74,8 +74,9 @@ void dwt_hip_sync(void);
  * and 1 written once, 1 = sample-wise stores, 0 = dense results + scatter passes), "vol_nt"
  * (-1 = default: cacheable loads, non-temporal stores; bit 0 nt stores, bit 1 nt loads, bit 2
  * halo columns exempt), "vol_rows" (8 / 6 output rows per wave), "vol_tile_pairs",
- * "vol_swizzle", "vol_inplace_fused" (in-place forward calls of 2 GiB and more through the
- * one-pass levels + one copy back).  Every setting gives the same bits. */
+ * "vol_swizzle", "vol_inplace_fused" (in-place calls: 1 = one fused pass per level in place over a
+ * snapshot of the tile halos, forward and inverse; 2 = forward through the out-of-place levels + one
+ * copy back; 0 = two passes per level).  Every setting gives the same bits. */
 int dwt_hip_set_option(const char *name, int value);
 int dwt_hip_get_option(const char *name);
 
@@ -108,7 +109,9 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 /* Single-level 3-D CDF 9/7 float over the interleaved in-place layout of
  * cdf97_3f_ip_sep_horizontal_s / cdf97_3i_ip_sep_horizontal_s
  * (src/volume-dwt.c:677, 1115); `levels` > 1 re-applies it on the LLL lattice
- * (strides doubled) as SURVEY.md s8 a11 describes.  Device pointer, dense x. */
+ * (strides doubled) as SURVEY.md s8 a11 describes.  Device pointer, dense x.  Volumes of about
+ * 448^3 and more run every level in ONE pass in place (tile halos read from a snapshot, ~10.5 B per
+ * voxel), smaller ones in two passes through a scratch volume. */
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z,
 	int size_x, int size_y, int size_z, int levels);
 
@@ -118,6 +121,16 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
  * 448^3 and more, at least 128 samples wide; any size and 4-byte alignment), two passes otherwise. */
 int dwt_hip_transform3d_op(const void *src, void *dst, size_t stride_y, size_t stride_z,
 	int size_x, int size_y, int size_z, int levels);
+
+/* The same two transforms on the FIELDS of the reference's struct volume_t (include/volume.h; the
+ * typed wrappers cdf97_3f_op_sep_horizontal_s & co. of include/volume-dwt.h sit on these): one level,
+ * host or device pointers (host volumes are staged through HBM), source and destination with
+ * their own row / slice strides in bytes, samples dense along x.  dirs: 7 = x, y and z; 1 = x lines
+ * only (copy, then lift); 2 / 4 = y / z lines only, in place on dst (src unused) -- the reference's
+ * VOL_SEP_HORIZONTAL_X / _Y / _Z measurements (src/volume-dwt.c:788, :852, :918). */
+int dwt_hip_volume_fwd_op(const void *src, size_t src_stride_y, size_t src_stride_z, void *dst, size_t dst_stride_y,
+	size_t dst_stride_z, int size_x, int size_y, int size_z, int dirs);
+int dwt_hip_volume_ip(int inverse, void *data, size_t stride_y, size_t stride_z, int size_x, int size_y, int size_z);
 
 /* Device-side twins of dwt_util_conv_show_{s,i} (src/libdwt.c:21075, 21020) and
  * dwt_util_compare_{s,i} (:1593, :1531) for images that stay in HBM between a forward and
@@ -129,6 +142,9 @@ int dwt_hip_compare(int is_int, const void *ptr1, const void *ptr2, int stride_x
 /* Device memory helpers so that C callers need no HIP headers. */
 void *dwt_hip_malloc(size_t bytes);
 void dwt_hip_free(void *dev_ptr);
+/* page-locked host memory (what volume_alloc_realiably_locked hands out): DMA without a bounce buffer */
+void *dwt_hip_malloc_host(size_t bytes);
+void dwt_hip_free_host(void *host_ptr);
 int dwt_hip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int dwt_hip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
 int dwt_hip_is_device_pointer(const void *p);

@@ -79,6 +79,10 @@ lib.dwt_hip_transform3d.argtypes = [_I, _P, _S, _S, _I, _I, _I, _I]
 lib.dwt_hip_transform3d.restype = _I
 lib.dwt_hip_transform3d_op.argtypes = [_P, _P, _S, _S, _I, _I, _I, _I]
 lib.dwt_hip_transform3d_op.restype = _I
+lib.dwt_hip_volume_fwd_op.argtypes = [_P, _S, _S, _P, _S, _S, _I, _I, _I, _I]
+lib.dwt_hip_volume_fwd_op.restype = _I
+lib.dwt_hip_volume_ip.argtypes = [_I, _P, _S, _S, _I, _I, _I]
+lib.dwt_hip_volume_ip.restype = _I
 lib.dwt_hip_malloc.argtypes = [_S]
 lib.dwt_hip_malloc.restype = _P
 lib.dwt_hip_free.argtypes = [_P]
@@ -402,6 +406,85 @@ def transform3d_op(src, dst, stride_y, stride_z, size_x, size_y, size_z, levels=
     """Forward 3-D transform out of place (cdf97_3f_op_sep_horizontal_s, src/volume-dwt.c:727)."""
     _check(lib.dwt_hip_transform3d_op(_addr(src), _addr(dst), stride_y, stride_z, size_x, size_y, size_z, levels),
            "dwt_hip_transform3d_op")
+
+
+# ---- struct volume_t (include/volume.h, include/volume-dwt.h) ---------------------------
+class volume_t(C.Structure):
+    """The reference's 3-D container (src/volume.h:14-24): sizes, byte strides, data pointer."""
+    _fields_ = [("size_x", _I), ("size_y", _I), ("size_z", _I), ("stride_x", _S), ("stride_y", _S), ("stride_z", _S),
+                ("data", _P)]
+
+
+def volume_of(arr_or_ptr, shape_zyx=None, strides_zyx=None):
+    """A volume_t over a (z, y, x) float32 numpy array / torch tensor, or over a raw pointer with
+    explicit shape and byte strides.  The caller keeps the memory alive."""
+    if shape_zyx is None:
+        shape_zyx = tuple(arr_or_ptr.shape)
+        if hasattr(arr_or_ptr, "data_ptr"):
+            strides_zyx = tuple(s * arr_or_ptr.element_size() for s in arr_or_ptr.stride())
+        else:
+            strides_zyx = tuple(arr_or_ptr.strides)
+    nz, ny, nx = shape_zyx
+    sz, sy, sx = strides_zyx
+    return volume_t(nx, ny, nz, sx, sy, sz, _addr(arr_or_ptr))
+
+
+_VP = C.POINTER(volume_t)
+for _n in ("volume_alloc_realiably", "volume_alloc_realiably_locked", "volume_alloc_device"):
+    getattr(lib, _n).argtypes = [_S, _I, _I, _I, _I]
+    getattr(lib, _n).restype = _VP
+for _n in ("volume_free", "volume_fill_s", "volume_invalidate_cache", "cdf97_3f_ip_sep_horizontal_s", "cdf97_3i_ip_sep_horizontal_s"):
+    getattr(lib, _n).argtypes = [_VP]
+    getattr(lib, _n).restype = None
+for _n in ("volume_copy_s", "volume_compare_s"):
+    getattr(lib, _n).argtypes = [_VP, _VP]
+    getattr(lib, _n).restype = _I
+VOLUME_OP_SCHEDULES = ("sep_horizontal", "sep_vertical", "slices_vert4x4", "baseline_vert2x2x2", "HORIZ_vert2x2x2",
+                       "cube_vert4x4x2", "HORIZ_vert4x4x2", "HORIZ_vert4x4x4", "baseline_diag2x2x2", "HORIZ_diag2x2x2")
+for _n in VOLUME_OP_SCHEDULES:
+    getattr(lib, "cdf97_3f_op_%s_s" % _n).argtypes = [_VP, _VP]
+    getattr(lib, "cdf97_3f_op_%s_s" % _n).restype = None
+lib.cdf97_3f_op_wrapper_s.argtypes = [_VP, _VP, _I]
+lib.cdf97_3f_op_wrapper_s.restype = None
+lib.volume_save_to_pgm_s.argtypes = [_VP, C.c_char_p]
+lib.volume_save_to_pgm_s.restype = None
+lib.volume_perftest_fwd97op_s.argtypes = [_I, _I, _I, _I, C.POINTER(C.c_double), C.POINTER(C.c_ulong)]
+lib.volume_perftest_fwd97op_s.restype = _I
+lib.volume_perftest_fwd97op_device_s.argtypes = [_I, _I, _I, _I, C.POINTER(C.c_double)]
+lib.volume_perftest_fwd97op_device_s.restype = _I
+lib.volume_measure_fwd97op_s.argtypes = [_I, _I, _I, _I, _I, _I]
+lib.volume_measure_fwd97op_s.restype = _I
+
+
+def cdf97_3f_ip_sep_horizontal_s(volume):
+    """src/volume-dwt.c:677: forward, in place (a volume_t; host or device data)."""
+    lib.cdf97_3f_ip_sep_horizontal_s(C.byref(volume))
+
+
+def cdf97_3i_ip_sep_horizontal_s(volume):
+    """src/volume-dwt.c:1115: inverse, in place."""
+    lib.cdf97_3i_ip_sep_horizontal_s(C.byref(volume))
+
+
+def cdf97_3f_op_sep_horizontal_s(volume_src, volume_dst):
+    """src/volume-dwt.c:727: forward, out of place."""
+    lib.cdf97_3f_op_sep_horizontal_s(C.byref(volume_src), C.byref(volume_dst))
+
+
+def cdf97_3f_op_wrapper_s(volume_src, volume_dst, approach):
+    """src/volume-dwt.c:2787: the schedule dispatcher (enum volume_approach 0..12)."""
+    lib.cdf97_3f_op_wrapper_s(C.byref(volume_src), C.byref(volume_dst), int(approach))
+
+
+def volume_perftest_fwd97op_s(size, opt_stride, approach, N, device=False):
+    """src/volume-dwt.c:2810: (errors, seconds per voxel); device=True keeps both volumes in HBM."""
+    secs = C.c_double()
+    if device:
+        err = lib.volume_perftest_fwd97op_device_s(size, opt_stride, int(approach), N, C.byref(secs))
+    else:
+        faults = C.c_ulong()
+        err = lib.volume_perftest_fwd97op_s(size, opt_stride, int(approach), N, C.byref(secs), C.byref(faults))
+    return err, secs.value
 
 
 # ---- device memory without torch -------------------------------------------------------

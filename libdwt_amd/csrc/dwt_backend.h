@@ -36,6 +36,9 @@ struct Ctx {
 	size_t host_a_bytes = 0, host_b_bytes = 0;
 	void *vol_out = nullptr; // dense result volume of an in-place 3-D forward call (fused levels, then copied back)
 	size_t vol_out_bytes = 0;
+	void *vol_host[2] = {nullptr, nullptr}; // device staging of host volumes (struct volume_t entries)
+	size_t vol_host_bytes[2] = {0, 0};
+	hipEvent_t dl_ev[8] = {}; // strip events of host_download, created once
 	void *pin = nullptr; // pinned host staging for host-pointer calls with awkward strides
 	size_t pin_bytes = 0;
 	// pipeline lanes for batches: image k runs all its levels on lane k % lanes, so the

@@ -275,12 +275,15 @@ int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, co
 	// strips: strip k is spread back into the caller's image while strip k+1 crosses PCIe
 	const int strips = (int)std::min<size_t>(8, std::max<size_t>(1, (size_t)pitch * h / (16u << 20))); // >= 16 MiB each
 	const int rows_per = (h + strips - 1) / strips;
-	hipEvent_t ev[8];
+	// one event per strip, created once per context (they used to be created and destroyed per call,
+	// and leaked when a call failed half way)
+	hipEvent_t *ev = g.dl_ev;
 	int n_ev = 0;
 	for (int y_a = 0; y_a < h; y_a += rows_per, n_ev++) {
 		const int y_b = y_a + rows_per < h ? y_a + rows_per : h;
 		HIP_TRY(hipMemcpyAsync(pin + (long)y_a * pitch, (const char *)dp + (long)y_a * pitch, (size_t)pitch * (y_b - y_a), hipMemcpyDeviceToHost, g.stream));
-		HIP_TRY(hipEventCreateWithFlags(&ev[n_ev], hipEventDisableTiming));
+		if (!ev[n_ev])
+			HIP_TRY(hipEventCreateWithFlags(&ev[n_ev], hipEventDisableTiming));
 		HIP_TRY(hipEventRecord(ev[n_ev], g.stream));
 	}
 	int k = 0;
@@ -300,8 +303,6 @@ int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, co
 			}
 		});
 	}
-	for (int i = 0; i < n_ev; i++)
-		hipEventDestroy(ev[i]);
 	return 0;
 }
 
@@ -830,13 +831,19 @@ void dwt_hip_finish(void)
 	if (!g.inited)
 		return;
 	hipStreamSynchronize(g.stream);
-	void **bufs[] = {&g.stage_img, &g.ll[0], &g.ll[1], &g.host_a, &g.host_b, &g.vol_out};
+	void **bufs[] = {&g.stage_img, &g.ll[0], &g.ll[1], &g.host_a, &g.host_b, &g.vol_out, &g.vol_host[0], &g.vol_host[1]};
 	for (void **b : bufs) {
 		if (*b)
 			hipFree(*b);
 		*b = nullptr;
 	}
 	g.stage_bytes = g.ll_bytes[0] = g.ll_bytes[1] = g.host_a_bytes = g.host_b_bytes = g.vol_out_bytes = 0;
+	g.vol_host_bytes[0] = g.vol_host_bytes[1] = 0;
+	for (hipEvent_t &e : g.dl_ev) {
+		if (e)
+			hipEventDestroy(e);
+		e = nullptr;
+	}
 	if (g.pin)
 		hipHostFree(g.pin);
 	g.pin = nullptr;
@@ -1009,6 +1016,24 @@ void dwt_hip_free(void *p)
 {
 	if (p)
 		hipFree(p);
+}
+
+void *dwt_hip_malloc_host(size_t bytes)
+{
+	if (check_inited())
+		return nullptr;
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		fail("hipHostMalloc(%zu) failed", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+void dwt_hip_free_host(void *p)
+{
+	if (p)
+		hipHostFree(p);
 }
 
 int dwt_hip_memcpy_h2d(void *d, const void *h, size_t n)

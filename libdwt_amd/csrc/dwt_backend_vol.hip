@@ -324,5 +324,146 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 	return 0;
 }
 
+
+// ---- struct volume_t level (include/volume.h, include/volume-dwt.h): host or device volumes ----
+
+// whole-volume transfer between a HOST volume (any byte strides: libdwt's "optimal" strides are odd
+// byte counts) and a dense DEVICE volume of 4-byte samples.  Host rows the DMA engines like (64-byte
+// multiples, 16-byte aligned) go as one 2-D copy, or one per slice when the slices are padded; any
+// other layout goes slice by slice through host_upload / host_download (CPU repacking into a pinned
+// buffer, pipelined with the transfer).  Padding is never touched.
+static int vol_xfer(bool to_device, void *dev, size_t d_sy, size_t d_sz, void *host, size_t h_sy, size_t h_sz, int nx, int ny, int nz)
+{
+	const size_t row = (size_t)nx * 4;
+	const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+	const bool fast = h_sy % 64 == 0 && h_sz % 16 == 0 && (uintptr_t)host % 16 == 0;
+	if (!fast) {
+		for (int z = 0; z < nz; z++) {
+			char *hp = (char *)host + (size_t)z * h_sz, *dp = (char *)dev + (size_t)z * d_sz;
+			if (to_device ? host_upload(hp, (int)h_sy, 4, 4, nx, ny, dp, (long)d_sy) : host_download(hp, (int)h_sy, 4, 4, nx, ny, dp, (long)d_sy))
+				return 1;
+		}
+		return 0;
+	}
+	void *dst = to_device ? dev : host;
+	const void *src = to_device ? host : dev;
+	const size_t dst_sy = to_device ? d_sy : h_sy, dst_sz = to_device ? d_sz : h_sz, src_sy = to_device ? h_sy : d_sy, src_sz = to_device ? h_sz : d_sz;
+	if (d_sy == h_sy && d_sz == h_sz && h_sy == row && h_sz == row * ny) {
+		HIP_TRY(hipMemcpyAsync(dst, src, row * ny * nz, kind, g.stream));
+	} else if (d_sz == d_sy * ny && h_sz == h_sy * ny) {
+		HIP_TRY(hipMemcpy2DAsync(dst, dst_sy, src, src_sy, row, (size_t)ny * nz, kind, g.stream));
+	} else {
+		for (int z = 0; z < nz; z++)
+			HIP_TRY(hipMemcpy2DAsync((char *)dst + z * dst_sz, dst_sy, (const char *)src + z * src_sz, src_sy, row, ny, kind, g.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+static int vol_check(const void *p, size_t sy, size_t sz, int nx, int ny, int nz, const char *who)
+{
+	if (!p || nx < 1 || ny < 1 || nz < 1)
+		return fail("%s: empty volume", who);
+	if (sy < (size_t)nx * 4 || sz < sy * (size_t)ny)
+		return fail("%s: bad volume strides", who);
+	if (dwt_hip_is_device_pointer(p) && ((sy & 3) || (sz & 3)))
+		return fail("%s: device volumes need strides that are multiples of 4 bytes", who);
+	return 0;
+}
+
+// one direction only, in place on a device volume (the reference's VOL_SEP_HORIZONTAL_X / _Y / _Z
+// measurements, src/volume-dwt.c:788-981): exact line passes through a staging volume
+static int vol_one_direction(float *vol, long sy, long sz, int nx, int ny, int nz, int dir)
+{
+	// the line pass shares its strides between source and destination: the staging volume mirrors the caller's
+	if (grow(&g.stage_img, &g.stage_bytes, (size_t)sz * nz * 4))
+		return 1;
+	float *T = (float *)g.stage_img;
+	hipError_t e = hipSuccess;
+	if (dir == 4) {
+		// the z lines of row y: adjacent lanes take adjacent x
+		for (int y = 0; y < ny && e == hipSuccess; y++)
+			e = launch_line_pass(kCdf97S, false, vol + (long)y * sy, T + (long)y * sy, 4, sz * 4, nx, nz, -1, true, g.stream);
+	} else {
+		for (int z = 0; z < nz && e == hipSuccess; z++)
+			e = dir == 1 ? launch_line_pass(kCdf97S, false, vol + (long)z * sz, T + (long)z * sz, sy * 4, 4, ny, nx, -1, false, g.stream)
+			             : launch_line_pass(kCdf97S, false, vol + (long)z * sz, T + (long)z * sz, 4, sy * 4, nx, ny, -1, true, g.stream);
+	}
+	if (e != hipSuccess)
+		return fail("3-D line pass launch failed: %s", hipGetErrorString(e));
+	e = launch_lattice_copy(T, 1, sy, sz, vol, 1, sy, sz, nx, ny, nz, g.stream);
+	if (e != hipSuccess)
+		return fail("3-D copy back failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
+// Forward, out of place, on the fields of two struct volume_t (cdf97_3f_op_sep_horizontal_s,
+// src/volume-dwt.c:727-785, and the single-direction variants :788-981).  Host or device pointers,
+// each with its own strides.  dirs: 7 = the transform; 1 = x only (copy, then x lines); 2 / 4 = y / z
+// only, IN PLACE on dst as the reference does (src is not read).
+int dwt_hip_volume_fwd_op(const void *src, size_t s_sy, size_t s_sz, void *dst, size_t d_sy, size_t d_sz, int nx, int ny, int nz, int dirs)
+{
+	if (check_inited())
+		return 1;
+	if (dirs != 7 && dirs != 1 && dirs != 2 && dirs != 4)
+		return fail("dwt_hip_volume_fwd_op: dirs must be 7, 1, 2 or 4");
+	const bool reads_src = dirs == 7 || dirs == 1;
+	if ((reads_src && vol_check(src, s_sy, s_sz, nx, ny, nz, __func__)) || vol_check(dst, d_sy, d_sz, nx, ny, nz, __func__))
+		return 1;
+	if (reads_src && src == dst)
+		return fail("dwt_hip_volume_fwd_op is out of place");
+	const bool s_dev = !reads_src || dwt_hip_is_device_pointer(src), d_dev = dwt_hip_is_device_pointer(dst);
+	const long t_sy = align_up(nx, 4), t_sz = t_sy * ny;
+	const float *S = (const float *)src;
+	float *D = (float *)dst;
+	long S_sy = (long)s_sy / 4, S_sz = (long)s_sz / 4, D_sy = (long)d_sy / 4, D_sz = (long)d_sz / 4;
+	if (!s_dev) {
+		if (grow(&g.vol_host[0], &g.vol_host_bytes[0], (size_t)t_sz * nz * 4) ||
+			vol_xfer(true, g.vol_host[0], t_sy * 4, t_sz * 4, (void *)src, s_sy, s_sz, nx, ny, nz))
+			return 1;
+		S = (const float *)g.vol_host[0];
+		S_sy = t_sy; S_sz = t_sz;
+	}
+	if (!d_dev) {
+		if (grow(&g.vol_host[1], &g.vol_host_bytes[1], (size_t)t_sz * nz * 4))
+			return 1;
+		D = (float *)g.vol_host[1];
+		D_sy = t_sy; D_sz = t_sz;
+		if (!reads_src && vol_xfer(true, D, t_sy * 4, t_sz * 4, dst, d_sy, d_sz, nx, ny, nz))
+			return 1;
+	}
+	int rc;
+	if (dirs == 7) {
+		rc = vol_forward_op(S, S_sy, S_sz, D, D_sy, D_sz, nx, ny, nz, 1);
+	} else if (dirs == 1) {
+		// copy every x line to the destination, lift it there (src/volume-dwt.c:800-813)
+		hipError_t e = launch_lattice_copy(S, 1, S_sy, S_sz, D, 1, D_sy, D_sz, nx, ny, nz, g.stream);
+		rc = e == hipSuccess ? vol_one_direction(D, D_sy, D_sz, nx, ny, nz, 1) : fail("volume copy failed: %s", hipGetErrorString(e));
+	} else {
+		rc = vol_one_direction(D, D_sy, D_sz, nx, ny, nz, dirs);
+	}
+	if (rc)
+		return 1;
+	if (!d_dev)
+		return vol_xfer(false, D, t_sy * 4, t_sz * 4, dst, d_sy, d_sz, nx, ny, nz);
+	return 0;
+}
+
+// One level in place on the fields of a struct volume_t (cdf97_3f_ip_sep_horizontal_s /
+// cdf97_3i_ip_sep_horizontal_s, src/volume-dwt.c:677, :1115); host volumes are staged through HBM.
+int dwt_hip_volume_ip(int inverse, void *data, size_t sy, size_t sz, int nx, int ny, int nz)
+{
+	if (check_inited() || vol_check(data, sy, sz, nx, ny, nz, __func__))
+		return 1;
+	if (dwt_hip_is_device_pointer(data))
+		return dwt_hip_transform3d(inverse, data, sy, sz, nx, ny, nz, 1);
+	const long t_sy = align_up(nx, 4), t_sz = t_sy * ny;
+	if (grow(&g.vol_host[0], &g.vol_host_bytes[0], (size_t)t_sz * nz * 4) ||
+		vol_xfer(true, g.vol_host[0], t_sy * 4, t_sz * 4, data, sy, sz, nx, ny, nz) ||
+		dwt_hip_transform3d(inverse, g.vol_host[0], t_sy * 4, t_sz * 4, nx, ny, nz, 1))
+		return 1;
+	return vol_xfer(false, g.vol_host[0], t_sy * 4, t_sz * 4, data, sy, sz, nx, ny, nz);
+}
+
 } // extern "C"
 #pragma GCC visibility pop

@@ -138,9 +138,94 @@ def gen_multichannel(ref, manifest):
     print(path, os.path.getsize(path), "bytes", len(meta), "cases")
 
 
+# 3-D volumes WIDE enough for the fused one-pass kernels (>= 128 samples along x, several tile rows /
+# columns, tiles that overhang), through the reference's in-place AND out-of-place forward entries
+# (cdf97_3f_ip_sep_horizontal_s, cdf97_3f_op_sep_horizontal_s, src/volume-dwt.c:677, :727) and its
+# inverse (:1115); inputs: seeded uniform [0,1) and the reference's own volume_fill_s pattern
+# (src/volume.c:41-66).  "full" cases store the arrays; "digest" cases store the sha256 of the
+# input and of each output (the volumes would be megabytes each) -- the input is regenerated by the
+# test from the same seed / by the product's volume_fill_s and checked against its digest first.
+# (name, (nz, ny, nx), input kind, full?)
+CASES_VOL = [
+    ("vol_10x34x260_rand", (10, 34, 260), "rand", True),
+    ("vol_12x40x256_pat", (12, 40, 256), "pattern", True),
+    ("vol_24x40x256_rand", (24, 40, 256), "rand", False),
+    ("vol_33x35x300_rand", (33, 35, 300), "rand", False),
+    ("vol_9x130x513_rand", (9, 130, 513), "rand", False),
+    ("vol_37x50x260_pat", (37, 50, 260), "pattern", False),
+    ("vol_64x96x512_pat", (64, 96, 512), "pattern", False),
+    ("vol_40x70x1030_rand", (40, 70, 1030), "rand", False),
+]
+
+
+def gen_volumes(ref, manifest):
+    import ctypes as C
+
+    class Vol(C.Structure):
+        _fields_ = [("size_x", C.c_int), ("size_y", C.c_int), ("size_z", C.c_int), ("stride_x", C.c_size_t),
+                    ("stride_y", C.c_size_t), ("stride_z", C.c_size_t), ("data", C.c_void_p)]
+
+    def vol(a):
+        return Vol(a.shape[2], a.shape[1], a.shape[0], a.strides[2], a.strides[1], a.strides[0], a.ctypes.data)
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    arrays, meta = {}, []
+    for idx, (name, shp, kind, full) in enumerate(CASES_VOL):
+        if kind == "rand":
+            v = np.random.default_rng(7000 + idx).random(shp, dtype=np.float32)
+        else:
+            v = np.zeros(shp, np.float32)
+            ref.lib.volume_fill_s(C.byref(vol(v)))
+        ip = v.copy()
+        ref.lib.cdf97_3f_ip_sep_horizontal_s(C.byref(vol(ip)))
+        op = np.full(shp, -7.0, np.float32)
+        src = v.copy()
+        ref.lib.cdf97_3f_op_sep_horizontal_s(C.byref(vol(src)), C.byref(vol(op)))
+        assert np.array_equal(src.view(np.uint32), v.view(np.uint32)), "the reference modified its source"
+        inv = ip.copy()
+        ref.lib.cdf97_3i_ip_sep_horizontal_s(C.byref(vol(inv)))
+        m = {"name": name, "shape_zyx": shp, "input": kind, "seed": 7000 + idx if kind == "rand" else None, "full": full,
+             "sha256": {"in": sha(v), "fwd": sha(ip), "fwd_op": sha(op), "inv": sha(inv)},
+             "op_equals_ip": bool(np.array_equal(ip.view(np.uint32), op.view(np.uint32)))}
+        if full:
+            arrays[f"{name}.in"] = v
+            arrays[f"{name}.fwd"] = ip
+            arrays[f"{name}.fwd_op"] = op
+            arrays[f"{name}.inv"] = inv
+        meta.append(m)
+    # the single-direction schedules of the dispatcher (VOL_SEP_HORIZONTAL_X / _Y / _Z = 10, 11, 12,
+    # src/volume-dwt.c:788, :852, :918: x copies then lifts, y and z lift the destination in place)
+    shp = (9, 11, 14)
+    v = np.random.default_rng(7100).random(shp, dtype=np.float32)
+    arrays["vol_dirs.in"] = v
+    src = v.copy()  # (the struct holds an address only: the array must outlive the call)
+    for ap, tag in ((10, "x"), (11, "y"), (12, "z")):
+        dst = v.copy() if ap != 10 else np.full(shp, -3.0, np.float32)
+        ref.lib.cdf97_3f_op_wrapper_s(C.byref(vol(src)), C.byref(vol(dst)), ap)
+        arrays[f"vol_dirs.{tag}"] = dst
+    assert np.array_equal(src, v)
+    # the pattern itself
+    pat = np.zeros((13, 9, 21), np.float32)
+    ref.lib.volume_fill_s(C.byref(vol(pat)))
+    arrays["vol_fill_13x9x21"] = pat
+    path = os.path.join(OUT, "cdf97_3d_wide.npz")
+    np.savez_compressed(path, **arrays)
+    manifest["files"]["cdf97_3d_wide.npz"] = {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "cases": meta}
+    print(path, os.path.getsize(path), "bytes", len(meta), "cases")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = Reference()
+    if sys.argv[1:] == ["volumes"]:
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_volumes(ref, manifest)
+        with open(os.path.join(OUT, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return
     if sys.argv[1:] == ["multichannel"]:
         # add / refresh this one file, leaving the others (and their hashes) as they are
         with open(os.path.join(OUT, "manifest.json")) as f:
@@ -259,6 +344,7 @@ def main():
     print(path, os.path.getsize(path), "bytes")
 
     gen_multichannel(ref, manifest)
+    gen_volumes(ref, manifest)
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)

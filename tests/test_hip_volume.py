@@ -300,3 +300,135 @@ def test_one_pass_in_place_padded_strides(dwt, oracle):
     finally:
         dwt.set_option("vol_fused", 1)
     dwt.lib.dwt_hip_free(ptr)
+
+
+# ---- the reference's own 3-D boundary: struct volume_t, include/volume.h / volume-dwt.h ----
+
+def _wide_cases():
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)["files"]["cdf97_3d_wide.npz"]["cases"]
+
+
+def _sha(a):
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("fused", [2, 1, 0], ids=["one-pass", "default", "two-pass"])
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("meta", _wide_cases(), ids=lambda m: m["name"])
+def test_reference_fixtures_through_the_volume_api(dwt, meta, where, fused):
+    """tests/golden/cdf97_3d_wide.npz -- volumes wide enough for the fused kernels, transformed by the
+    REFERENCE through cdf97_3f_ip_sep_horizontal_s, cdf97_3f_op_sep_horizontal_s and
+    cdf97_3i_ip_sep_horizontal_s -- replayed through the same three functions of include/volume-dwt.h on
+    struct volume_t, host volumes (staged) and device volumes, with the one-pass kernels forced
+    (vol_fused = 2: k_vol_fwd_fused out of place, k_vol_level_ip in place), as shipped, and in two passes.
+    Inputs: the fixture's array, the seed's stream, or the product's own volume_fill_s (each checked
+    against the reference's digest first).  Bit for bit."""
+    import os
+
+    from conftest import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "cdf97_3d_wide.npz"))
+    shp = tuple(meta["shape_zyx"])
+    if meta["full"]:
+        v = z[meta["name"] + ".in"]
+    elif meta["input"] == "rand":
+        v = np.random.default_rng(meta["seed"]).random(shp, dtype=np.float32)
+    else:
+        v = np.zeros(shp, np.float32)
+        vt = dwt.volume_of(v)
+        dwt.lib.volume_fill_s(vt)
+    assert _sha(v) == meta["sha256"]["in"]
+    dwt.set_option("vol_fused", fused)
+    try:
+        if where == "host":
+            ip = v.copy()
+            dwt.cdf97_3f_ip_sep_horizontal_s(dwt.volume_of(ip))
+            big = np.full((shp[0], shp[1] + 1, shp[2] + 5), -2.0, np.float32)  # a destination with other strides
+            op = big[:, :shp[1], :shp[2]]
+            src = v.copy()
+            dwt.cdf97_3f_op_sep_horizontal_s(dwt.volume_of(src), dwt.volume_of(op))
+            assert np.array_equal(bits(src), bits(v)), "source modified"
+            assert np.all(big[:, shp[1]:, :] == -2.0) and np.all(big[:, :, shp[2]:] == -2.0), "padding written"
+            inv = ip.copy()
+            dwt.cdf97_3i_ip_sep_horizontal_s(dwt.volume_of(inv))
+        else:
+            d1, d2 = DevVol(dwt, v), DevVol(dwt, np.full(shp, -2.0, np.float32))
+            strides = (shp[1] * shp[2] * 4, shp[2] * 4, 4)
+            dwt.cdf97_3f_op_sep_horizontal_s(dwt.volume_of(d1.ptr, shp, strides), dwt.volume_of(d2.ptr, shp, strides))
+            op = d2.get()
+            assert np.array_equal(bits(d1.get()), bits(v)), "source modified"
+            dwt.cdf97_3f_ip_sep_horizontal_s(dwt.volume_of(d1.ptr, shp, strides))
+            ip = d1.get()
+            dwt.cdf97_3i_ip_sep_horizontal_s(dwt.volume_of(d1.ptr, shp, strides))
+            inv = d1.get()
+            d1.free()
+            d2.free()
+    finally:
+        dwt.set_option("vol_fused", 1)
+    assert _sha(ip) == meta["sha256"]["fwd"], "in-place forward"
+    assert _sha(op) == meta["sha256"]["fwd_op"], "out-of-place forward"
+    assert _sha(inv) == meta["sha256"]["inv"], "inverse"
+    if meta["full"]:
+        assert np.array_equal(bits(ip), bits(z[meta["name"] + ".fwd"]))
+        assert np.array_equal(bits(inv), bits(z[meta["name"] + ".inv"]))
+
+
+def test_schedule_dispatcher(dwt):
+    """cdf97_3f_op_wrapper_s (src/volume-dwt.c:2787): approaches 0..9 are schedules of the one transform
+    (one kernel here, the separable schedules' bits); 10 / 11 / 12 lift x / y / z lines only -- x copies
+    first, y and z work in place on the destination -- pinned by the reference's outputs."""
+    import os
+
+    from conftest import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "cdf97_3d_wide.npz"))
+    v = z["vol_dirs.in"]
+    full = v.copy()
+    dwt.cdf97_3f_ip_sep_horizontal_s(dwt.volume_of(full))
+    src = v.copy()  # (volume_of keeps the address only: the array has to outlive the call)
+    for ap in range(10):
+        dst = np.zeros_like(v)
+        dwt.cdf97_3f_op_wrapper_s(dwt.volume_of(src), dwt.volume_of(dst), ap)
+        assert np.array_equal(bits(dst), bits(full)), ap
+    for ap, tag in ((10, "x"), (11, "y"), (12, "z")):
+        dst = v.copy() if ap != 10 else np.full(v.shape, -3.0, np.float32)
+        dwt.cdf97_3f_op_wrapper_s(dwt.volume_of(src), dwt.volume_of(dst), ap)
+        assert np.array_equal(bits(dst), bits(z["vol_dirs." + tag])), tag
+    # the three directions one after another are the transform
+    dst = np.zeros_like(v)
+    for ap in (10, 11, 12):
+        dwt.cdf97_3f_op_wrapper_s(dwt.volume_of(src), dwt.volume_of(dst), ap)
+    assert np.array_equal(bits(dst), bits(full))
+    assert np.array_equal(bits(src), bits(v))
+
+
+def test_volume_perftest_protocol(dwt, tmp_path):
+    """volume_perftest_fwd97op_s(256, ...) -- the reference's 3-D perf test (src/volume-dwt.c:2810) --
+    returns 0 errors through ctypes and from a C program written against include/volume-dwt.h."""
+    import os
+    import subprocess
+
+    err, secs = dwt.volume_perftest_fwd97op_s(256, 1, 0, 2)
+    assert err == 0 and 0 < secs < 1e-6
+    err, secs_dev = dwt.volume_perftest_fwd97op_s(256, 0, 0, 3, device=True)
+    assert err == 0 and 0 < secs_dev < secs
+    err, _ = dwt.volume_perftest_fwd97op_s(40, 2, 7, 1)  # VOL_HORIZ_VERT4X4X4
+    assert err == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "volume_perftest"
+    libdir = os.path.join(root, "libdwt_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "volume_perftest.c"), "-o", str(exe),
+                           "-L", libdir, "-l:libdwt_hip.so", "-Wl,-rpath," + libdir, "-lm"])
+    out = subprocess.run([str(exe), "256"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "volume perftest: success (0 errors)" in out.stderr
+    assert "host volumes" in out.stderr and "device volumes" in out.stderr

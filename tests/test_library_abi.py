@@ -29,13 +29,23 @@ def declared_functions(header):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     text = re.sub(r"enum\s+\w+\s*\{.*?\};", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:dwt_|fdwt)\w+)\s*\(", text)))
+    # static inline helpers of volume.h are not exports
+    text = re.sub(r"static\s+inline[^{;]*\{.*?\n\}", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:dwt_|fdwt|volume_|cdf97_3)\w+)\s*\(", text)))
 
 
-@pytest.mark.parametrize("header", ["libdwt.h", "libdwt_hip.h", "dwt-simple.h"])
+@pytest.mark.parametrize("header", ["libdwt.h", "libdwt_hip.h", "dwt-simple.h", "volume.h", "volume-dwt.h"])
 def test_exports_every_declared_symbol(dwt, header):
     names = declared_functions(header)
-    assert len(names) > (15 if header != "dwt-simple.h" else 5)
+    assert len(names) > {"dwt-simple.h": 5, "volume.h": 8, "volume-dwt.h": 15}.get(header, 15)
+    if header == "volume-dwt.h":  # what the reference's 3-D perf test and its callers bind (src/volume-dwt.h:21,38,208,227,234)
+        for n in ("cdf97_3f_ip_sep_horizontal_s", "cdf97_3f_op_sep_horizontal_s", "cdf97_3i_ip_sep_horizontal_s",
+                  "cdf97_3f_op_wrapper_s", "volume_perftest_fwd97op_s", "volume_measure_fwd97op_s"):
+            assert n in names
+    if header == "volume.h":
+        for n in ("volume_alloc_realiably", "volume_alloc_realiably_locked", "volume_free", "volume_fill_s", "volume_copy_s",
+                  "volume_compare_s", "volume_save_to_pgm_s", "volume_invalidate_cache"):
+            assert n in names
     missing = [n for n in names if not hasattr(dwt.lib, n)]
     assert not missing, missing
 
@@ -64,7 +74,8 @@ def test_exports_every_function_the_opencv_wrapper_calls(dwt):
 
 def test_headers_compile_as_c99_and_cxx(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "libdwt.h"\n#include "libdwt_hip.h"\n#include "dwt-simple.h"\nint main(void){int j=-1;(void)j;return 0;}\n')
+    src.write_text('#include "libdwt.h"\n#include "libdwt_hip.h"\n#include "dwt-simple.h"\n#include "volume.h"\n#include "volume-dwt.h"\n'
+                   'int main(void){int j=-1;struct volume_t v;v.data=0;(void)j;(void)v;return 0;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", INCLUDE, "-c", str(src), "-o", str(tmp_path / "t.o")])
     subprocess.check_call(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-I", INCLUDE, "-c", str(src), "-o", str(tmp_path / "t2.o")])
 
@@ -279,3 +290,45 @@ def test_fill2_patterns_match_reference(dwt, reference):
         dwt.lib.dwt_util_test_image_fill2_i(a.ctypes.data, a.strides[0], 4, 53, 37, 1, t)
         reference.lib.dwt_util_test_image_fill2_i(b.ctypes.data, b.strides[0], 4, 53, 37, 1, t)
         assert np.array_equal(a, b), t
+
+
+def test_volume_header_layout_matches_the_reference(tmp_path):
+    """struct volume_t must have the reference's field layout (src/volume.h:14-24) -- callers fill it
+    by hand -- and enum volume_approach its values (src/volume-dwt.h:210-225)."""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "volume-dwt.h"\nint main(void){'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %d %d %d\\n", sizeof(struct volume_t), offsetof(struct volume_t,size_x),'
+                   'offsetof(struct volume_t,size_y), offsetof(struct volume_t,size_z), offsetof(struct volume_t,stride_x),'
+                   'offsetof(struct volume_t,stride_y), offsetof(struct volume_t,stride_z), offsetof(struct volume_t,data),'
+                   '(int)VOL_SEP_HORIZONTAL, (int)VOL_SEP_HORIZONTAL_Z, (int)VOL_LAST);return 0;}\n')
+    outs = []
+    incs = [INCLUDE] + (["/root/reference/src"] if os.path.exists("/root/reference/src/volume-dwt.h") else [])
+    for k, inc in enumerate(incs):
+        exe = tmp_path / f"layout{k}"
+        subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)])
+        outs.append(subprocess.check_output([str(exe)]).decode().split())
+    assert outs[0] == ["48", "0", "4", "8", "16", "24", "32", "40", "0", "12", "13"]
+    assert all(o == outs[0] for o in outs)
+
+
+def test_volume_housekeeping_on_host(dwt, tmp_path):
+    """volume_alloc_realiably / fill / copy / compare / save on host volumes need no GPU; the fill is the
+    reference's pattern (fixture generated by the reference's own volume_fill_s)."""
+    L = dwt.lib
+    v = L.volume_alloc_realiably(4, 21, 9, 13, 1)
+    assert v.contents.size_x == 21 and v.contents.stride_x == 4
+    assert v.contents.stride_y == L.dwt_util_get_stride(84, 1) and v.contents.stride_z == L.dwt_util_get_stride(v.contents.stride_y * 9, 1)
+    L.volume_fill_s(v)
+    raw = (C.c_uint8 * (v.contents.stride_z * 13)).from_address(v.contents.data)
+    # libdwt's "optimal" strides are odd byte counts: rows are not 4-byte aligned (numpy copes)
+    view = np.ndarray((13, 9, 21), np.float32, buffer=raw, strides=(v.contents.stride_z, v.contents.stride_y, 4))
+    want = np.load(os.path.join(ROOT, "tests", "golden", "cdf97_3d_wide.npz"))["vol_fill_13x9x21"]
+    assert np.array_equal(np.ascontiguousarray(view).view(np.uint32), want.view(np.uint32))
+    w = L.volume_alloc_realiably(4, 21, 9, 13, 0)  # dense strides: a copy across different strides
+    assert L.volume_copy_s(w, v) == 0 and L.volume_compare_s(v, w) == 0
+    C.cast(w.contents.data, C.POINTER(C.c_float))[5] += 0.5
+    assert L.volume_compare_s(v, w) != 0
+    L.volume_save_to_pgm_s(v, str(tmp_path / "s%02d.pgm").encode())
+    assert sorted(os.listdir(tmp_path)) == ["s%02d.pgm" % z for z in range(13)]
+    L.volume_free(v)
+    L.volume_free(w)

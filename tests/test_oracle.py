@@ -195,3 +195,87 @@ def test_oracle_multichannel_equals_reference_seeded(oracle, reference):
             oracle.call_channel(fi, a, ch, ja)
             reference.call_channel(fi, b, ch, jb)
             assert np.array_equal(bits(a), bits(b)), (wname, h, w, c, ch)
+
+
+def _vol_input(meta, z):
+    import hashlib
+
+    nz, ny, nx = meta["shape_zyx"]
+    if meta["full"]:
+        v = z[meta["name"] + ".in"]
+    elif meta["input"] == "rand":
+        v = np.random.default_rng(meta["seed"]).random((nz, ny, nx), dtype=np.float32)
+    else:
+        return None
+    assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == meta["sha256"]["in"], "input not reproduced"
+    return v
+
+
+def test_oracle_3d_matches_the_wide_fixtures(oracle):
+    """tests/golden/cdf97_3d_wide.npz: volumes the fused GPU kernels take, transformed by the reference
+    in place, out of place and back (oracle/gen_golden.py volumes).  The restatement must give the same
+    bits (arrays for the `full` cases, sha256 digests for the megabyte-sized ones)."""
+    import hashlib
+    import json
+
+    from conftest import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "cdf97_3d_wide.npz"))
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        cases = json.load(f)["files"]["cdf97_3d_wide.npz"]["cases"]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    done = 0
+    for m in cases:
+        assert m["op_equals_ip"]  # the reference's out-of-place entry writes the in-place entry's bits
+        v = _vol_input(m, z)
+        if v is None:
+            # pattern inputs come from volume_fill_s; the oracle has the 2-D pattern it is made of
+            nz, ny, nx = m["shape_zyx"]
+            v = np.zeros((nz, ny, nx), np.float32)
+            for k in range(nz):
+                rnd = k & 11
+                oracle.fill_s(v[k], 11 - rnd if rnd > 5 else rnd)
+            assert sha(v) == m["sha256"]["in"]
+        f = oracle.vol("cdf97_3f_s", v.copy())
+        assert sha(f) == m["sha256"]["fwd"] == m["sha256"]["fwd_op"], m["name"]
+        if m["full"]:
+            assert np.array_equal(bits(f), bits(z[m["name"] + ".fwd"])) and np.array_equal(bits(f), bits(z[m["name"] + ".fwd_op"]))
+        r = oracle.vol("cdf97_3i_s", f.copy())
+        assert sha(r) == m["sha256"]["inv"], m["name"]
+        done += 1
+    assert done >= 8
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_3d_equals_reference_seeded(oracle, reference, seed):
+    """Seeded sweep of the 3-D restatement against the reference itself (in-place forward, out-of-place
+    forward into a volume with other strides, in-place inverse), odd and even sizes from 5 (the
+    reference's minimum, src/dwt-simple.c:2172) up to volumes the fused GPU kernels take."""
+    import ctypes as C
+
+    class Vol(C.Structure):
+        _fields_ = [("size_x", C.c_int), ("size_y", C.c_int), ("size_z", C.c_int), ("stride_x", C.c_size_t),
+                    ("stride_y", C.c_size_t), ("stride_z", C.c_size_t), ("data", C.c_void_p)]
+
+    def vol(a):
+        return Vol(a.shape[2], a.shape[1], a.shape[0], a.strides[2], a.strides[1], a.strides[0], a.ctypes.data)
+
+    rng = np.random.default_rng(900 + seed)
+    shapes = [tuple(int(x) for x in rng.integers(5, 40, 3)) for _ in range(4)]
+    shapes += [(int(rng.integers(5, 24)), int(rng.integers(5, 70)), int(rng.integers(128, 530)))]
+    for shp in shapes:
+        v = rng.random(shp, dtype=np.float32)
+        want = oracle.vol("cdf97_3f_s", v.copy())
+        ip = v.copy()
+        reference.lib.cdf97_3f_ip_sep_horizontal_s(C.byref(vol(ip)))
+        assert np.array_equal(bits(ip), bits(want)), shp
+        # out of place into a padded destination
+        big = np.full((shp[0], shp[1] + 2, shp[2] + 3), -1.0, np.float32)
+        dst = big[:, :shp[1], :shp[2]]
+        src = v.copy()
+        reference.lib.cdf97_3f_op_sep_horizontal_s(C.byref(vol(src)), C.byref(vol(dst)))
+        assert np.array_equal(bits(np.ascontiguousarray(dst)), bits(want)), shp
+        assert np.array_equal(bits(src), bits(v))
+        assert np.all(big[:, shp[1]:, :] == -1.0) and np.all(big[:, :, shp[2]:] == -1.0)
+        reference.lib.cdf97_3i_ip_sep_horizontal_s(C.byref(vol(ip)))
+        assert np.array_equal(bits(ip), bits(oracle.vol("cdf97_3i_s", want.copy()))), shp

@@ -394,10 +394,12 @@ def _event_times(torch, fn, reps, warm):
 
 
 def single_image_stats(torch, dwt, src, dst, n, J):
-    """the libdwt.h entries on ONE device-resident image -- the out-of-place
-    dwt_cdf97_2f_s2 and the in-place dwt_cdf97_2f_s -- HIP-event min and median over 100 calls
-    after 20 warm-up calls, each call on a different image of the resident batch (so nothing
-    is served from the 256 MiB Infinity Cache), against the same algorithmic bytes."""
+    """the libdwt.h entries on ONE device-resident image -- forward out of place
+    (dwt_cdf97_2f_s2) and in place (dwt_cdf97_2f_s), inverse out of place (dwt_cdf97_2i_s2) and in
+    place (dwt_cdf97_2i_s) -- HIP-event min and median over 100 calls after 20 warm-up calls, each
+    call on a different image of the resident batch (so nothing is served from the 256 MiB Infinity
+    Cache), against the same algorithmic bytes.  (Timing is data independent: the in-place legs run
+    on whatever the previous leg left in the batch's output images.)"""
     nb = src.shape[0]
     alg = algorithmic_bytes(n, n, J)
     work = dst  # the batch's output images double as in-place work buffers
@@ -410,10 +412,20 @@ def single_image_stats(torch, dwt, src, dst, n, J):
         k = i % nb
         dwt.dwt_cdf97_2f_s(work[k], n * 4, 4, n, n, n, n, J)
 
+    def inv_s2(i):
+        k = i % nb
+        dwt.dwt_cdf97_2i_s2(dst[k], src[k], n * 4, 4, n, n, n, n, J)  # coefficients -> (the image again)
+
+    def inv_inplace(i):
+        k = i % nb
+        dwt.dwt_cdf97_2i_s(work[k], n * 4, 4, n, n, n, n, J)
+
     out = {"reps": 100, "warmup": 20, "algorithmic_bytes": alg}
-    for name, fn in (("s2", s2), ("inplace", inplace)):
+    for name, fn in (("s2", s2), ("inplace", inplace), ("inv_s2", inv_s2), ("inv_inplace", inv_inplace)):
         if name == "inplace":
             work.copy_(src)
+        if name == "inv_s2":  # coefficients of the whole batch back in dst
+            dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
         ms = _event_times(torch, fn, 100, 20)
         mn, med = min(ms), statistics.median(ms)
         out[f"{name}_us_min"] = round(mn * 1e3, 1)

@@ -93,9 +93,11 @@ void dwt_cdf53_2i_d(void *ptr, int stride_x, int stride_y,
 /* Interleaved (in-place lifting) layout: no de-interleave, level j works on the
  * stride-2^j lattice of the image.  src/libdwt.h:586, 889, 599, 944.  The 9/7 pair runs its
  * rows and columns in interleaved phases in the reference (src/libdwt.c:12970-13480,
- * 17517-17594); the fused sweeps finish rows before columns, which differs in fp32 rounding
- * only (<= 1e-5 relative, border bands); dwt_util_set_accel(1) follows the reference's phase
- * order and is bit-identical.  The 5/3 pair is bit-identical either way. */
+ * 17517-17594), which rounds differently from rows-then-columns in the top 8 rows and the last
+ * 5 columns of a level.  Bit-identical to the reference BY DEFAULT: the fused sweep's two border
+ * strips are recomputed in the reference's phase order (k_il_strip); dwt_util_set_accel(1) runs
+ * that order pass by pass over the whole image (the cross-check).  The 5/3 pair is bit-identical
+ * either way. */
 void dwt_cdf97_2f_inplace_s(void *ptr, int stride_x, int stride_y,
 	int size_o_big_x, int size_o_big_y, int size_i_big_x, int size_i_big_y,
 	int *j_max_ptr, int decompose_one, int zero_padding);

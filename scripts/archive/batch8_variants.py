@@ -2,7 +2,7 @@
 """Batch of 8 images of 8192^2 (the shard of one GPU in the 8-GPU split): option variants A/B in one
 process.  python scripts/batch8_variants.py "" "pipeline=2" ..."""
 import os, sys, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

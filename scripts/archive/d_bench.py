@@ -2,7 +2,7 @@
 """Double-precision entries (dwt_cdf97_2f_d / _2i_d, dwt_cdf53_2f_d), device resident, in place:
     python scripts/d_bench.py [n] [levels]"""
 import os, sys, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does an RCCL communicator in the process slow the transform kernels?  Run under torchrun."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch, torch.distributed as dist
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """Single 8192^2 5-level forward transform: direct launches against HIP graph replay
 (out of place and in place).  python scripts/graph_bench.py"""
 import os, sys, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

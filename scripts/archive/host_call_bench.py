@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-pointer (drop-in) call cost vs row pitch: dense, libdwt's prime 'optimal' stride."""
 import os, sys, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import libdwt_amd as dwt

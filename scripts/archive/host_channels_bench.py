@@ -2,7 +2,7 @@
 """Host-pointer call on ONE channel of an interleaved multi-channel image (the calling convention of
 the reference's OpenCV wrapper, src/cvdwt.cpp:98-135: stride_y = channels * sizeof(T))."""
 import os, sys, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import libdwt_amd as dwt

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workload for a kernel trace of the interleaved entries (8192^2 J=5, out of place): 10 forward, 10 inverse."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """Level-0 kernel time of the single-image inverse (and forward) for the float 9/7 and 5/3 wavelets:
 is the inverse bound by its arithmetic or by its memory pattern?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

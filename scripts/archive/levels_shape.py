@@ -2,7 +2,7 @@
 """Per-level kernel time and achieved bandwidth of the batched forward transform for a given shape:
     python scripts/levels_shape.py W H BATCH [LEVELS] ["opt=val,..."]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

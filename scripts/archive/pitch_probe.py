@@ -2,7 +2,7 @@
 """Does the row pitch (not the row length) set the bandwidth?  One forward level over a batch
 of n x n images stored with different row pitches: python scripts/pitch_probe.py [n] [images]"""
 import os, sys, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

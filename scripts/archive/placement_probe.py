@@ -3,7 +3,7 @@
 Several (src, dst) sets are allocated one after the other in one process (all kept alive) and the
 same 16-image forward transform is timed on each.  python scripts/placement_probe.py [sets] [images]"""
 import os, sys, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """2-D forward / inverse float 9/7 on image sizes that are not made of whole tiles, beside 8192^2.
 python scripts/ragged2d_bench.py"""
 import os, sys, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """Runs the 16-image forward transform for a few seconds and prints the rate per half second;
 meant to run beside a `rocm-smi` sampling loop (scripts/r02_clocks.sh)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -3,7 +3,7 @@
 scratch is released and re-allocated between timings, with dummy allocations of odd sizes in
 between so that it lands somewhere else each time.  python scripts/scratch_probe.py"""
 import os, sys, statistics, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

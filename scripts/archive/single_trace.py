@@ -3,7 +3,7 @@
 calls of dwt_cdf97_2f_s on rotating 8192^2 images.
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/trace_single -- python3 scripts/single_trace.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """Device-resident small images (BASELINE config 1: 512^2, full depth as examples/simple runs it):
 HIP-event time per call and the kernels of one call."""
 import os, sys, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """Does the rate depend on the stream (hardware queue) the launches go to?  Same 16-image forward
 transform timed on the default stream and on several new streams of one process."""
 import os, sys, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

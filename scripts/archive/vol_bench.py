@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """3-D path timing (config 5): python scripts/vol_bench.py [n] [levels]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """A/B the 3-D path's knobs in one process: python scripts/vol_sweep.py [n] [levels]
 Each line: option set, median ms of 7 calls (forward, in place)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -897,6 +897,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.wave_horiz = value;
 	else if (!strcmp(name, "ring"))
 		g.tune.ring = value;
+	else if (!strcmp(name, "nt_auto"))
+		g.tune.nt_auto = value;
 	else if (!strcmp(name, "nt"))
 		g.tune.nt = value;
 	else if (!strcmp(name, "nt_inv"))
@@ -952,6 +954,8 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.wave_horiz;
 	if (!strcmp(name, "ring"))
 		return g.tune.ring;
+	if (!strcmp(name, "nt_auto"))
+		return g.tune.nt_auto;
 	if (!strcmp(name, "nt"))
 		return g.tune.nt;
 	if (!strcmp(name, "nt_inv"))

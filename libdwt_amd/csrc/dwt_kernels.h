@@ -23,6 +23,7 @@ struct SweepTuning {
 	int ring = 0;        // LDS ring rows per wave (8 or 16); 0 = auto
 	int nt = 7;          // forward: bit 0 non-temporal stores, bit 1 non-temporal LDS-DMA loads,
 	                     // bit 2 keep the LL band's stores temporal (the next level reads it)
+	int nt_auto = 1;     // forward: drop bit 2 of `nt` when the launch's LL bands exceed the Infinity Cache
 	int nt_inv = 1;      // inverse sweep: non-temporal stores only (measured best)
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
 	int wave_horiz_inv = 0;

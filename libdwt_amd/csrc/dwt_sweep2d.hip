@@ -828,6 +828,14 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 			return hipErrorInvalidValue;
 		}
 	}
+	// Cache policy bit 2 keeps the LL band's stores temporal so that the next level finds it in the
+	// 256 MiB Infinity Cache.  The LL bands of a large batch do not fit (64 images of 8192^2: 4.3 GB):
+	// temporal stores then only displace other lines -- non-temporal like the detail bands (64 images,
+	// one process, alternated: level 0 5863-5882 -> 5959-5964 GB/s, level 1 5323-5341 -> 5381-5409, step
+	// 8.08-8.10 -> 8.00-8.02 ms).  At 0.5 GB of LL (8 images) the two policies tie (level 0 loses what
+	// level 1 gains), below that temporal wins: switch from 1 GiB on.  Option nt_auto = 0 turns it off.
+	if (tt.nt_auto && (tt.nt & 15) == 7 && (size_t)a.batch * ((a.W + 1) / 2) * ((a.H + 1) / 2) * sizeof(typename W::T) >= ((size_t)1 << 30))
+		tt.nt = 3;
 	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, tt, s) : fwd_pick<W, 4>(a, g, grid, waves, tt, s);
 }
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_shell_cols(const float *__restrict__ in
 		return;
 	const int col = 256 * (k / 2 + 1) - 4 + 4 * (k & 1);
 	const float *row = in + (long)z * in_sz + (long)y * in_sy;
-	u4 v = load16_row<false>(row_rsrc(row, (unsigned)nx * 4), (unsigned)col * 4);
+	u4 v = load16_row<true>(row_rsrc(row, (unsigned)nx * 4), (unsigned)col * 4);
 	// (a piece that straddles the row's end: its missing columns are never read -- reflection
 	// brings them from the tile's own side)
 	store16_row<false>(row_rsrc(sh.cs + (long)z * sh.cs_sz + (long)y * sh.cs_sy, (unsigned)npc * 16), (unsigned)k * 16, v);

@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void k_shell_rows(const float *__restrict__ in
 	const unsigned x = (blockIdx.x * 256 + threadIdx.x) * 16;
 	const row_rsrc_t s = row_rsrc(in + (long)z * in_sz + (long)r * in_sy, (unsigned)nx * 4);
 	const row_rsrc_t d = row_rsrc(sh.rs + (long)z * sh.rs_sz + (long)k * sh.rs_sy, (unsigned)nx * 4);
-	store16_row<false>(d, x, load16_row<false>(s, x));
+	// read once here (its owner reads the volume's row again much later), written for one reader: both
+	// non-temporal (1024^3: 330 -> 285 us)
+	store16_row<true>(d, x, load16_row<true>(s, x));
 }
 
 // columns: boundary b (between the tile columns b and b+1) holds the columns 256 (b+1) - 4 .. + 3

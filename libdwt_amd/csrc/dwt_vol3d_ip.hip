@@ -170,12 +170,23 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 				char *lrow = ring + (size_t)i * RS * 4;
 				// lane i's 16 B land at lrow + 16 i; beyond the row's end the bounds check fills zeros, and
 				// the four reflected columns next to the edge -- all a valid output can reach -- come one by one
-				dma16_row<kLdAux>(row_rsrc(grow, (unsigned)a.nx * 4), (unsigned)c * 4, lrow);
 				const float *cp = shell_cols && colsh >= 0 ? crow + colsh : grow + colrow;
-				if (lane >= 8 && lane < 16)
-					dma4<kLdAux>(cp, lrow + TW * 4 - 32); // lane 8's dword lands behind the row's 256 columns
-				if (lane < over)
-					dma4<kLdAux>(cp, lrow + (a.nx - c0) * 4);
+				if (shell_cols) {
+					// the volume's row: read by this tile only
+					dma16_row<kLdAux>(row_rsrc(grow, (unsigned)a.nx * 4), (unsigned)c * 4, lrow);
+					if (lane >= 8 && lane < 16)
+						dma4<kLdAux>(cp, lrow + TW * 4 - 32); // lane 8's dword lands behind the row's 256 columns
+					if (lane < over)
+						dma4<kLdAux>(cp, lrow + (a.nx - c0) * 4);
+				} else {
+					// a shell row: the x-neighbour tiles read the lines next to this tile's 1 KiB at about the same
+					// time and this tile needs 16 bytes of each -- cacheable, so that the second one hits in L2
+					dma16_row<0>(row_rsrc(grow, (unsigned)a.nx * 4), (unsigned)c * 4, lrow);
+					if (lane >= 8 && lane < 16)
+						dma4<0>(cp, lrow + TW * 4 - 32);
+					if (lane < over)
+						dma4<0>(cp, lrow + (a.nx - c0) * 4);
+				}
 			}
 		}
 	};

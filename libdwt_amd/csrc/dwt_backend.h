@@ -57,7 +57,7 @@ struct Ctx {
 	// side stream: the copy-back of an in-place level 0 (and the copy-aside of an in-place
 	// final inverse level) overlaps the small levels instead of preceding/following them
 	hipStream_t side = nullptr;
-	hipEvent_t side_a = nullptr, side_b = nullptr;
+	hipEvent_t side_a = nullptr, side_b = nullptr, side_c = nullptr;
 	bool side_pending = false;
 	int pipeline = 0; // 0: one launch per level for the whole batch; n>=2: n lanes
 	// options
@@ -66,6 +66,7 @@ struct Ctx {
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
 	int inplace_overlap = 0; // 1: the copy-back (forward) / copy-aside (inverse) of an in-place call on a side stream beside the deeper levels (measured 8-10 us slower than in line)
+	int il_lazy_strips = 1; // interleaved 9/7 forward: the exact border strips on the side stream beside the next level's sweep (0: in line)
 	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
 	// profiling
 	int prof_on = 0;

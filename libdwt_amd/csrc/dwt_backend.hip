@@ -319,6 +319,7 @@ int side_fork()
 		HIP_TRY(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
 		HIP_TRY(hipEventCreateWithFlags(&g.side_a, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&g.side_b, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&g.side_c, hipEventDisableTiming));
 	}
 	HIP_TRY(hipEventRecord(g.side_a, g.stream));
 	HIP_TRY(hipStreamWaitEvent(g.side, g.side_a, 0));
@@ -899,6 +900,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.ring = value;
 	else if (!strcmp(name, "nt_auto"))
 		g.tune.nt_auto = value;
+	else if (!strcmp(name, "il_lazy_strips"))
+		g.il_lazy_strips = value;
 	else if (!strcmp(name, "nt"))
 		g.tune.nt = value;
 	else if (!strcmp(name, "nt_inv"))
@@ -956,6 +959,8 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.ring;
 	if (!strcmp(name, "nt_auto"))
 		return g.tune.nt_auto;
+	if (!strcmp(name, "il_lazy_strips"))
+		return g.il_lazy_strips;
 	if (!strcmp(name, "nt"))
 		return g.tune.nt;
 	if (!strcmp(name, "nt_inv"))

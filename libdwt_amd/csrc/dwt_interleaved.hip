@@ -165,7 +165,11 @@ template <class W, bool INV>
 __global__ __launch_bounds__(512) void k_il_strip(IlStripArgs a)
 {
 	using T = typename W::T;
-	constexpr int kKeep = 104, kMargin = 12, kBand = 24, kKeepTop = 8, kKeepRight = 6, kLong = kKeep + 2 * kMargin;
+	// kept across the strip: 8 rows from the top / the last 8 columns.  The reference's order differs from
+	// the sweep's in the last 5 (6 with the parity) columns only; 8 makes the kept region closed under
+	// "what a forward level computes from the uncorrected low-pass samples of the level above" (the
+	// lazy strips of il_level); the band's artificial edge, 23-24 samples from the border, reaches 4.
+	constexpr int kKeep = 104, kMargin = 12, kBand = 24, kKeepTop = 8, kKeepRight = 8, kLong = kKeep + 2 * kMargin;
 	constexpr int kOwn = 8, kHalo = 4, kPiece = kOwn + 2 * kHalo;
 	__shared__ T buf[2][kBand * kLong];
 	// blocks [0, n_top): tiles of the top strip; the rest: tiles of the right strip
@@ -315,10 +319,10 @@ static __device__ __forceinline__ int il_level_of(int p, int q, int J)
 }
 
 __global__ __launch_bounds__(256) void k_il_compose(const float *__restrict__ base, long base_pitch, float *__restrict__ out,
-	long out_pitch, int W, int H, IlPyramid py, int vec_ok, int out_dense)
+	long out_pitch, int W, int H, IlPyramid py, int vec_ok, int out_dense, int x_begin)
 {
-	// grid.x = even rows (may exceed 65535), grid.y = blocks of 2048 columns
-	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
+	// grid.x = even rows (may exceed 65535), grid.y = blocks of 2048 columns from x_begin (a multiple of 8)
+	const int x0 = x_begin + (blockIdx.y * blockDim.x + threadIdx.x) * 8;
 	const int q = blockIdx.x, y = 2 * q;
 	if (x0 >= W || y >= H)
 		return;
@@ -405,12 +409,12 @@ static int il_vec_ok(const float *a, long ap, const float *b, long bp, const IlP
 }
 
 hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H, const IlPyramid &py, hipStream_t s,
-	bool out_dense)
+	bool out_dense, int x_begin)
 {
-	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
+	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || x_begin < 0 || x_begin >= W || (x_begin & 7) || ((W + 7) / 8 + 255) / 256 > 65535)
 		return hipErrorInvalidValue;
-	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
-	k_il_compose<<<grid, 256, 0, s>>>(base, base_pitch, out, out_pitch, W, H, py, il_vec_ok(base, base_pitch, out, out_pitch, py), out_dense);
+	dim3 grid((H + 1) / 2, ((W - x_begin + 7) / 8 + 255) / 256);
+	k_il_compose<<<grid, 256, 0, s>>>(base, base_pitch, out, out_pitch, W, H, py, il_vec_ok(base, base_pitch, out, out_pitch, py), out_dense, x_begin);
 	return hipGetLastError();
 }
 

@@ -194,7 +194,7 @@ struct IlPyramid {
 // the sample of the deepest level (< J) that owns it.  base may equal out.  out_dense: `out`
 // holds only the even rows, packed (row q of `out` = image row 2q).
 hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H,
-	const IlPyramid &py, hipStream_t s, bool out_dense = false);
+	const IlPyramid &py, hipStream_t s, bool out_dense = false, int x_begin = 0);
 // decompose: every level's lattice gathered from `img` into its dense image, one pass
 hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s);
 

@@ -438,11 +438,14 @@ bool vol_level_ip_can(const VolFusedArgs &a)
 
 bool vol_level_ip_applies(const VolFusedArgs &a)
 {
-	// as vol_fused_applies: about one workgroup per CU at 32 slice pairs per march, tiles mostly used
+	// about one workgroup per CU at 32 slice pairs per march, tiles mostly used.  Measured (one level,
+	// forward / inverse, ms; scripts/r03_vol_ip_sizes.py): 448^3 one pass 0.33 / 0.36 against two passes
+	// 0.28 / 0.29 (which run partly out of the Infinity Cache); 512^3 0.38 / 0.41 against 0.41 / 0.42;
+	// 640^3 0.80 / 0.87 against 0.90 / 0.86; 768^3 1.05 / 1.13 against 1.50 / 1.46
 	if (!vol_level_ip_can(a) || a.nx < 128)
 		return false;
 	const long tiles = (long)((a.nx + 255) / 256) * ((a.ny + 31) / 32);
-	return tiles * (((a.nz + 1) / 2 + 31) / 32) >= 192;
+	return tiles * (((a.nz + 1) / 2 + 31) / 32) >= 256;
 }
 
 size_t vol_level_ip_scratch(const VolFusedArgs &a, const VolTuning &vt)

@@ -315,6 +315,18 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 			if (lattice(j, true))
 				return 1;
 		for (int j = levels - 1; j >= 0; j--) {
+			if (j >= 1 && g.vol.direct && ip_level(L[j].p, L[j].sy, L[j].sz, L[j].lx, L[j].ly, L[j].lz)) {
+				// a level >= 1 in ONE pass, out of place: from its dense copy straight into the lattice of the
+				// level above (no shell: the source stays intact; no dense result, no scatter pass)
+				const Lvl &c = L[j], &par = L[j - 1];
+				VolFusedArgs fa{c.p, c.sy, c.sz, par.p, par.sy * 2, par.sz * 2, nullptr, 0, 0, c.lx, c.ly, c.lz};
+				fa.mode = 1;
+				fa.out_sx = 2;
+				hipError_t e = launch_vol_inv_fused(fa, g.vol, g.stream);
+				if (e != hipSuccess)
+					return fail("fused 3-D inverse level launch failed: %s", hipGetErrorString(e));
+				continue;
+			}
 			if (one_level(L[j], nullptr))
 				return 1;
 			if (j >= 1 && lattice(j, false))

@@ -140,6 +140,9 @@ bool vol_level_ip_can(const VolFusedArgs &a);     // the kernel can run (any siz
 bool vol_level_ip_applies(const VolFusedArgs &a); // ... and pays
 size_t vol_level_ip_scratch(const VolFusedArgs &a, const VolTuning &vt);
 hipError_t launch_vol_level_ip(bool inverse, const VolFusedArgs &a, float *scratch, const VolTuning &vt, hipStream_t s);
+// the same kernel OUT OF PLACE, inverse (in != out, dense source, no shell): mode 0 dense result, mode 1
+// result into the stride-out_sx lattice of `out` (a level >= 1 of a multi-level inverse)
+hipError_t launch_vol_inv_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s);
 
 // Strided 3-D copy (lattice pack/unpack for the levels >= 1 of the 3-D path);
 // strides in ELEMENTS, including the x strides.

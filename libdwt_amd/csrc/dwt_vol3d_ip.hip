@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 	constexpr int HL = INV ? K - 1 : K; // halo rows above the tile
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
 	constexpr bool kNtStore = (NT & 1) != 0;
-	static_assert(MODE == 4 || (MODE == 2 && !INV), "store variants");
+	static_assert(MODE == 4 || (MODE == 2 && !INV) || (MODE == 1 && INV), "store variants");
+	// no row shell: an OUT-OF-PLACE call (a.in != a.out) -- the source stays intact, every row, column and
+	// slice a tile reads comes from it (inverse levels >= 1 of a multi-level call: dense source, result
+	// into the lattice of the level above, MODE 1)
+	const bool ip = sh.rs != nullptr;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 		// that set are reached only by reflections that feed no valid output.)
 		const int u = r + HL, b = (u >> 5) - 1, o = u & 31;
 		const bool inrs = !own && o < 7 && b >= 0 && b < nty - 1;
-		rowinfo = r | (own ? 1 << 16 : 0) | (inrs ? (1 << 17) | ((7 * b + o) << 18) : 0);
+		rowinfo = r | (ip && own ? 1 << 16 : 0) | (ip && inrs ? (1 << 17) | ((7 * b + o) << 18) : 0);
 	}
 	// Likewise the single columns a row needs beside its 16-byte pieces: lanes 8..15 fetch the tile's
 	// halo columns (c0-4 .. c0-1, c0+256 .. c0+259), lanes 0..3 the reflected columns right of the
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 		// volume's first slice -- unwritten so far: the tile's own part comes from the volume, the rest
 		// from the row and column shells.  Anything else was (or is being) overwritten by another march
 		// and comes from the slice shell as a whole.
-		const bool live = v < own_end && (v >= 2 * A || tz == 0);
-		const int s = v < 0 ? -v : v;
+		const bool live = !ip || (v < own_end && (v >= 2 * A || tz == 0));
+		const int s = ip ? (v < 0 ? -v : v) : reflect(v, a.nz);
 		int slot = 0;
 		if (!live)
 			slot = v >= a.nz ? 9 * (sh.nzt - 1) + (a.nz + 4 - v) : v < 2 * A ? 9 * (tz - 1) + (v - (2 * A - 5)) : 9 * tz + (v - (2 * B - 5));
@@ -371,10 +375,26 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 					store8_row<false>(row_rsrc(a.lll + (long)k * a.lll_sz + (long)(y >> 1) * a.lll_sy, (unsigned)((a.nx + 1) >> 1) * 4), cb / 2, u2{to_bits(o0[0]), to_bits(o0[2])});
 			} else {
 				const int q = q0 + it, po = q - 2, pe = q - 1;
-				if (po >= A && po < B && 2 * po + 1 < a.nz)
-					store16_row<kNtStore>(row_rsrc(a.out + (long)(2 * po + 1) * a.out_sz + (long)y * a.out_sy, nb), cb, p0);
-				if (pe >= A && pe < B)
-					store16_row<kNtStore>(row_rsrc(a.out + (long)(2 * pe) * a.out_sz + (long)y * a.out_sy, nb), cb, p1);
+				const bool st_o = po >= A && po < B && 2 * po + 1 < a.nz, st_e = pe >= A && pe < B;
+				float *row_o = a.out + (long)(2 * po + 1) * a.out_sz + (long)y * a.out_sy, *row_e = a.out + (long)(2 * pe) * a.out_sz + (long)y * a.out_sy;
+				if constexpr (MODE == 1) {
+					// into the lattice of the level above: sample x of this level at x * out_sx of the row, one
+					// dword store per sample, the row's last lattice sample bounds the buffer
+					const unsigned nbl = ((unsigned)(a.nx - 1) * (unsigned)a.out_sx + 1) * 4, sx4 = (unsigned)a.out_sx * 4;
+					const row_rsrc_t d_o = row_rsrc(row_o, nbl), d_e = row_rsrc(row_e, nbl);
+#pragma unroll
+					for (int e = 0; e < CPT; e++) {
+						if (st_o)
+							__builtin_amdgcn_raw_buffer_store_b32(to_bits(o0[e]), d_o, (unsigned)c * sx4, e * sx4, 0);
+						if (st_e)
+							__builtin_amdgcn_raw_buffer_store_b32(to_bits(o1[e]), d_e, (unsigned)c * sx4, e * sx4, 0);
+					}
+				} else {
+					if (st_o)
+						store16_row<kNtStore>(row_rsrc(row_o, nb), cb, p0);
+					if (st_e)
+						store16_row<kNtStore>(row_rsrc(row_e, nb), cb, p1);
+				}
 			}
 		}
 	}
@@ -497,6 +517,26 @@ hipError_t launch_vol_level_ip(bool inverse, const VolFusedArgs &a, float *scrat
 		DWT_IP_GO(false, 2);
 	DWT_IP_GO(false, 4);
 #undef DWT_IP_GO
+}
+
+// One INVERSE level in one pass, OUT OF PLACE: the dense source `a.in` stays intact (no shell needed);
+// a.mode 0: dense result; 1: result into the stride-out_sx lattice of `a.out` (out_sy / out_sz the
+// destination's strides times out_sx) -- a level >= 1 of a multi-level inverse writing straight into
+// the level above instead of a dense result plus a scatter pass.
+hipError_t launch_vol_inv_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s)
+{
+	if (!vol_level_ip_can(a) || a.in == a.out || (a.mode != 0 && a.mode != 1) || (a.mode == 0 && a.out_sx != 1))
+		return hipErrorInvalidValue;
+	VolShell sh{};
+	sh.tile_pairs_z = vol_ip_march(a, vt);
+	sh.nzt = ((a.nz + 1) / 2 + sh.tile_pairs_z - 1) / sh.tile_pairs_z;
+	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
+	if ((long)ntx * nty * sh.nzt > 0x7fffffffL)
+		return hipErrorInvalidValue;
+	// cacheable loads (neighbouring tiles share their halo lines), non-temporal stores
+	if (a.mode == 1)
+		return vol_ip_go<true, 1, 1>(a, sh, ntx, nty, vt.swizzle, s);
+	return vol_ip_go<true, 4, 1>(a, sh, ntx, nty, vt.swizzle, s);
 }
 
 } // namespace dwt

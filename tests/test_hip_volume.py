@@ -432,3 +432,44 @@ def test_volume_perftest_protocol(dwt, tmp_path):
     assert out.returncode == 0, out.stderr
     assert "volume perftest: success (0 errors)" in out.stderr
     assert "host volumes" in out.stderr and "device volumes" in out.stderr
+
+
+def test_one_pass_levels_randomised(dwt, oracle):
+    """Seeded soak of the one-pass 3-D levels (vol_fused = 2 forces them wherever they can run): random
+    sizes from 2 x 2 x 8 up (tiles overhanging by any amount, one or several tile rows / columns),
+    1-3 levels, marches of 4 .. 20 slice pairs; in place forward and inverse (k_vol_level_ip over its
+    shell, levels >= 1 of the inverse out of place into the lattice above) and out of place forward
+    (k_vol_fwd_fused): the oracle's bits every time."""
+    rng = np.random.default_rng(20261004)
+    dwt.set_option("vol_fused", 2)
+    done = 0
+    try:
+        for case in range(140):
+            nz = int(rng.integers(8, 72))
+            ny = int(rng.choice([2, 3, 31, 32, 33, 64, 65, 100])) if rng.random() < 0.5 else int(rng.integers(2, 140))
+            nx = int(rng.choice([2, 5, 255, 256, 257, 260, 511, 512, 513, 520])) if rng.random() < 0.5 else int(rng.integers(2, 600))
+            levels = int(rng.integers(1, 4))
+            while levels > 1 and min(-(-n // (1 << (levels - 1))) for n in (nx, ny, nz)) < 2:
+                levels -= 1
+            tp = int(rng.choice([0, 4, 5, 8, 13, 20]))
+            dwt.set_option("vol_tile_pairs", tp)
+            vol = rng.random((nz, ny, nx), dtype=np.float32)
+            want = oracle_multilevel(oracle, vol.copy(), levels, False)
+            what = f"case {case}: {nz}x{ny}x{nx} levels {levels} march {tp}"
+            d = DevVol(dwt, vol)
+            d.run(0, levels)
+            assert np.array_equal(bits(d.get()), bits(want)), what + " (in place, forward)"
+            d.run(1, levels)
+            assert np.array_equal(bits(d.get()), bits(oracle_multilevel(oracle, want.copy(), levels, True))), what + " (in place, inverse)"
+            if case % 3 == 0:
+                s, o = DevVol(dwt, vol), DevVol(dwt, np.zeros_like(vol))
+                dwt.transform3d_op(s.ptr, o.ptr, nx * 4, nx * ny * 4, nx, ny, nz, levels)
+                assert np.array_equal(bits(o.get()), bits(want)), what + " (out of place)"
+                s.free()
+                o.free()
+            d.free()
+            done += 1
+    finally:
+        dwt.set_option("vol_fused", 1)
+        dwt.set_option("vol_tile_pairs", 0)
+    assert done == 140

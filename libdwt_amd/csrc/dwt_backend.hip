@@ -902,6 +902,10 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.nt_auto = value;
 	else if (!strcmp(name, "il_lazy_strips"))
 		g.il_lazy_strips = value;
+	else if (!strcmp(name, "vol_ip_waves"))
+		g.vol.ip_waves = value;
+	else if (!strcmp(name, "vol_fwd_tall"))
+		g.vol.fwd_tall = value;
 	else if (!strcmp(name, "nt"))
 		g.tune.nt = value;
 	else if (!strcmp(name, "nt_inv"))
@@ -961,6 +965,10 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.nt_auto;
 	if (!strcmp(name, "il_lazy_strips"))
 		return g.il_lazy_strips;
+	if (!strcmp(name, "vol_ip_waves"))
+		return g.vol.ip_waves;
+	if (!strcmp(name, "vol_fwd_tall"))
+		return g.vol.fwd_tall;
 	if (!strcmp(name, "nt"))
 		return g.tune.nt;
 	if (!strcmp(name, "nt_inv"))

@@ -84,6 +84,9 @@ static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long
 				if (grow(&g.vol_out, &g.vol_out_bytes, vol_level_ip_scratch(fa, g.vol)))
 					return 1;
 				e = launch_vol_level_ip(false, fa, (float *)g.vol_out, g.vol, g.stream);
+			} else if (g.vol.fwd_tall && (fa.mode == 0 || fa.mode == 2) && g.vol.whole && g.vol.rows != 6 && vol_level_ip_can(fa)) {
+				// dense / withholding levels: the 64-row tiles of dwt_vol3d_ip.hip's kernel, out of place
+				e = launch_vol_level_op(false, fa, g.vol, g.stream);
 			} else {
 				e = launch_vol_fwd_fused(fa, g.vol, g.stream);
 			}
@@ -322,7 +325,7 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 				VolFusedArgs fa{c.p, c.sy, c.sz, par.p, par.sy * 2, par.sz * 2, nullptr, 0, 0, c.lx, c.ly, c.lz};
 				fa.mode = 1;
 				fa.out_sx = 2;
-				hipError_t e = launch_vol_inv_fused(fa, g.vol, g.stream);
+				hipError_t e = launch_vol_level_op(true, fa, g.vol, g.stream);
 				if (e != hipSuccess)
 					return fail("fused 3-D inverse level launch failed: %s", hipGetErrorString(e));
 				continue;

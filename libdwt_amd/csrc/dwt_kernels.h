@@ -90,6 +90,8 @@ struct VolTuning {
 	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes
 	int swizzle = 1;    // fused level: hand contiguous runs of tiles to one XCD
 	int rows = 8;       // fused level: output rows per wave, 8 (measured best) or 6 (two workgroups per CU)
+	int ip_waves = 0;   // k_vol_level_ip: waves per workgroup, 4 (tiles of 32 rows, two workgroups per CU) or 8 (64 rows, one); 0 = 8 where the volume has more than 32 rows
+	int fwd_tall = 1;   // out-of-place forward levels 0 (dense / withholding) through k_vol_level_ip's 64-row tiles instead of k_vol_fwd_fused
 };
 
 // z pass of the 3-D path: CDF 9/7 float along the slice axis of an interleaved volume,
@@ -140,9 +142,10 @@ bool vol_level_ip_can(const VolFusedArgs &a);     // the kernel can run (any siz
 bool vol_level_ip_applies(const VolFusedArgs &a); // ... and pays
 size_t vol_level_ip_scratch(const VolFusedArgs &a, const VolTuning &vt);
 hipError_t launch_vol_level_ip(bool inverse, const VolFusedArgs &a, float *scratch, const VolTuning &vt, hipStream_t s);
-// the same kernel OUT OF PLACE, inverse (in != out, dense source, no shell): mode 0 dense result, mode 1
-// result into the stride-out_sx lattice of `out` (a level >= 1 of a multi-level inverse)
-hipError_t launch_vol_inv_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s);
+// the same kernel OUT OF PLACE (in != out, dense source, no shell).  Forward: mode 0 / 2 and `lll` as for
+// launch_vol_fwd_fused (tiles of 64 rows where the volume has them).  Inverse: mode 0 dense result, mode 1
+// result into the stride-out_sx lattice of `out` (a level >= 1 of a multi-level inverse).
+hipError_t launch_vol_level_op(bool inverse, const VolFusedArgs &a, const VolTuning &vt, hipStream_t s);
 
 // Strided 3-D copy (lattice pack/unpack for the levels >= 1 of the 3-D path);
 // strides in ELEMENTS, including the x strides.

@@ -25,10 +25,10 @@ namespace dwt {
 // ---------------------------------------------------------------------------------
 // rows: boundary b (between the tile rows b and b+1) holds the rows 32 (b+1) - HL .. + 6, HL = rows
 // a tile reads above itself (4 forward, 3 inverse)
-__global__ __launch_bounds__(256) void k_shell_rows(const float *__restrict__ in, long in_sy, long in_sz, VolShell sh, int nx, int ny, int hl)
+__global__ __launch_bounds__(256) void k_shell_rows(const float *__restrict__ in, long in_sy, long in_sz, VolShell sh, int nx, int ny, int hl, int ty_rows)
 {
 	const int k = blockIdx.y, b = k / 7, o = k % 7, z = blockIdx.z;
-	const int r = 32 * (b + 1) - hl + o;
+	const int r = ty_rows * (b + 1) - hl + o;
 	if (r >= ny)
 		return;
 	const unsigned x = (blockIdx.x * 256 + threadIdx.x) * 16;
@@ -83,11 +83,14 @@ __global__ __launch_bounds__(256) void k_shell_slices(const float *__restrict__ 
 // MODE 4: every row of the level stored densely; MODE 2 (forward, level 0 of a multi-level call): the
 // rows with even y in the even slices are withheld -- level 1 writes them whole -- and their odd-x
 // samples parked in `side` (see k_vol_fwd_fused).
-template <bool INV, int MODE, int NT>
-__global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShell sh, int ntx, int nty, int swz)
+// NW: waves per workgroup = 4 (tile of 32 rows, two workgroups per CU) or 8 (tile of 64 rows, ONE
+// workgroup of 512 threads per CU: half the halo rows -- 7 per 64 -- at the price of one barrier domain).
+template <bool INV, int MODE, int NT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_vol_level_ip(VolFusedArgs a, VolShell sh, int ntx, int nty, int swz)
 {
 	using W = Cdf97S;
-	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, RW = 8, TY = 4 * RW, NR = TY + 2 * K - 1, RPW = (NR + 3) / 4;
+	constexpr int K = 4, CPT = 4, TW = 256, RS = TW + 8, RW = 8, TY = NW * RW, NR = TY + 2 * K - 1, RPW = 10; // 39 = 10+10+10+9 rows, 71 = 7 x 9 + 8 (one slot idle)
+	static_assert((NR + NW - 1) / NW <= RPW, "rows per wave");
 	constexpr int NV = RW + 2 * K - 1; // slab rows a wave's vertical lift reads
 	constexpr int HL = INV ? K - 1 : K; // halo rows above the tile
 	constexpr int kLdAux = (NT & 2) ? 2 : 0;
@@ -114,19 +117,21 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 	const int own_end = min(2 * B, a.nz);
 
 	char *ring = smem + (size_t)wv * RPW * RS * 4;
-	char *slab = smem + (size_t)NR * RS * 4;
+	// (4 waves: the last wave's idle tenth slot overlaps the slab's first row, so that two workgroups fit a CU)
+	constexpr int kRingRows = NW == 4 ? NR : NW * RPW;
+	char *slab = smem + (size_t)kRingRows * RS * 4;
 	const unsigned ring_off = lds_offset(ring), slab_off = lds_offset(slab);
 
 	// Where a staged row comes from does not change along the march: lane i of the wave keeps the
-	// facts of the wave's i-th row (tile row wv + 4 i) and the loop fetches them with v_readlane --
+	// facts of the wave's i-th row (tile row wv + NW i) and the loop fetches them with v_readlane --
 	// bits 0..15 the (reflected) row, 16 "this tile's own row", 17 "in the row shell", 18.. its row there.
 	int rowinfo;
 	{
-		const int r = reflect(y0 - HL + min(wv + 4 * lane, NR - 1), a.ny);
+		const int r = reflect(y0 - HL + min(wv + NW * lane, NR - 1), a.ny);
 		const bool own = r >= y0 && r < y0 + TY;
-		// a neighbour's row: boundary b = (r + HL) / 32 - 1, offset (r + HL) % 32 < 7.  (Rows outside
+		// a neighbour's row: boundary b = (r + HL) / TY - 1, offset (r + HL) % TY < 7.  (Rows outside
 		// that set are reached only by reflections that feed no valid output.)
-		const int u = r + HL, b = (u >> 5) - 1, o = u & 31;
+		const int u = r + HL, b = u / TY - 1, o = u % TY;
 		const bool inrs = !own && o < 7 && b >= 0 && b < nty - 1;
 		rowinfo = r | (ip && own ? 1 << 16 : 0) | (ip && inrs ? (1 << 17) | ((7 * b + o) << 18) : 0);
 	}
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 		const float *csl = sh.cs + (long)s * sh.cs_sz;
 #pragma unroll 1
 		for (int i = 0; i < RPW; i++) {
-			if (wv + 4 * i < NR) {
+			if (wv + NW * i < NR) {
 				const int info = __builtin_amdgcn_readlane(rowinfo, i);
 				const int r = info & 0xffff;
 				const float *grow = sl + (long)r * sy;
@@ -263,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 #pragma unroll
 				for (int q = 0; q < 2; q++) {
 					const int i = 2 * ip + q;
-					if (wv + 4 * i < NR) // (the last wave stages one row fewer: its read of that slot is harmless)
-						lds_write4(slab_off + (unsigned)(wv + 4 * i) * TW * 4 + lane * 16,
+					if (wv + NW * i < NR) // (a wave may stage fewer rows than it has slots: the idle slot's lift is harmless)
+						lds_write4(slab_off + (unsigned)(wv + NW * i) * TW * 4 + lane * 16,
 							u4{to_bits(y0_[q]), to_bits(y1_[q]), to_bits(y2_[q]), to_bits(y3_[q])});
 				}
 			}
@@ -403,30 +408,48 @@ __global__ __launch_bounds__(256, 2) void k_vol_level_ip(VolFusedArgs a, VolShel
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
-static int vol_ip_march(const VolFusedArgs &a, const VolTuning &vt)
+static int vol_ip_march(const VolFusedArgs &a, const VolTuning &vt, int nw = 4)
 {
-	// the model of launch_vol_fwd_fused (two workgroups per CU: 512 slots)
-	const int Zd = (a.nz + 1) / 2, ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
-	const double slots = 512;
-	int tp = 128;
+	// The model of launch_vol_fwd_fused -- rounds of workgroups over the chip's slots (4 waves: two
+	// workgroups per CU, 512 slots, a workgroup that has its CU to itself marches faster; 8 waves: one per
+	// CU, 256) times (slice pairs + 4 warm-up pairs) -- over BALANCED marches: the depth is cut into nzt
+	// equal parts (896^3: 4 x 112 pairs instead of 128 + 128 + 128 + 64).
+	const int Zd = (a.nz + 1) / 2, ntx = (a.nx + 255) / 256, nty = (a.ny + 8 * nw - 1) / (8 * nw);
+	const double slots = nw == 4 ? 512 : 256;
+	int tp = Zd;
 	double best = -1;
-	for (int cand = 128; cand >= 16; cand >>= 1) {
+	for (int nzt = 1; nzt <= 64; nzt++) {
+		const int cand = (Zd + nzt - 1) / nzt;
+		if (cand < 8 && nzt > 1)
+			break;
 		const double n = (double)ntx * nty * ((Zd + cand - 1) / cand);
-		const double rounds = n <= slots ? (n <= slots / 2 ? 0.6 : 1.0) : n / slots + 0.35;
+		const double rounds = n <= slots ? ((nw == 4 && n <= slots / 2) ? 0.6 : 1.0) : n / slots + 0.35;
 		const double cost = rounds * (cand + 4);
 		if (best < 0 || cost < best) {
 			best = cost;
 			tp = cand;
 		}
 	}
+	if (tp > 256)
+		tp = 256; // (bounds the slice shell's distance from the data it mirrors; deeper volumes take more marches)
 	if (vt.tile_pairs >= 4)
 		tp = vt.tile_pairs;
-	return tp;
+	return tp < 4 ? 4 : tp;
 }
 
-static size_t vol_shell_layout(const VolFusedArgs &a, int tp, float *base, VolShell *sh)
+// Waves per workgroup: tiles of 64 rows (8 waves, one workgroup per CU) halve the halo rows and win at
+// every size measured (1024^3 in place: forward 2.30 -> 1.96 ms, inverse 2.38 -> 2.16; 512^3 0.40 -> 0.36;
+// scripts/r03_vol_ip_waves.py) -- unless the volume has a single tile row of 32 anyway.
+static int vol_ip_waves(const VolFusedArgs &a, const VolTuning &vt)
 {
-	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32, Zd = (a.nz + 1) / 2;
+	if (vt.ip_waves == 4 || vt.ip_waves == 8)
+		return vt.ip_waves;
+	return a.ny > 32 ? 8 : 4;
+}
+
+static size_t vol_shell_layout(const VolFusedArgs &a, int tp, float *base, VolShell *sh, int nw = 4)
+{
+	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 8 * nw - 1) / (8 * nw), Zd = (a.nz + 1) / 2;
 	const int nzt = (Zd + tp - 1) / tp;
 	VolShell s{};
 	s.tile_pairs_z = tp;
@@ -470,17 +493,18 @@ bool vol_level_ip_applies(const VolFusedArgs &a)
 
 size_t vol_level_ip_scratch(const VolFusedArgs &a, const VolTuning &vt)
 {
-	return vol_shell_layout(a, vol_ip_march(a, vt), nullptr, nullptr) * 4;
+	const int nw = vol_ip_waves(a, vt);
+	return vol_shell_layout(a, vol_ip_march(a, vt, nw), nullptr, nullptr, nw) * 4;
 }
 
-template <bool INV, int MODE, int NT>
+template <bool INV, int MODE, int NT, int NW = 4>
 static hipError_t vol_ip_go(const VolFusedArgs &a, const VolShell &sh, int ntx, int nty, int swz, hipStream_t s)
 {
-	constexpr int NR = 39;
-	const size_t lds = (size_t)NR * (256 + 8) * 4 + (size_t)NR * 256 * 4;
-	if (hipError_t e = allow_lds((const void *)k_vol_level_ip<INV, MODE, NT>, lds))
+	constexpr int NR = 8 * NW + 7;
+	const size_t lds = (size_t)(NW == 4 ? NR : NW * 10) * (256 + 8) * 4 + (size_t)NR * 256 * 4;
+	if (hipError_t e = allow_lds((const void *)k_vol_level_ip<INV, MODE, NT, NW>, lds))
 		return e;
-	k_vol_level_ip<INV, MODE, NT><<<dim3(ntx * nty * sh.nzt), 256, lds, s>>>(a, sh, ntx, nty, swz);
+	k_vol_level_ip<INV, MODE, NT, NW><<<dim3(ntx * nty * sh.nzt), 64 * NW, lds, s>>>(a, sh, ntx, nty, swz);
 	return hipGetLastError();
 }
 
@@ -490,15 +514,16 @@ hipError_t launch_vol_level_ip(bool inverse, const VolFusedArgs &a, float *scrat
 		return hipErrorInvalidValue;
 	if (a.mode != 0 && !(a.mode == 2 && !inverse && a.side))
 		return hipErrorInvalidValue;
+	const int nw = vol_ip_waves(a, vt);
 	VolShell sh;
-	vol_shell_layout(a, vol_ip_march(a, vt), scratch, &sh);
-	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
+	vol_shell_layout(a, vol_ip_march(a, vt, nw), scratch, &sh, nw);
+	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 8 * nw - 1) / (8 * nw);
 	if ((long)ntx * nty * sh.nzt > 0x7fffffffL)
 		return hipErrorInvalidValue;
 	const int hl = inverse ? 3 : 4;
 	const int nbx = ((a.nx + 3) / 4 + 255) / 256;
 	if (nty > 1)
-		k_shell_rows<<<dim3(nbx, 7 * (nty - 1), a.nz), 256, 0, s>>>(a.in, a.in_sy, a.in_sz, sh, a.nx, a.ny, hl);
+		k_shell_rows<<<dim3(nbx, 7 * (nty - 1), a.nz), 256, 0, s>>>(a.in, a.in_sy, a.in_sz, sh, a.nx, a.ny, hl, 8 * nw);
 	if (ntx > 1) {
 		const int npc = 2 * (ntx - 1);
 		k_shell_cols<<<dim3((unsigned)(((long)a.ny * npc + 255) / 256), a.nz), 256, 0, s>>>(a.in, a.in_sy, a.in_sz, sh, a.nx, a.ny, npc);
@@ -506,11 +531,16 @@ hipError_t launch_vol_level_ip(bool inverse, const VolFusedArgs &a, float *scrat
 	k_shell_slices<<<dim3(nbx, a.ny, 9 * (sh.nzt - 1) + 5), 256, 0, s>>>(a.in, a.in_sy, a.in_sz, sh, a.nx, a.ny, a.nz);
 	if (hipError_t e = hipGetLastError())
 		return e;
-	// cache policy: nothing a tile loads is loaded by another tile (the halo comes from the shell), so
-	// loads are non-temporal like the stores (1024^3: inverse 2.51 -> 2.47 ms, forward unchanged)
+	// cache policy: a tile's own rows are loaded by no other tile (the halo comes from the shell): non-temporal
+	// like the stores (1024^3: inverse 2.51 -> 2.47 ms, forward unchanged); shell rows stay cacheable
 	const int want = vt.nt < 0 ? 3 : (vt.nt & 3);
 	const bool nt_loads = (want & 2) != 0;
-#define DWT_IP_GO(INV_, MODE_) return nt_loads ? vol_ip_go<INV_, MODE_, 3>(a, sh, ntx, nty, vt.swizzle, s) : vol_ip_go<INV_, MODE_, 1>(a, sh, ntx, nty, vt.swizzle, s)
+#define DWT_IP_GO(INV_, MODE_) \
+	do { \
+		if (nw == 8) \
+			return nt_loads ? vol_ip_go<INV_, MODE_, 3, 8>(a, sh, ntx, nty, vt.swizzle, s) : vol_ip_go<INV_, MODE_, 1, 8>(a, sh, ntx, nty, vt.swizzle, s); \
+		return nt_loads ? vol_ip_go<INV_, MODE_, 3>(a, sh, ntx, nty, vt.swizzle, s) : vol_ip_go<INV_, MODE_, 1>(a, sh, ntx, nty, vt.swizzle, s); \
+	} while (0)
 	if (inverse)
 		DWT_IP_GO(true, 4);
 	if (a.mode == 2)
@@ -519,24 +549,37 @@ hipError_t launch_vol_level_ip(bool inverse, const VolFusedArgs &a, float *scrat
 #undef DWT_IP_GO
 }
 
-// One INVERSE level in one pass, OUT OF PLACE: the dense source `a.in` stays intact (no shell needed);
-// a.mode 0: dense result; 1: result into the stride-out_sx lattice of `a.out` (out_sy / out_sz the
-// destination's strides times out_sx) -- a level >= 1 of a multi-level inverse writing straight into
-// the level above instead of a dense result plus a scatter pass.
-hipError_t launch_vol_inv_fused(const VolFusedArgs &a, const VolTuning &vt, hipStream_t s)
+// One level in one pass, OUT OF PLACE, with this file's kernel: the source `a.in` stays intact, so no
+// shell is needed (every row, column and slice a tile reads comes from the source; cacheable loads:
+// neighbouring tiles share their halo lines).  Forward: a.mode 0 (dense result) or 2 (level 0 of a
+// multi-level call withholding the rows level 1 writes whole, see k_vol_fwd_fused), `lll` as there;
+// tiles of 64 rows (8 waves) where the volume has more than 32 rows.  Inverse: a.mode 0, or 1 = result
+// into the stride-out_sx lattice of `a.out` (out_sy / out_sz the destination's strides times out_sx):
+// a level >= 1 of a multi-level inverse writing straight into the level above instead of a dense
+// result plus a scatter pass.
+hipError_t launch_vol_level_op(bool inverse, const VolFusedArgs &a, const VolTuning &vt, hipStream_t s)
 {
-	if (!vol_level_ip_can(a) || a.in == a.out || (a.mode != 0 && a.mode != 1) || (a.mode == 0 && a.out_sx != 1))
+	if (!vol_level_ip_can(a) || a.in == a.out)
 		return hipErrorInvalidValue;
+	if (inverse ? ((a.mode != 0 && a.mode != 1) || (a.mode == 0 && a.out_sx != 1)) : (a.mode != 0 && !(a.mode == 2 && a.side)))
+		return hipErrorInvalidValue;
+	const int nw = vol_ip_waves(a, vt);
 	VolShell sh{};
-	sh.tile_pairs_z = vol_ip_march(a, vt);
+	sh.tile_pairs_z = vol_ip_march(a, vt, nw);
 	sh.nzt = ((a.nz + 1) / 2 + sh.tile_pairs_z - 1) / sh.tile_pairs_z;
-	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 31) / 32;
+	const int ntx = (a.nx + 255) / 256, nty = (a.ny + 8 * nw - 1) / (8 * nw);
 	if ((long)ntx * nty * sh.nzt > 0x7fffffffL)
 		return hipErrorInvalidValue;
-	// cacheable loads (neighbouring tiles share their halo lines), non-temporal stores
-	if (a.mode == 1)
-		return vol_ip_go<true, 1, 1>(a, sh, ntx, nty, vt.swizzle, s);
-	return vol_ip_go<true, 4, 1>(a, sh, ntx, nty, vt.swizzle, s);
+#define DWT_OP_GO(INV_, MODE_) return nw == 8 ? vol_ip_go<INV_, MODE_, 1, 8>(a, sh, ntx, nty, vt.swizzle, s) : vol_ip_go<INV_, MODE_, 1, 4>(a, sh, ntx, nty, vt.swizzle, s)
+	if (inverse) {
+		if (a.mode == 1)
+			DWT_OP_GO(true, 1);
+		DWT_OP_GO(true, 4);
+	}
+	if (a.mode == 2)
+		DWT_OP_GO(false, 2);
+	DWT_OP_GO(false, 4);
+#undef DWT_OP_GO
 }
 
 } // namespace dwt

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""In-place 3-D level (1024^3, 1 level), variants alternated inside one process:
+"""In-place 3-D level (SIZE^3, default 1024; 1 level), variants alternated inside one process:
 python scripts/r03_vol_ip_variants.py name=v1,v2 [name=...]   e.g. vol_nt=1,3 vol_tile_pairs=0,64"""
 import os, sys, time, statistics, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt
-n = 1024
+n = int(os.environ.get("SIZE", 1024))
 dwt.dwt_util_init(); dwt.use_torch_stream()
 a = torch.rand((n, n, n), device="cuda")
 axes = [(kv.split("=")[0], [int(x) for x in kv.split("=")[1].split(",")]) for kv in sys.argv[1:]]

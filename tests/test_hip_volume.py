@@ -452,10 +452,12 @@ def test_one_pass_levels_randomised(dwt, oracle):
             while levels > 1 and min(-(-n // (1 << (levels - 1))) for n in (nx, ny, nz)) < 2:
                 levels -= 1
             tp = int(rng.choice([0, 4, 5, 8, 13, 20]))
+            waves = int(rng.choice([4, 8]))  # tiles of 32 rows (two workgroups per CU) or of 64 rows (one)
             dwt.set_option("vol_tile_pairs", tp)
+            dwt.set_option("vol_ip_waves", waves)
             vol = rng.random((nz, ny, nx), dtype=np.float32)
             want = oracle_multilevel(oracle, vol.copy(), levels, False)
-            what = f"case {case}: {nz}x{ny}x{nx} levels {levels} march {tp}"
+            what = f"case {case}: {nz}x{ny}x{nx} levels {levels} march {tp} waves {waves}"
             d = DevVol(dwt, vol)
             d.run(0, levels)
             assert np.array_equal(bits(d.get()), bits(want)), what + " (in place, forward)"
@@ -472,4 +474,5 @@ def test_one_pass_levels_randomised(dwt, oracle):
     finally:
         dwt.set_option("vol_fused", 1)
         dwt.set_option("vol_tile_pairs", 0)
+        dwt.set_option("vol_ip_waves", 0)
     assert done == 140

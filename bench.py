@@ -16,6 +16,10 @@ the barrier and the max-over-ranks only.  value = total samples / slowest rank's
     python bench.py --gpus N ...        # starts the N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Before the warm-up every rank picks the PLACEMENT of its shard: the sweeps' rate depends on which
+physical memory backs the two buffers, so up to `--placements` allocations are tried
+(three untimed steps each) and the fastest kept; the attempts are reported in the line (`placement`).
+
 Prints ONE JSON line on rank 0.  For N > 1 the line also carries `batch_split`: the time to
 scatter the whole batch from rank 0 and gather the coefficients back over RCCL (grouped
 point-to-point, libdwt_amd.batch) -- reported beside the transform, never inside `value`.

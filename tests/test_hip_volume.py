@@ -476,3 +476,23 @@ def test_one_pass_levels_randomised(dwt, oracle):
         dwt.set_option("vol_tile_pairs", 0)
         dwt.set_option("vol_ip_waves", 0)
     assert done == 140
+
+
+def test_volume_entry_errors(dwt):
+    """The field-level entries refuse what they cannot do -- non-zero return and a message, nothing
+    transformed -- as the typed wrappers then log and abort (dwt_util_error semantics)."""
+    L = dwt.lib
+    v = np.random.default_rng(3).random((9, 10, 12), dtype=np.float32)
+    keep = v.copy()
+    sy, sz = 12 * 4, 12 * 10 * 4
+    assert L.dwt_hip_volume_fwd_op(v.ctypes.data, sy, sz, v.ctypes.data, sy, sz, 12, 10, 9, 7) != 0  # out of place only
+    assert "out of place" in dwt.last_error()
+    out = np.zeros_like(v)
+    assert L.dwt_hip_volume_fwd_op(v.ctypes.data, sy, sz, out.ctypes.data, sy, sz, 12, 10, 9, 3) != 0  # dirs
+    assert L.dwt_hip_volume_fwd_op(v.ctypes.data, sy - 4, sz, out.ctypes.data, sy, sz, 12, 10, 9, 7) != 0  # rows overlap
+    assert L.dwt_hip_volume_ip(0, None, sy, sz, 12, 10, 9) != 0
+    d = DevVol(dwt, v)
+    assert L.dwt_hip_volume_ip(0, d.ptr, sy + 2, (sy + 2) * 10, 12, 10, 9) != 0  # device strides must be whole samples
+    assert "multiples of 4" in dwt.last_error()
+    d.free()
+    assert np.array_equal(v, keep) and not out.any()

@@ -476,6 +476,40 @@ def batch_split_times(torch, plane, src, total, n, rank, world, dev):
             "how": "rank 0 -> all ranks and back, grouped isend/irecv (batch_isend_irecv), root-egress bound"}
 
 
+def choose_placement(torch, dev, tries, make, run):
+    """Up to `tries` allocations of a workload's buffers (`make()` -> tuple of tensors) behind spacers of
+    different sizes, `run(bufs)` once to warm and three times timed (untimed for the benchmark), the
+    fastest kept: the sweeps' rate depends on which physical memory backs their buffers (DESIGN s5)."""
+    spacers_gib = [0, 7, 2.6, 50]
+    cands, report = [], []
+    for k in range(max(1, tries)):
+        sp_gib = spacers_gib[k % len(spacers_gib)]
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        spacer = None
+        if k > 0:
+            need = int(sp_gib * (1 << 30)) + cands[0][3] + (8 << 30)
+            if free_b < need:
+                break
+            spacer = torch.empty(int(sp_gib * (1 << 30)), dtype=torch.uint8, device=dev) if sp_gib else None
+        bufs = make()
+        nbytes = sum(t.numel() * t.element_size() for t in bufs)
+        run(bufs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run(bufs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        cands.append((dt, spacer, bufs, nbytes))
+        report.append({"spacer_GiB": sp_gib, "ms_per_step": round(dt * 1e3, 4)})
+    best = min(range(len(cands)), key=lambda i: cands[i][0])
+    bufs = cands[best][2]
+    keep_spacer = cands[best][1]  # stays allocated: it is what holds the placement
+    cands = None
+    torch.cuda.empty_cache()
+    return bufs, keep_spacer, {"attempts": report, "chosen": best, "how": "untimed: 3 steps per candidate allocation of the buffers; DESIGN s5"}
+
+
 def other_workload(args, dwt, torch, plane, world, rank, dev):
     """The other BASELINE.json configs through the same contract (one JSON line, whole-job rate,
     barrier + synchronize on both sides, max over ranks): config3 = int CDF 5/3 4096^2 3 levels
@@ -490,52 +524,54 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
     scaling = "weak"
     if w == "config3":
         n, J, nb = 4096, 3, 16
-        src = torch.randint(-32768, 32768, (nb, n, n), generator=gen, device=dev, dtype=torch.int32)
-        dst = torch.empty_like(src)
-        back = torch.empty_like(src)
-        def step():
-            dwt.transform2d_batch("cdf53_i", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
-            dwt.transform2d_batch("cdf53_i", 1, dst, back, n * n * 4, nb, n * 4, n, n, J)
+        def make():
+            s_ = torch.randint(-32768, 32768, (nb, n, n), generator=gen, device=dev, dtype=torch.int32)
+            return s_, torch.empty_like(s_), torch.empty_like(s_)
+        def run(b):
+            dwt.transform2d_batch("cdf53_i", 0, b[0], b[1], n * n * 4, nb, n * 4, n, n, J)
+            dwt.transform2d_batch("cdf53_i", 1, b[1], b[2], n * n * 4, nb, n * 4, n, n, J)
         units, unit, dtype = world * nb * n * n, "Gsamples/s", "i32"
         alg = 2 * algorithmic_bytes(n, n, J) * nb
         metric = "Gsamples/s CDF 5/3 2-D int forward+inverse, 4096^2 3-level"
         name = f"CDF 5/3 forward + inverse 2-D int32, {n}x{n}, {J} levels, {nb} device-resident images per step per GPU"
-        check = lambda: {"round_trip_exact": bool(torch.equal(back, src))}
+        check = lambda b: {"round_trip_exact": bool(torch.equal(b[2], b[0]))}
     elif w == "config4":
         n, J, total = 4096, 5, 256
         lo, hi = shard_range(total, rank, world)
         nb = hi - lo
-        src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
-        dst = torch.empty_like(src)
-        def step():
-            dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
+        def make():
+            s_ = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
+            return s_, torch.empty_like(s_)
+        def run(b):
+            dwt.transform2d_batch("cdf97_s", 0, b[0], b[1], n * n * 4, nb, n * 4, n, n, J)
         units, unit, dtype = total * n * n, "Gsamples/s", "f32"
         alg = algorithmic_bytes(n, n, J) * nb
         scaling = "strong"
         metric = "Gsamples/s CDF 9/7 2-D fwd float, batch of 256 x 4096^2 5-level"
         name = (f"CDF 9/7 forward 2-D float, {n}x{n}, {J} levels, fixed batch of {total} device-resident images "
                 f"sharded b*N//B over {world} GPU(s) ({nb} on rank 0)")
-        def check():
+        def check(b):
             # in-run sanity: the first and the last image of this rank's shard, transformed ALONE through
             # the libdwt.h entry dwt_cdf97_2f_s2, must give the batch's bits
             one = torch.empty((n, n), dtype=torch.float32, device=dev)
             same = True
             for k in sorted({0, nb - 1}):
-                dwt.dwt_cdf97_2f_s2(src[k], one, n * 4, 4, n, n, n, n, J)
+                dwt.dwt_cdf97_2f_s2(b[0][k], one, n * 4, 4, n, n, n, n, J)
                 torch.cuda.synchronize()
-                same = same and bool(torch.equal(one.view(torch.int32), dst[k].view(torch.int32)))
+                same = same and bool(torch.equal(one.view(torch.int32), b[1][k].view(torch.int32)))
             return {"batch_equals_single_image_entry": same}
     else:
         n, J = 1024, 3
-        src = torch.rand((n, n, n), generator=gen, device=dev, dtype=torch.float32)
-        dst = torch.empty_like(src)
-        def step():
-            dwt.transform3d_op(src, dst, n * 4, n * n * 4, n, n, n, J)
+        def make():
+            s_ = torch.rand((n, n, n), generator=gen, device=dev, dtype=torch.float32)
+            return s_, torch.empty_like(s_)
+        def run(b):
+            dwt.transform3d_op(b[0], b[1], n * 4, n * n * 4, n, n, n, J)
         units, unit, dtype = world * n ** 3, "Gvoxels/s", "f32"
         alg = sum(8 * ((n >> j) ** 3) for j in range(J))
         metric = "Gvoxels/s CDF 9/7 3-D fwd float, 1024^3 3-level"
         name = f"CDF 9/7 forward 3-D float, {n}^3, {J} levels, out of place (cdf97_3f_op semantics), one volume per step per GPU"
-        def check():
+        def check(b):
             # in-run sanity: a constant volume has no detail -- every coefficient with an odd index on
             # any axis is ~0 and the deepest approximation is the constant times 2^(3J/2)
             c = torch.full((64, 64, 256), 3.0, dtype=torch.float32, device=dev)
@@ -545,6 +581,11 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
             lll = o[0::2, 0::2, 0::2]
             det = float(o[1::2].abs().max())
             return {"constant_volume_ok": bool(det < 1e-5 and float((lll - 3.0 * 2 ** 1.5).abs().max()) < 1e-4)}
+
+    bufs, _spacer, placement = choose_placement(torch, dev, min(args.placements, 3), make, run)
+
+    def step():
+        run(bufs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -560,7 +601,7 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
     elapsed = time.perf_counter() - t0
     elapsed = plane.max(elapsed)
     try:
-        checks = check()
+        checks = check(bufs)
     except Exception as e:  # noqa: BLE001
         checks = {"check_error": f"{type(e).__name__}: {e}"}
     if rank != 0:
@@ -576,6 +617,7 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "whole step (all levels) on rank 0: algorithmic bytes / step time"},
+        "placement": placement,
     }
 
 

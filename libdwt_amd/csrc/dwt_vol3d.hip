@@ -657,12 +657,33 @@ __global__ __launch_bounds__(256) void k_lattice_merge(const float *__restrict__
 		}
 }
 
+// Gather of a stride-2 lattice into a dense volume (the pack of a multi-level inverse): one thread
+// per four output samples -- two 16-byte loads of the source row (rows as buffers: the tail of an odd
+// row is zero-filled), the even samples of them as one 16-byte store.
+__global__ __launch_bounds__(256) void k_lattice_pack2(const float *__restrict__ src, long s_sy, long s_sz, float *__restrict__ dst, long d_sy, long d_sz,
+	int nx, int src_nx, int ny, int nxb)
+{
+	const int x4 = ((blockIdx.x % nxb) * 256 + threadIdx.x) * 4; // first output sample of this thread
+	const int y = blockIdx.x / nxb, z = blockIdx.y;
+	if (x4 >= nx || y >= ny)
+		return;
+	const row_rsrc_t rs = row_rsrc(src + (long)z * s_sz + (long)y * s_sy, (unsigned)src_nx * 4);
+	const u4 a = load16_row<true>(rs, (unsigned)x4 * 8), b = load16_row<true>(rs, (unsigned)x4 * 8 + 16);
+	store16_row<false>(row_rsrc(dst + (long)z * d_sz + (long)y * d_sy, (unsigned)nx * 4), (unsigned)x4 * 4, u4{a[0], a[2], b[0], b[2]});
+}
+
 hipError_t launch_lattice_copy(const float *src, long s_sx, long s_sy, long s_sz, float *dst, long d_sx, long d_sy, long d_sz,
 	int nx, int ny, int nz, hipStream_t s)
 {
 	const int nxb = (nx + 255) / 256;
 	if (nx < 1 || ny < 1 || nz < 1 || nz > 65535 || (long)nxb * ny > 0x7fffffffL)
 		return hipErrorInvalidValue;
+	if (s_sx == 2 && d_sx == 1 && nx >= 64) {
+		// the source row holds the samples 0, 2, ..., 2 (nx - 1): 2 nx - 1 of them are addressable for sure
+		const int nxb4 = ((nx + 3) / 4 + 255) / 256;
+		k_lattice_pack2<<<dim3(nxb4 * ny, nz), 256, 0, s>>>(src, s_sy, s_sz, dst, d_sy, d_sz, nx, 2 * nx - 1, ny, nxb4);
+		return hipGetLastError();
+	}
 	dim3 grid(nxb * ny, nz);
 	k_lattice_copy<<<grid, 256, 0, s>>>(src, s_sx, s_sy, s_sz, dst, d_sx, d_sy, d_sz, nx, ny, nxb);
 	return hipGetLastError();

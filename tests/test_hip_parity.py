@@ -630,6 +630,23 @@ g.replay(); torch.cuda.synchronize()
 want = x[1].cpu().numpy().copy()
 Oracle().fwd("cdf97_2f_s", want, 4)
 assert np.array_equal(y[1].cpu().numpy().view(np.uint32), want.view(np.uint32)), "graph replay differs"
+# the interleaved 9/7 forward forks its exact border strips onto a side stream and joins it again:
+# that fork / join is captured with the call
+m = 2048
+a = torch.rand((m, m), device="cuda"); b = torch.empty_like(a)
+with torch.cuda.stream(s):
+    dwt.use_torch_stream()
+    dwt.transform2d_interleaved("cdf97_s", 0, 0, a, b, m * 4, 4, m, m, None, None, 4)
+    s.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        dwt.use_torch_stream()
+        dwt.transform2d_interleaved("cdf97_s", 0, 0, a, b, m * 4, 4, m, m, None, None, 4)
+b.zero_(); a.copy_(torch.rand((m, m), device="cuda"))
+g2.replay(); torch.cuda.synchronize()
+want = a.cpu().numpy().copy()
+Oracle().fwd("cdf97_2f_inplace_s", want, 4)
+assert np.array_equal(b.cpu().numpy().view(np.uint32), want.view(np.uint32)), "graph replay of the interleaved call differs"
 print("graph OK")
 """
 

@@ -693,7 +693,7 @@ def run_rank(args):
                 dwt.transform2d_batch("cdf97_s", 0, src[k:k + c], dst[k:k + c], img_bytes, c, n * 4, n, n, J)
 
     # Placement of the batch (untimed, before the warm-up).  The rate of the SAME binary on the SAME
-    # virtual addresses depends on which physical memory backs the two buffers: scripts/r03_state_probe.py
+    # virtual addresses depends on which physical memory backs the two buffers: scripts/probes/r03_state_probe.py
     # and r03_alloc_probe*.py show the level-0 kernel at 5.2, 5.4, 5.75 or 6.1 TB/s from one allocation of
     # the batch to the next inside one process (a plain device copy between the same buffers does not
     # move) -- DESIGN s5 "fast / slow state".  A caller who keeps a batch resident picks its buffers once;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fast / slow state (DESIGN s5) against HOW the batch's two buffers are allocated, alternated in one process."""
 import os, sys, time, ctypes
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

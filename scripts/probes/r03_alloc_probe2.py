@@ -3,7 +3,7 @@
 allocations of 16 GiB behind spacers of various sizes) print the level-0 kernel's rate next to the rate
 of a plain device copy between the same two buffers and of a read-only / write-only pass over each."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

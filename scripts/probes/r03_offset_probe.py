@@ -3,7 +3,7 @@
 destination batch?  ONE allocation holds both; the destination starts `delta` bytes behind the end of
 the source.  Several processes in a row (the state changes from process to process)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

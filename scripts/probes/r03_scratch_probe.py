@@ -2,7 +2,7 @@
 """Fast / slow state (DESIGN s5): with the batch's buffers FIXED, does re-allocating the library's own LL
 scratch (dwt_util_finish + init, behind spacers) move the level-0 rate?"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -2,7 +2,7 @@
 """Fast / slow state (DESIGN s5): find a SLOW and a FAST placement of the batch inside one process, then
 run the launch options over both: does any option close the gap?"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -3,7 +3,7 @@
 allocate the bench's batch, measure, free everything (empty_cache), allocate again -- optionally behind
 a spacer allocation that shifts the placement -- and measure again."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt

@@ -12,8 +12,14 @@
 //
 // Conventions.  A line is an interleaved signal a[0..N): even samples become L
 // (s), odd samples become H (d).  Ends use whole-sample symmetric reflection, which
-// reproduces the reference's explicit end formulas (`2*c*x` == `c*(x+x)` in fp32;
-// `(2d+2)>>2 == (d+1)>>1` for |d| < 2^30).  A forward transform runs K lifting
+// reproduces the reference's explicit end formulas (`2*c*x` == `c*(x+x)` in fp32; the
+// fixed-point 9/7 writes `a[N-2]+a[N-2]` itself).  The int 5/3 is the exception: its
+// line ends are `(d+1)>>1` and `-= s` (:10971-10976, :11768-11773), which differ from the
+// reflected `(d+d+2)>>2` / `(s+s)>>1` once the doubled term wraps (|x| >= 2^30), so that
+// policy carries explicit END FORMS (kEndForms, fwd_end / inv_end) and every kernel
+// applies them to the samples whose two taps are one and the same sample (index 0 and
+// N-1 after reflection).  Int arithmetic wraps modulo 2^32 like the compiled reference
+// (done in unsigned here: signed overflow is undefined for the compiler).  A forward transform runs K lifting
 // steps, step s acting on samples of parity (s+1)&1, then scales; an inverse
 // transform descales, then runs K steps, step s acting on parity s&1.
 #pragma once
@@ -23,6 +29,7 @@ namespace dwt {
 
 struct Cdf97S {
 	using T = float;
+	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
 	static constexpr int K = 4;          // lifting steps; also the halo in samples
 	static constexpr bool kScaleSingle = true;   // N==1 lines are scaled (:10757, :11546)
 	static constexpr bool kSkipSingleLine = true; // 2-D drivers skip a direction with one line (:12837)
@@ -60,17 +67,26 @@ struct Cdf97SFma : Cdf97S {
 struct Cdf53I {
 	using T = int;
 	static constexpr int K = 2;
+	static constexpr bool kEndForms = true;       // :10971-10976, :11768-11773
 	static constexpr bool kScaleSingle = false;   // N<2 untouched (:10961)
 	static constexpr bool kSkipSingleLine = false;
 	static constexpr bool kInvColsFirst = true;   // inverse: columns then rows (:18178-18195)
+	// wrapping int32 sums (the compiled reference wraps; the shifts are arithmetic)
+	static __device__ __forceinline__ T add(T a, T b) { return (T)((unsigned)a + (unsigned)b); }
+	static __device__ __forceinline__ T sub(T a, T b) { return (T)((unsigned)a - (unsigned)b); }
 	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
 	{
-		return s == 0 ? c - ((l + r) >> 1) : c + ((l + r + 2) >> 2);
+		return s == 0 ? sub(c, add(l, r) >> 1) : add(c, add(add(l, r), 2) >> 2);
 	}
 	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
 	{
-		return s == 0 ? c - ((l + r + 2) >> 2) : c + ((l + r) >> 1);
+		return s == 0 ? sub(c, add(add(l, r), 2) >> 2) : add(c, add(l, r) >> 1);
 	}
+	// line ends: both taps are the sample m.  Forward (:10971-10976): the last odd sample of an
+	// even-length line `-= s`, sample 0 and the last even sample of an odd-length line
+	// `+= (d+1)>>1`; inverse (:11768-11773) the same terms with the opposite sign.
+	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return s == 0 ? sub(c, m) : add(c, add(m, 1) >> 1); }
+	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return s == 0 ? sub(c, add(m, 1) >> 1) : add(c, m); }
 	static __device__ __forceinline__ T fwd_scale(int, T v) { return v; }
 	static __device__ __forceinline__ T inv_scale(int, T v) { return v; }
 	static __device__ __forceinline__ T fwd_single(T v) { return v; }
@@ -82,23 +98,32 @@ struct Cdf53I {
 // is exact here for any input.
 struct Cdf97I {
 	using T = int;
+	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
 	static constexpr int K = 4;
 	static constexpr bool kScaleSingle = false;
 	static constexpr bool kSkipSingleLine = false;
 	static constexpr bool kInvColsFirst = true; // :18256-18274: columns, then rows
+	// wrapping int32 arithmetic (as the compiled reference behaves; unsigned for the compiler)
+	static __device__ __forceinline__ T add(T a, T b) { return (T)((unsigned)a + (unsigned)b); }
+	static __device__ __forceinline__ T sub(T a, T b) { return (T)((unsigned)a - (unsigned)b); }
+	// (k * (l + r) + bias) >> sh
+	static __device__ __forceinline__ T term(int k, T l, T r, int bias, int sh)
+	{
+		return (T)((unsigned)k * ((unsigned)l + (unsigned)r) + (unsigned)bias) >> sh;
+	}
 	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
 	{
-		return s == 0 ? c - ((+203 * (l + r) - (1 << 6)) >> 7)
-		     : s == 1 ? c + ((-217 * (l + r) + (1 << 11)) >> 12)
-		     : s == 2 ? c - ((-113 * (l + r) - (1 << 6)) >> 7)
-		              : c + ((1817 * (l + r) + (1 << 11)) >> 12);
+		return s == 0 ? sub(c, term(+203, l, r, -(1 << 6), 7))
+		     : s == 1 ? add(c, term(-217, l, r, 1 << 11, 12))
+		     : s == 2 ? sub(c, term(-113, l, r, -(1 << 6), 7))
+		              : add(c, term(1817, l, r, 1 << 11, 12));
 	}
 	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
 	{
-		return s == 0 ? c - ((1817 * (l + r) + (1 << 11)) >> 12)
-		     : s == 1 ? c + ((-113 * (l + r) - (1 << 6)) >> 7)
-		     : s == 2 ? c - ((-217 * (l + r) + (1 << 11)) >> 12)
-		              : c + ((+203 * (l + r) - (1 << 6)) >> 7);
+		return s == 0 ? sub(c, term(1817, l, r, 1 << 11, 12))
+		     : s == 1 ? add(c, term(-113, l, r, -(1 << 6), 7))
+		     : s == 2 ? sub(c, term(-217, l, r, 1 << 11, 12))
+		              : add(c, term(+203, l, r, -(1 << 6), 7));
 	}
 	static __device__ __forceinline__ T fwd_scale(int, T v) { return v; }
 	static __device__ __forceinline__ T inv_scale(int, T v) { return v; }
@@ -112,22 +137,23 @@ struct Cdf97I {
 struct Cdf97IIp : Cdf97I {
 	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r)
 	{
-		return s == 0 ? c + ((-203 * (l + r) + (1 << 6)) >> 7)
-		     : s == 1 ? c + ((-217 * (l + r) + (1 << 11)) >> 12)
-		     : s == 2 ? c + ((+113 * (l + r) + (1 << 6)) >> 7)
-		              : c + ((1817 * (l + r) + (1 << 11)) >> 12);
+		return s == 0 ? add(c, term(-203, l, r, 1 << 6, 7))
+		     : s == 1 ? add(c, term(-217, l, r, 1 << 11, 12))
+		     : s == 2 ? add(c, term(+113, l, r, 1 << 6, 7))
+		              : add(c, term(1817, l, r, 1 << 11, 12));
 	}
 	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r)
 	{
-		return s == 0 ? c - ((1817 * (l + r) + (1 << 11)) >> 12)
-		     : s == 1 ? c - ((+113 * (l + r) + (1 << 6)) >> 7)
-		     : s == 2 ? c - ((-217 * (l + r) + (1 << 11)) >> 12)
-		              : c - ((-203 * (l + r) + (1 << 6)) >> 7);
+		return s == 0 ? sub(c, term(1817, l, r, 1 << 11, 12))
+		     : s == 1 ? sub(c, term(+113, l, r, 1 << 6, 7))
+		     : s == 2 ? sub(c, term(-217, l, r, 1 << 11, 12))
+		              : sub(c, term(-203, l, r, 1 << 6, 7));
 	}
 };
 
 struct Cdf53S {
 	using T = float;
+	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
 	static constexpr int K = 2;
 	static constexpr bool kScaleSingle = true;    // :10998-11003, :11797-11802
 	static constexpr bool kSkipSingleLine = false; // :16507-16523 run unconditionally
@@ -159,6 +185,7 @@ struct Cdf53SNew : Cdf53S {
 // two stored constants s1, s2 = 1/1.1496043988602.
 struct Cdf97D {
 	using T = double;
+	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
 	static constexpr int K = 4;
 	static constexpr bool kScaleSingle = true;
 	static constexpr bool kSkipSingleLine = false; // :12490-12506 run unconditionally
@@ -186,6 +213,7 @@ struct Cdf97D {
 // src/libdwt.c:2085-2130, 11484-11530; constants src/inline.h:337-341
 struct Cdf53D {
 	using T = double;
+	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
 	static constexpr int K = 2;
 	static constexpr bool kScaleSingle = true;
 	static constexpr bool kSkipSingleLine = false;
@@ -218,31 +246,66 @@ static __device__ __forceinline__ int reflect1(int i, int N)
 	return i >= N ? 2 * (N - 1) - i : i;
 }
 
+// Step s on a sample whose taps are l and r; `end`: the sample sits on a line end (index 0 or
+// N-1 after reflection), where l and r are one and the same sample.  Only policies with explicit
+// end forms look at `end`.
+template <class W>
+static __device__ __forceinline__ typename W::T fwd_step_at(int s, bool end, typename W::T c, typename W::T l, typename W::T r)
+{
+	if constexpr (W::kEndForms)
+		return end ? W::fwd_end(s, c, l) : W::fwd_step(s, c, l, r);
+	else
+		return W::fwd_step(s, c, l, r);
+}
+
+template <class W>
+static __device__ __forceinline__ typename W::T inv_step_at(int s, bool end, typename W::T c, typename W::T l, typename W::T r)
+{
+	if constexpr (W::kEndForms)
+		return end ? W::inv_end(s, c, l) : W::inv_step(s, c, l, r);
+	else
+		return W::inv_step(s, c, l, r);
+}
+
+// Bit j of the result: sample g0 + j of a line of N samples (N >= 2, any g0: reflected) is a line end.
+template <int n>
+static __device__ __forceinline__ unsigned end_mask(int g0, int N)
+{
+	unsigned m = 0;
+#pragma unroll
+	for (int j = 0; j < n; j++) {
+		const int i = reflect(g0 + j, N);
+		m |= (unsigned)(i == 0 || i == N - 1) << j;
+	}
+	return m;
+}
+
 // Run the K lifting steps of a forward transform over a register array a[0..n)
 // whose element 0 is an EVEN sample.  After step s, entries j in [s+1, n-2-s] of
 // parity (s+1)&1 are valid; the caller takes the centre it needs.  Fully unrolled:
 // all indices are compile-time constants.
+// `ends`: end_mask of the array (used by policies with explicit end forms only).
 template <class W, int n>
-static __device__ __forceinline__ void lift_fwd_regs(typename W::T (&a)[n])
+static __device__ __forceinline__ void lift_fwd_regs(typename W::T (&a)[n], unsigned ends = 0)
 {
 #pragma unroll
 	for (int s = 0; s < W::K; s++) {
 #pragma unroll
 		for (int j = s + 1; j <= n - 2 - s; j += 2)
-			a[j] = W::fwd_step(s, a[j], a[j - 1], a[j + 1]);
+			a[j] = fwd_step_at<W>(s, (ends >> j) & 1, a[j], a[j - 1], a[j + 1]);
 	}
 }
 
 // Inverse steps over a[0..n) whose element 0 is an ODD sample (so step 0, which
 // acts on even samples, again starts at j = 1).  Entries must be descaled first.
 template <class W, int n>
-static __device__ __forceinline__ void lift_inv_regs(typename W::T (&a)[n])
+static __device__ __forceinline__ void lift_inv_regs(typename W::T (&a)[n], unsigned ends = 0)
 {
 #pragma unroll
 	for (int s = 0; s < W::K; s++) {
 #pragma unroll
 		for (int j = s + 1; j <= n - 2 - s; j += 2)
-			a[j] = W::inv_step(s, a[j], a[j - 1], a[j + 1]);
+			a[j] = inv_step_at<W>(s, (ends >> j) & 1, a[j], a[j - 1], a[j + 1]);
 	}
 }
 

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_line_pass(const char *__restrict__ src,
 #pragma unroll
 		for (int j = 0; j <= 2 * K; j++)
 			w[j] = ld(reflect(2 * k - K + j, N));
-		lift_fwd_regs<W, 2 * K + 1>(w);
+		lift_fwd_regs<W, 2 * K + 1>(w, W::kEndForms ? end_mask<2 * K + 1>(2 * k - K, N) : 0u);
 		st(il ? 2 * k : k, W::fwd_scale(0, w[K]));
 		if (2 * k + 1 < N)
 			st(il ? 2 * k + 1 : hoff + k, W::fwd_scale(1, w[K + 1]));
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_line_pass(const char *__restrict__ src,
 			const T raw = il ? ld(i) : (i & 1) ? ld(hoff + (i >> 1)) : ld(i >> 1);
 			w[j] = W::inv_scale(i & 1, raw);
 		}
-		lift_inv_regs<W, 2 * K + 1>(w);
+		lift_inv_regs<W, 2 * K + 1>(w, W::kEndForms ? end_mask<2 * K + 1>(2 * k - K + 1, N) : 0u);
 		st(2 * k, w[K - 1]);
 		if (2 * k + 1 < N)
 			st(2 * k + 1, w[K]);
@@ -222,6 +222,13 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 		for (int v = 0; v < CPT; v++)
 			st[s][v] = 0;
 
+	// explicit line-end forms (int 5/3 only): which of the lane's columns c - K .. c + CPT + K - 1
+	// are a row's ends; the rows that are a column's ends are found per iteration (wave-uniform)
+	static_assert(!W::kEndForms || K == 2, "end forms are wired into the two-step vertical lift only");
+	[[maybe_unused]] unsigned hends = 0;
+	if constexpr (W::kEndForms)
+		hends = end_mask<NARR>(c0 + lane * CPT - K, a.W);
+
 	for (int it = 0; it < kAhead && it < n_iter; it++)
 		issue(it);
 
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 #pragma unroll
 			for (int e = 0; e < 4; e++)
 				x[K + e] = from_bits<T>(O0[e]);
-			lift_fwd_regs<W, NARR>(x);
+			lift_fwd_regs<W, NARR>(x, hends);
 #pragma unroll
 			for (int v = 0; v < CPT; v++)
 				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
@@ -292,6 +299,12 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 		rslot = rslot + 2 >= kRing ? 0 : rslot + 2;
 
 		// vertical pass: streaming lifting, state in registers
+		[[maybe_unused]] bool vend_o = false, vend_e = false; // rows 2q-1 / 2q-2 are column ends
+		if constexpr (W::kEndForms) {
+			const int ro = reflect(2 * (q0 + it) - 1, a.H), re = reflect(2 * (q0 + it) - 2, a.H);
+			vend_o = ro == 0 || ro == a.H - 1;
+			vend_e = re == 0 || re == a.H - 1;
+		}
 		T lo[CPT], hi[CPT];
 #pragma unroll
 		for (int v = 0; v < CPT; v++) {
@@ -308,8 +321,8 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 				st[2][v] = s1n;
 				st[3][v] = d2n;
 			} else {
-				const T d1n = W::fwd_step(0, ov, st[0][v], ev);
-				const T s1n = W::fwd_step(1, st[0][v], st[1][v], d1n);
+				const T d1n = fwd_step_at<W>(0, vend_o, ov, st[0][v], ev);
+				const T s1n = fwd_step_at<W>(1, vend_e, st[0][v], st[1][v], d1n);
 				lo[v] = W::fwd_scale(0, s1n);
 				hi[v] = W::fwd_scale(1, d1n);
 				st[0][v] = ev;
@@ -534,6 +547,16 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 			for (int v = 0; v < NVG; v++)
 				st[s][gi][v] = 0;
 
+	// explicit line-end forms (int 5/3 only): the ends of a row among each group's samples
+	// c - K + 1 .. c + CG + K - 1; the rows that are a column's ends are found per iteration
+	static_assert(!W::kEndForms || (K == 2 && !IL), "end forms are wired into the two-step Mallat sweeps only");
+	[[maybe_unused]] unsigned hends[G] = {};
+	if constexpr (W::kEndForms) {
+#pragma unroll
+		for (int gi = 0; gi < G; gi++)
+			hends[gi] = end_mask<NARR>(c0 + 64 * CG * gi + lane * CG - K + 1, a.W);
+	}
+
 	for (int it = 0; it < kAhead && it < n_iter; it++)
 		issue(it);
 
@@ -614,7 +637,7 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 			if constexpr (!W::kInvColsFirst) {
 #pragma unroll
 				for (int rr = 0; rr < 2; rr++) {
-					lift_inv_regs<W, NARR>(x[rr][gi]);
+					lift_inv_regs<W, NARR>(x[rr][gi], hends[gi]);
 					// after the horizontal inverse the row is plain samples again; the
 					// vertical pass descales by ROW parity
 #pragma unroll
@@ -632,6 +655,12 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 
 		// vertical inverse, streaming.  K == 4: at step p the rows 2p-3 (odd) and
 		// 2p-2 (even) are final; K == 2: rows 2p-1 and 2p.
+		[[maybe_unused]] bool vend_e = false, vend_o = false; // rows 2p / 2p-1 are column ends
+		if constexpr (W::kEndForms) {
+			const int re = reflect(2 * p, a.H), ro = reflect(2 * p - 1, a.H);
+			vend_e = re == 0 || re == a.H - 1;
+			vend_o = ro == 0 || ro == a.H - 1;
+		}
 		T odd_row[G][NVG], even_row[G][NVG];
 #pragma unroll
 		for (int gi = 0; gi < G; gi++)
@@ -652,8 +681,8 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 				st[3][gi][v] = en;
 			} else {
 				// st: [0] d[p-1], [1] e[p-1]
-				const T en = W::inv_step(0, s2, st[0][gi][v], d2);                // e[p]
-				const T on = W::inv_step(1, st[0][gi][v], st[1][gi][v], en);      // o[p-1]
+				const T en = inv_step_at<W>(0, vend_e, s2, st[0][gi][v], d2);                // e[p]
+				const T on = inv_step_at<W>(1, vend_o, st[0][gi][v], st[1][gi][v], en);      // o[p-1]
 				odd_row[gi][v] = on;
 				even_row[gi][v] = en;
 				st[0][gi][v] = d2;
@@ -670,8 +699,8 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 #pragma unroll
 		for (int gi = 0; gi < G; gi++) {
 			if constexpr (W::kInvColsFirst) {
-				lift_inv_regs<W, NARR>(odd_row[gi]);
-				lift_inv_regs<W, NARR>(even_row[gi]);
+				lift_inv_regs<W, NARR>(odd_row[gi], hends[gi]);
+				lift_inv_regs<W, NARR>(even_row[gi], hends[gi]);
 #pragma unroll
 				for (int v = 0; v < CG; v++) {
 					orow[gi][v] = odd_row[gi][K - 1 + v];

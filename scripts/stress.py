@@ -81,7 +81,8 @@ while time.time() < t_end:
         wav = str(rng.choice(["cdf97_s", "cdf53_i", "cdf53_s"]))
         pitch_b = dwt.lib.dwt_util_get_opt_stride(w_ * 4) if rng.integers(0, 2) else w_ * 4 + 4 * int(rng.integers(0, 4))
         hb = np.zeros(pitch_b * h_ + 8, np.uint8)
-        img = rng.integers(-32768, 32768, (h_, w_)).astype(np.int32) if wav.endswith("_i") else rng.random((h_, w_), dtype=np.float32)
+        lim = 2**31 if rng.integers(0, 2) else 32768
+        img = rng.integers(-lim, lim, (h_, w_)).astype(np.int32) if wav.endswith("_i") else rng.random((h_, w_), dtype=np.float32)
         for y in range(h_):
             hb[y * pitch_b:y * pitch_b + w_ * 4] = img[y].view(np.uint8)
         j = dwt.FORWARD[wav](hb, pitch_b, 4, w_, h_, w_, h_, J, d1)
@@ -97,7 +98,9 @@ while time.time() < t_end:
         if kind == "mallat":
             wav = str(rng.choice(["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"]))
             if wav.endswith("_i"):
-                a = torch.randint(-32768, 32768, (h_, pitch), device="cuda", dtype=torch.int32)
+                # half of the draws over the whole int32 range (the kernels wrap like the reference)
+                lim = 2**31 if rng.integers(0, 2) else 32768
+                a = torch.randint(-lim, lim, (h_, pitch), device="cuda", dtype=torch.int64).to(torch.int32)
             else:
                 a = torch.rand((h_, pitch), device="cuda")
             inplace = bool(rng.integers(0, 2))

@@ -77,3 +77,22 @@ def multichannel_cases():
     z = np.load(os.path.join(GOLDEN, "multichannel.npz"))
     return [(m, z[m["name"] + ".in"], z[m["name"] + ".fwd"], z[m["name"] + ".inv"])
             for m in man["files"]["multichannel.npz"]["cases"]]
+
+
+def full_range_ints(rng, shape):
+    """int32 samples over the WHOLE range: uniform draws mixed with the values where doubled or
+    incremented terms wrap (+-2^30 +- k, +-2^31 -+ k, INT_MIN, INT_MAX), the specials also forced
+    onto the first / last two rows and columns (the line ends have formulas of their own in the
+    reference's int 5/3, src/libdwt.c:10971-10976)."""
+    a = rng.integers(-2**31, 2**31, size=shape, dtype=np.int64)
+    special = np.array([s * (b + k) for b in (2**30, 2**31 - 8) for k in range(-7, 8) for s in (1, -1)]
+                       + [-2**31, 2**31 - 1, -2**31 + 1, 2**31 - 2, 0, 1, -1], dtype=np.int64)
+    special = special[(special >= -2**31) & (special < 2**31)]
+    pick = rng.random(shape) < 0.3
+    a[pick] = rng.choice(special, size=int(pick.sum()))
+    h, w = shape
+    for r in {0, 1, h - 2, h - 1} & set(range(h)):
+        a[r, :] = rng.choice(special, size=w)
+    for c in {0, 1, w - 2, w - 1} & set(range(w)):
+        a[:, c] = rng.choice(special, size=h)
+    return a.astype(np.int32)

@@ -318,6 +318,34 @@ def test_fixed_point_int_inplace_entries(dwt, oracle, shape, j):
     dst.free()
 
 
+@pytest.mark.parametrize("shape", [(2, 2), (5, 4), (37, 53), (64, 65), (300, 513)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_fixed_point_int_inplace_entries_over_the_whole_int32_range(dwt, oracle, shape):
+    """dwt_cdf97_2{f,i}_inplace_i wrap modulo 2^32 like the compiled reference: samples over the whole
+    int32 range, host and device pointers."""
+    from conftest import full_range_ints
+    h, w = shape
+    a = full_range_ints(np.random.default_rng(h * 17 + w), (h, w))
+    for j in (1, -1):
+        want = a.copy()
+        jw = oracle.fwd("cdf97_2f_inplace_i", want, j)
+        rec = want.copy()
+        oracle.inv("cdf97_2i_inplace_i", rec, jw)
+        got = a.copy()
+        assert dwt.dwt_cdf97_2f_inplace_i(got, got.strides[0], 4, w, h, w, h, j, 0) == jw
+        assert np.array_equal(got, want)
+        dwt.dwt_cdf97_2i_inplace_i(got, got.strides[0], 4, w, h, w, h, jw, 0)
+        assert np.array_equal(got, rec)
+        pitch = ((w * 4 + 63) // 64) * 64
+        pad = np.zeros((h, pitch // 4), np.int32)
+        pad[:, :w] = a
+        src = dwt.DeviceImage(h, w, 4, pitch).upload(pad)
+        dst = dwt.DeviceImage(h, w, 4, pitch).upload(np.full_like(pad, 5))
+        assert dwt.transform2d_interleaved("cdf97_i", 0, 0, src.ptr, dst.ptr, pitch, 4, w, h, None, None, j, 0) == jw
+        assert np.array_equal(dst.download(np.int32)[:, :w], want)
+        src.free()
+        dst.free()
+
+
 @pytest.mark.parametrize("case", CASES, ids=IDS)
 def test_golden_fixed_point_int_inplace_host(dwt, case):
     """dwt_cdf97_2f_inplace_i / _2i_inplace_i against the reference's own outputs, host-pointer entry."""

@@ -6,7 +6,7 @@ tolerance the north star allows, which is also asserted explicitly)."""
 import numpy as np
 import pytest
 
-from conftest import bits, golden_cases, multichannel_cases
+from conftest import bits, full_range_ints, golden_cases, multichannel_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -844,6 +844,77 @@ def test_int_single_sample_lines_out_of_place(dwt, oracle, wname, shape):
     assert np.array_equal(a.download(dt)[:, :w], img)
     a.free()
     b.free()
+
+
+@pytest.mark.parametrize("wname", ["cdf53_i", "cdf97_i"])
+@pytest.mark.parametrize("shape", [(2, 2), (2, 3), (3, 5), (5, 4), (8, 8), (37, 53), (64, 65), (65, 64), (300, 513), (514, 301), (1100, 1300), (1027, 2050)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+def test_int_wavelets_over_the_whole_int32_range(dwt, oracle, wname, shape):
+    """Bit-exact for ANY int32 input, not only small ones: the reference's int kernels wrap modulo 2^32
+    and the int 5/3 has line-end formulas of its own (`(d+1)>>1`, `-= s`: src/libdwt.c:10971-10976,
+    11768-11773) that differ from the reflected interior form once the doubled term wraps
+    (|x| >= 2^30).  Samples over the whole range with the wrap points forced onto the borders; odd and
+    even sizes, single- and multi-tile; host entry (fused sweeps and exact line passes), device entry in
+    place and out of place; one level and full depth; rows and columns; forward and inverse."""
+    ff, fi, dt = NAMES[wname]
+    h, w = shape
+    rng = np.random.default_rng(h * 131 + w)
+    wid = dwt.WAVELET_ID[wname]
+    for j_in in (1, -1):
+        img = full_range_ints(rng, (h, w))
+        want = img.copy()
+        jw = oracle.fwd(ff, want, j_in)
+        rec_want = want.copy()
+        oracle.inv(fi, rec_want, jw)
+        for accel in (0, 1):
+            dwt.dwt_util_set_accel(accel)
+            try:
+                got = img.copy()
+                assert dwt.FORWARD[wname](got, got.strides[0], 4, w, h, w, h, j_in) == jw
+                assert np.array_equal(got, want), f"forward, host entry, accel {accel}, j {j_in}"
+                dwt.INVERSE[wname](got, got.strides[0], 4, w, h, w, h, jw)
+                assert np.array_equal(got, rec_want), f"inverse, host entry, accel {accel}, j {j_in}"
+            finally:
+                dwt.dwt_util_set_accel(0)
+        for inplace in (True, False):
+            a = dwt.DeviceImage(h, w).upload(img)
+            b = a if inplace else dwt.DeviceImage(h, w).upload(np.zeros_like(img))
+            assert dwt._fwd(wid, a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, j_in, 0, 0, "fwd") == jw
+            assert np.array_equal(b.download(dt), want), f"forward, device entry, inplace {inplace}, j {j_in}"
+            dwt._inv(wid, b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, jw, 0, 0, "inv")
+            assert np.array_equal(a.download(dt), rec_want), f"inverse, device entry, inplace {inplace}, j {j_in}"
+            a.free()
+            if b is not a:
+                b.free()
+    if wname == "cdf53_i":
+        assert np.array_equal(rec_want, img), "the int 5/3 is reversible over the whole range"
+
+
+def test_int_tile_variants_agree_over_the_whole_int32_range(dwt, oracle):
+    """The line ends fall into different lanes / tiles / ring slots with every tile geometry."""
+    h, w = 515, 1030
+    img = full_range_ints(np.random.default_rng(99), (h, w))
+    want = img.copy()
+    jw = oracle.fwd("cdf53_2f_i", want, 3)
+    wid = dwt.WAVELET_ID["cdf53_i"]
+    try:
+        for cpt in (4, 8):
+            for tp in (2, 8, 64):
+                for waves in (1, 4):
+                    dwt.set_option("cpt", cpt)
+                    dwt.set_option("tile_pairs", tp)
+                    dwt.set_option("waves", waves)
+                    a = dwt.DeviceImage(h, w).upload(img)
+                    b = dwt.DeviceImage(h, w).upload(np.zeros_like(img))
+                    assert dwt._fwd(wid, a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, 3, 0, 0, "fwd") == jw
+                    assert np.array_equal(b.download(np.int32), want), (cpt, tp, waves)
+                    dwt._inv(wid, b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, jw, 0, 0, "inv")
+                    assert np.array_equal(a.download(np.int32), img), (cpt, tp, waves)
+                    a.free()
+                    b.free()
+    finally:
+        for k, v in (("cpt", 0), ("tile_pairs", 0), ("waves", 4)):
+            dwt.set_option(k, v)
 
 
 def test_randomised_soak():

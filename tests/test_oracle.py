@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, bits, golden_cases, multichannel_cases
+from conftest import GOLDEN, bits, full_range_ints, golden_cases, multichannel_cases
 from oraclelib import ENTRIES
 
 WAVELETS = {
@@ -87,6 +87,27 @@ def test_oracle_bitwise_equals_reference(oracle, reference, wname):
             oracle.inv(fi, a, jo, decompose_one=d1)
             reference.inv(fi, b, jr, decompose_one=d1)
             assert np.array_equal(bits(a), bits(b)), (h, w, j, d1)
+
+
+@pytest.mark.parametrize("ff,fi", [("cdf53_2f_i", "cdf53_2i_i"), ("cdf97_2f_i", "cdf97_2i_i"),
+                                   ("cdf97_2f_inplace_i", "cdf97_2i_inplace_i")])
+def test_oracle_equals_reference_over_the_whole_int32_range(oracle, reference, ff, fi):
+    """The int kernels wrap modulo 2^32 in the compiled reference; the int 5/3 line ends
+    (`(d+1)>>1`, `-= s`: src/libdwt.c:10971-10976, 11768-11773) are NOT the reflected interior form
+    once a doubled term wraps.  Oracle == reference bit for bit on samples over the whole range,
+    odd / even sizes, forward and inverse."""
+    rng = np.random.default_rng(2024)
+    for (h, w) in [(2, 2), (3, 5), (5, 4), (8, 8), (37, 53), (64, 65), (130, 97)]:
+        for j in (1, -1):
+            a = full_range_ints(rng, (h, w))
+            b = a.copy()
+            jo = oracle.fwd(ff, a, j)
+            jr = reference.fwd(ff, b, j)
+            assert jo == jr
+            assert np.array_equal(a, b), (ff, h, w, j)
+            oracle.inv(fi, a, jo)
+            reference.inv(fi, b, jr)
+            assert np.array_equal(a, b), (fi, h, w, j)
 
 
 def test_reference_accel_variants_agree(reference):

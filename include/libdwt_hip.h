@@ -62,6 +62,11 @@ const char *dwt_hip_last_error(void);
 
 /* Run on this hipStream_t (NULL = the default stream). */
 void dwt_hip_set_stream(void *hip_stream);
+/* The running-LL scratch of the 2-D Mallat drivers (two bands: the level-1 band, ceil(W/2) x ceil(H/2)
+ * elements per image, and the level-2 band) in memory the CALLER owns and places -- the library then
+ * neither grows nor frees it (a call that needs more fails).  Two NULLs hand the scratch back to the
+ * library.  Per thread, like the rest of the context. */
+int dwt_hip_set_workspace(void *band0, size_t bytes0, void *band1, size_t bytes1);
 void dwt_hip_sync(void);
 
 /* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).

@@ -65,6 +65,20 @@ lib.dwt_hip_get_device.restype = _I
 lib.dwt_hip_device_name.restype = C.c_char_p
 lib.dwt_hip_last_error.restype = C.c_char_p
 lib.dwt_hip_set_stream.argtypes = [_P]
+lib.dwt_hip_set_workspace.argtypes = [_P, C.c_size_t, _P, C.c_size_t]
+lib.dwt_hip_set_workspace.restype = _I
+lib.dwt_hip_probe_pair_us.argtypes = [_P, _P, C.c_size_t]
+lib.dwt_hip_probe_pair_us.restype = C.c_double
+lib.dwt_hip_probe_copy_us.argtypes = [_P, _P, C.c_size_t]
+lib.dwt_hip_probe_copy_us.restype = C.c_double
+lib.dwt_hip_malloc_mapped.argtypes = [C.c_size_t, C.c_size_t, _I, C.c_size_t]
+lib.dwt_hip_malloc_mapped.restype = _P
+lib.dwt_hip_free_mapped.argtypes = [_P]
+lib.dwt_hip_alloc_placed.argtypes = [C.POINTER(C.c_size_t), _I, C.POINTER(C.c_size_t), _I, C.POINTER(_P), C.POINTER(_P)]
+lib.dwt_hip_alloc_placed.restype = _I
+lib.dwt_hip_placed_stats.argtypes = [C.POINTER(_I)] * 3 + [C.POINTER(C.c_double)] * 3
+lib.dwt_hip_malloc_spread.argtypes = [C.c_size_t, C.c_size_t]
+lib.dwt_hip_malloc_spread.restype = _P
 lib.dwt_hip_set_option.argtypes = [C.c_char_p, _I]
 lib.dwt_hip_set_option.restype = _I
 lib.dwt_hip_get_option.argtypes = [C.c_char_p]
@@ -545,3 +559,21 @@ def prof_read():
     ms, n = C.c_double(0), _I(0)
     _check(lib.dwt_hip_prof_read(C.byref(ms), C.byref(n)), "dwt_hip_prof_read")
     return ms.value, n.value
+
+
+def alloc_placed(bytes_a, bytes_b):
+    """Device buffers of two different physical classes (dwt_hip_alloc_placed): `bytes_a` sizes from one
+    class, `bytes_b` from another.  Returns (pointers_a, pointers_b, stats); free each with
+    lib.dwt_hip_free_mapped."""
+    na, nbb = len(bytes_a), len(bytes_b)
+    a = (C.c_size_t * max(na, 1))(*bytes_a)
+    b = (C.c_size_t * max(nbb, 1))(*bytes_b)
+    oa = (_P * max(na, 1))()
+    ob = (_P * max(nbb, 1))()
+    _check(lib.dwt_hip_alloc_placed(a, na, b, nbb, oa, ob), "dwt_hip_alloc_placed")
+    w, s_, o = _I(), _I(), _I()
+    lo, hi, sec = C.c_double(), C.c_double(), C.c_double()
+    lib.dwt_hip_placed_stats(C.byref(w), C.byref(s_), C.byref(o), C.byref(lo), C.byref(hi), C.byref(sec))
+    stats = {"chunks_walked": w.value, "same_class": s_.value, "other_class": o.value,
+             "probe_us_fastest": round(lo.value, 1), "probe_us_slowest": round(hi.value, 1), "seconds": round(sec.value, 2)}
+    return [oa[i] for i in range(na)], [ob[i] for i in range(nbb)], stats

@@ -32,6 +32,7 @@ struct Ctx {
 	size_t stage_bytes = 0;
 	void *ll[2] = {nullptr, nullptr}; // LL ping-pong
 	size_t ll_bytes[2] = {0, 0};
+	bool ll_external = false; // the caller owns the LL scratch (dwt_hip_set_workspace): never grown, never freed
 	void *host_a = nullptr, *host_b = nullptr; // device images for host-pointer calls
 	size_t host_a_bytes = 0, host_b_bytes = 0;
 	void *vol_out = nullptr; // dense result volume of an in-place 3-D forward call (fused levels, then copied back)
@@ -67,6 +68,8 @@ struct Ctx {
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
 	int inplace_overlap = 0; // 1: the copy-back (forward) / copy-aside (inverse) of an in-place call on a side stream beside the deeper levels (measured 8-10 us slower than in line)
 	int il_lazy_strips = 1; // interleaved 9/7 forward: the exact border strips on the side stream beside the next level's sweep (0: in line)
+	long ll_offset = 0; // bytes between the start of an LL scratch allocation and the band (placement experiments)
+	int ll_pad = 0; // elements added to the row pitch of the LL scratch bands (placement experiments)
 	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
 	// profiling
 	int prof_on = 0;

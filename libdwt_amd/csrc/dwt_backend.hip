@@ -440,19 +440,27 @@ void swap_lane(Ctx::Lane &l)
 	std::swap(g.stage_bytes, l.stage_bytes);
 }
 
-long ll_pitch_elems(int w) { return align_up(w, 4); }
+long ll_pitch_elems(int w) { return align_up(w, 4) + g.ll_pad; }
+static char *ll_band(int k) { return (char *)g.ll[k] + g.ll_offset; }
 
 int ensure_ll(const Geom &ge, int batch, int es)
 {
 	for (int k = 0; k < 2; k++) {
 		const int w = ge.Wo(k + 1), h = ge.Ho(k + 1);
-		if (grow(&g.ll[k], &g.ll_bytes[k], (size_t)ll_pitch_elems(w) * h * es * batch + 64))
+		if (g.ll_external) {
+			if (g.ll_bytes[k] < (size_t)ll_pitch_elems(w) * h * es * batch + 64 + (size_t)g.ll_offset)
+				return fail("the caller's workspace (dwt_hip_set_workspace) is too small: band %d needs %zu bytes", k,
+					(size_t)ll_pitch_elems(w) * h * es * batch + 64 + (size_t)g.ll_offset);
+			continue;
+		}
+		if (grow(&g.ll[k], &g.ll_bytes[k], (size_t)ll_pitch_elems(w) * h * es * batch + 64 + (size_t)g.ll_offset))
 			return 1;
 	}
 	return 0;
 }
 
 thread_local bool g_elems_are_32bit = true;
+extern thread_local int g_placed_prefer;
 
 // the fused sweeps exist for the 32-bit types and, since round 2, for the double-precision wavelets
 // (dwt_sweep2d_d.hip; option "fused_d" = 0 sends those back to the exact line passes)
@@ -497,7 +505,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				a.in_bstride = (cur.p == src.p ? src_bstride : dst_bstride) / es;
 				detour = (cur.p == dst.p); // reading the image we also write: stage the outputs
 			} else {
-				a.in = g.ll[ll_in];
+				a.in = ll_band(ll_in);
 				a.in_pitch = ll_pitch_elems(Wo);
 				a.in_bstride = a.in_pitch * Ho;
 			}
@@ -522,7 +530,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				a.ll_pitch = a.h_pitch;
 				a.ll_bstride = a.h_bstride;
 			} else {
-				a.out_ll = g.ll[ll_out];
+				a.out_ll = ll_band(ll_out);
 				a.ll_pitch = ll_pitch_elems(Wd);
 				a.ll_bstride = a.ll_pitch * Hd;
 			}
@@ -552,7 +560,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			return fail("batched transforms need dense frames with both sides >= 2 at every level");
 		if (ll_in >= 0) {
 			// bring the LL band back into the image
-			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Wo) * es, es};
+			Img s{ll_band(ll_in), ll_pitch_elems(Wo) * es, es};
 			if (copy_rect(dst, 0, 0, s, 0, 0, Wo, Ho))
 				return 1;
 			ll_in = -1;
@@ -658,7 +666,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				a.ll_pitch = cur.sx / es;
 				a.ll_bstride = cur_bstride / es;
 			} else {
-				a.in_ll = g.ll[ll_in];
+				a.in_ll = ll_band(ll_in);
 				a.ll_pitch = ll_pitch_elems(Ws);
 				a.ll_bstride = a.ll_pitch * Hs;
 			}
@@ -691,7 +699,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				}
 			} else {
 				ll_out = j & 1; // band of level m = j-1 lives in scratch (m-1)&1, as in the forward driver
-				a.out = g.ll[ll_out];
+				a.out = ll_band(ll_out);
 				a.out_pitch = ll_pitch_elems(Wo);
 				a.out_bstride = a.out_pitch * Ho;
 			}
@@ -718,7 +726,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 		cur_bstride = dst_bstride;
 		if (ll_in >= 0) {
 			// a deeper fused level left its result in scratch: bring it back into the image
-			Img s{(char *)g.ll[ll_in], ll_pitch_elems(Ws) * es, es};
+			Img s{ll_band(ll_in), ll_pitch_elems(Ws) * es, es};
 			if (copy_rect(dst, 0, 0, s, 0, 0, Ws, Hs))
 				return 1;
 			ll_in = -1;
@@ -832,6 +840,10 @@ void dwt_hip_finish(void)
 	if (!g.inited)
 		return;
 	hipStreamSynchronize(g.stream);
+	if (g.ll_external) {
+		g.ll[0] = g.ll[1] = nullptr;
+		g.ll_external = false;
+	}
 	void **bufs[] = {&g.stage_img, &g.ll[0], &g.ll[1], &g.host_a, &g.host_b, &g.vol_out, &g.vol_host[0], &g.vol_host[1]};
 	for (void **b : bufs) {
 		if (*b)
@@ -876,6 +888,35 @@ const char *dwt_hip_device_name(void)
 
 void dwt_hip_set_stream(void *s) { g.stream = (hipStream_t)s; }
 
+int dwt_hip_set_workspace(void *band0, size_t bytes0, void *band1, size_t bytes1)
+{
+	if (check_inited())
+		return 1;
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (!g.ll_external) {
+		for (int k = 0; k < 2; k++) {
+			if (g.ll[k])
+				HIP_TRY(hipFree(g.ll[k]));
+			g.ll[k] = nullptr;
+			g.ll_bytes[k] = 0;
+		}
+	}
+	if (!band0 || !band1) {
+		g.ll[0] = g.ll[1] = nullptr;
+		g.ll_bytes[0] = g.ll_bytes[1] = 0;
+		g.ll_external = false;
+		return 0;
+	}
+	if (!dwt_hip_is_device_pointer(band0) || !dwt_hip_is_device_pointer(band1) || ((uintptr_t)band0 & 15) || ((uintptr_t)band1 & 15))
+		return fail("dwt_hip_set_workspace takes two 16-byte aligned device buffers");
+	g.ll[0] = band0;
+	g.ll[1] = band1;
+	g.ll_bytes[0] = bytes0;
+	g.ll_bytes[1] = bytes1;
+	g.ll_external = true;
+	return 0;
+}
+
 void dwt_hip_sync(void)
 {
 	if (g.inited)
@@ -918,6 +959,12 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fma = value;
 	else if (!strcmp(name, "fused_d"))
 		g.fused_d = value;
+	else if (!strcmp(name, "ll_offset_kib"))
+		g.ll_offset = value < 0 ? 0 : (long)value * 1024;
+	else if (!strcmp(name, "placed_prefer"))
+		g_placed_prefer = value;
+	else if (!strcmp(name, "ll_pad"))
+		g.ll_pad = value < 0 ? 0 : (value + 3) / 4 * 4;
 	else if (!strcmp(name, "inplace_overlap"))
 		g.inplace_overlap = value;
 	else if (!strcmp(name, "vol_cpt"))

@@ -16,9 +16,14 @@ the barrier and the max-over-ranks only.  value = total samples / slowest rank's
     python bench.py --gpus N ...        # starts the N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Before the warm-up every rank picks the PLACEMENT of its shard: the sweeps' rate depends on which
-physical memory backs the two buffers, so up to `--placements` allocations are tried
-(three untimed steps each) and the fastest kept; the attempts are reported in the line (`placement`).
+PLACEMENT.  The sweeps' rate depends on which physical memory backs source, destination and the
+library's LL scratch relative to each other (profiles/r04_placement.md).  The library places
+what it allocates (dwt_hip_alloc_batch: up to `--placements` candidates of destination + scratch, each
+timed with the first two levels of the batch's own transform, untimed for the benchmark); the bench
+allocates its shard through it, as a caller that keeps a batch resident would.  Beside `value` the line
+carries `value_first_placement`: a short run (5 steps) on PLAIN first allocations with the library's
+search off -- what a caller that ignores placement gets in this process.  `--placements 1` makes that
+the whole run.
 
 Prints ONE JSON line on rank 0.  For N > 1 the line also carries `batch_split`: the time to
 scatter the whole batch from rank 0 and gather the coefficients back over RCCL (grouped
@@ -360,11 +365,124 @@ def cpu_baseline(size, levels):
                 rows.append({"threads": threads, "pitch_bytes": pitch_elems * 4, "accel": accel, "workers": workers,
                              "gsamples_per_s": round(size * size / best / 1e9, 3), "best_s": round(best, 4), "runs": timed})
     top = max(rows, key=lambda r: r["gsamples_per_s"])
-    return {"value": top["gsamples_per_s"], "unit": "Gsamples/s", "cores": top["threads"], "kind": kind,
+    return {"value": top["gsamples_per_s"], "unit": "Gsamples/s", "cores": top["threads"], "kind": kind, "cpu_model": cpu_model(),
             "sample": f"1 image {size}x{size} float, {levels} levels, dwt_cdf97_2f_s in place, best single run per row "
                       f"(dwt_util_perf protocol, M=1); value = best row: {top['threads']} OpenMP threads, pitch "
                       f"{top['pitch_bytes']} B, accel {top['accel']} / {top['workers']} workers",
             "rows": rows}
+
+
+def cpu_model():
+    """Model string and logical CPU count of the host (BASELINE.md s4.5 asks for it beside every CPU figure)."""
+    name = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                name = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return f"{name} ({os.cpu_count()} logical CPUs on the host)"
+
+
+def _cpu_env():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("BENCH_CPU_THREADS", min(avail, 16)))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    import oraclelib
+
+    kind = "reference"
+    try:
+        if not os.path.exists(oraclelib.REF_SO):
+            raise FileNotFoundError
+        lib = oraclelib.Reference()
+    except Exception:
+        kind = "port"
+        lib = oraclelib.Oracle()
+    return lib, kind, cores
+
+
+def cpu_baseline_config3(n, J):
+    """BASELINE config 3 on the host cores: libdwt's dwt_cdf53_2f_i + dwt_cdf53_2i_i (src/libdwt.c:16304,
+    18142) on ONE n x n int32 image, protocol of dwt_util_perf_cdf53_2_i (src/libdwt.c:21262: minimum over
+    runs of forward + inverse, M = 1), rows = {1 thread, this GPU's host cores} x {dense pitch,
+    dwt_util_get_stride pitch}; bounded to ~1.5 s or 8 runs per row (a single run where one takes > 2 s)."""
+    import numpy as np
+
+    lib, kind, cores = _cpu_env()
+    rng = np.random.default_rng(7)
+    src = rng.integers(-32768, 32768, size=(n, n), dtype=np.int32)
+    pitches = [n, n + 144] if n % 1024 == 0 else [n]
+    rows = []
+    for pe in pitches:
+        buf = np.zeros((n, pe), np.int32)
+        for threads in sorted({1, cores}):
+            if kind == "reference":
+                lib.lib.dwt_util_set_accel(0)
+                lib.lib.dwt_util_set_num_workers(1)
+                lib.lib.dwt_util_set_num_threads(threads)
+            else:
+                lib.set_threads(threads)
+            best, runs, timed, t_start = None, 0, 0, time.perf_counter()
+            while runs < 9 and (timed < 2 or time.perf_counter() - t_start < 1.5):
+                buf[:, :n] = src
+                t0 = time.perf_counter()
+                j = lib.fwd("cdf53_2f_i", buf[:, :n], J)
+                lib.inv("cdf53_2i_i", buf[:, :n], j)
+                dt = time.perf_counter() - t0
+                runs += 1
+                if runs > 1 or dt > 2.0:
+                    best = dt if best is None else min(best, dt)
+                    timed += 1
+                if dt > 2.0:
+                    break
+            rows.append({"threads": threads, "pitch_bytes": pe * 4, "gsamples_per_s": round(n * n / best / 1e9, 4), "best_s": round(best, 4), "runs": timed})
+    top = max(rows, key=lambda r: r["gsamples_per_s"])
+    return {"value": top["gsamples_per_s"], "unit": "Gsamples/s", "cores": top["threads"], "kind": kind, "cpu_model": cpu_model(),
+            "sample": f"1 image {n}x{n} int32, {J} levels, dwt_cdf53_2f_i + dwt_cdf53_2i_i in place (one forward + inverse pair counts "
+                      f"n^2 samples, as in `value`), best run per row; value = best row: {top['threads']} OpenMP threads, pitch {top['pitch_bytes']} B",
+            "rows": rows}
+
+
+def cpu_baseline_config5(n):
+    """BASELINE config 5 on the host: libdwt's cdf97_3f_op_sep_horizontal_s (src/volume-dwt.c:727; the schedule
+    volume_perftest_fwd97op_s times, :2810-2881) on ONE n^3 float volume, ONE level -- the reference has no
+    multi-level 3-D driver and no OpenMP in src/volume-dwt.c, so this is one thread whatever the host; minimum of
+    two runs (the perf test's protocol: min over runs of secs per voxel)."""
+    import ctypes as C
+
+    import numpy as np
+
+    lib, kind, _cores = _cpu_env()
+
+    class Vol(C.Structure):
+        _fields_ = [("size_x", C.c_int), ("size_y", C.c_int), ("size_z", C.c_int), ("stride_x", C.c_size_t),
+                    ("stride_y", C.c_size_t), ("stride_z", C.c_size_t), ("data", C.c_void_p)]
+
+    def vol(a):
+        return Vol(a.shape[2], a.shape[1], a.shape[0], a.strides[2], a.strides[1], a.strides[0], a.ctypes.data)
+
+    v = np.random.default_rng(1234).random((n, n, n), dtype=np.float32)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        if kind == "reference":
+            d = np.empty_like(v)
+            lib.lib.cdf97_3f_op_sep_horizontal_s(C.byref(vol(v)), C.byref(vol(d)))
+        else:
+            d = v.copy()
+            lib.vol("cdf97_3f_s", d)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(n ** 3 / best / 1e9, 5), "unit": "Gvoxels/s", "cores": 1, "kind": kind, "cpu_model": cpu_model(),
+            "sample": f"1 volume {n}^3 float, ONE level, cdf97_3f_op_sep_horizontal_s out of place, best of 2 runs "
+                      f"({best:.2f} s = {best / n ** 3 * 1e9:.2f} ns per voxel; single-threaded code in the reference)"}
 
 
 def _profile_traffic(l0_bytes, n):
@@ -438,6 +556,26 @@ def single_image_stats(torch, dwt, src, dst, n, J):
     return out
 
 
+def shard_sweep(torch, dwt, src, dst, n, J, nb):
+    """Strong-scaling projection measured on ONE GPU (the transform has no collective: at N ranks every rank
+    runs the same batched call on B/N images, so the N-rank step takes what a B/N-image call takes here):
+    the step timed at B, B/2, B/4 and B/8 images per call on the resident, placed batch (HIP events,
+    10 calls after 3 warm-up calls each), efficiency = rate(B/N) / rate(B), projected speed-up = N x that."""
+    img_bytes = n * n * 4
+    rows, rate = [], {}
+    for div in (1, 2, 4, 8):
+        k = nb // div
+        if k < 1 or nb % div:
+            continue
+        ms = _event_times(torch, lambda i: dwt.transform2d_batch("cdf97_s", 0, src[:k], dst[:k], img_bytes, k, n * 4, n, n, J), 10, 3)
+        med = statistics.median(ms)
+        rate[div] = k * n * n / (med * 1e-3) / 1e9
+        rows.append({"ranks": div, "images_per_call": k, "ms_per_step": round(med, 4), "gsamples_per_s_per_gpu": round(rate[div], 2),
+                     "efficiency": round(rate[div] / rate[1], 4)})
+    proj = {str(d): round(d * rate[d] / rate[1], 3) for d in rate if d > 1}
+    return rows, proj
+
+
 def batch_split_times(torch, plane, src, total, n, rank, world, dev):
     """Scatter the whole batch from rank 0 and gather it back (libdwt_amd.batch, grouped
     point-to-point over RCCL/xGMI): the cost of a batch that starts and ends on one GPU."""
@@ -474,6 +612,15 @@ def batch_split_times(torch, plane, src, total, n, rank, world, dev):
     return {"scatter_ms": round(sc, 3), "gather_ms": round(ga, 3), "bytes_each_way": int(b),
             "scatter_GBps": round(b / sc / 1e6, 1), "gather_GBps": round(b / ga / 1e6, 1),
             "how": "rank 0 -> all ranks and back, grouped isend/irecv (batch_isend_irecv), root-egress bound"}
+
+
+def raw_tensor(torch, dev, ptr, shape):
+    """A torch view of device memory the library allocated (CUDA array interface)."""
+    class _Dev:
+        pass
+    o = _Dev()
+    o.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None}
+    return torch.as_tensor(o, device=dev)
 
 
 def choose_placement(torch, dev, tries, make, run):
@@ -582,7 +729,30 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
             det = float(o[1::2].abs().max())
             return {"constant_volume_ok": bool(det < 1e-5 and float((lll - 3.0 * 2 ** 1.5).abs().max()) < 1e-4)}
 
-    bufs, _spacer, placement = choose_placement(torch, dev, min(args.placements, 3), make, run)
+    if w == "config4" and args.placements > 1:
+        # a resident 2-D batch: through the library's placement-aware allocator, like the headline; attempt 0 =
+        # plain first allocations with the library's own search off
+        dwt.set_option("place_tries", 1)
+        plain = make()
+        run(plain)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run(plain)
+        torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) / 3 * 1e3
+        plain = None
+        dwt.dwt_util_finish()
+        torch.cuda.empty_cache()
+        dwt.set_option("place_tries", args.placements)
+        p_src, p_dst = dwt.alloc_batch("cdf97_s", nb, n, n, J)
+        bufs = (raw_tensor(torch, dev, p_src, (nb, n, n)), raw_tensor(torch, dev, p_dst, (nb, n, n)))
+        gen.manual_seed(1234 + rank)
+        torch.rand((nb, n, n), generator=gen, out=bufs[0])
+        placement = {"by": "dwt_hip_alloc_batch", "attempts": [{"spacer_GiB": 0, "ms_per_step": round(first_ms, 4)}]}
+        placement.update(dwt.alloc_batch_report())
+    else:
+        bufs, _spacer, placement = choose_placement(torch, dev, min(args.placements, 3), make, run)
 
     def step():
         run(bufs)
@@ -609,7 +779,13 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
     ach = alg * args.steps / elapsed / 1e9
     cfg = {"workload": name, "parallelism": f"batch-sharded x{world}"}
     cfg.update(checks)
-    return {
+    cpu = None
+    if world == 1 and not args.no_cpu and w in ("config3", "config5"):
+        try:
+            cpu = cpu_baseline_config3(n, J) if w == "config3" else cpu_baseline_config5(512)
+        except Exception as e:  # noqa: BLE001 -- the checker is optional equipment of the bench
+            cpu = {"value": None, "unit": unit, "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
+    line = {
         "metric": metric, "value": round(units * args.steps / elapsed / 1e9, 3), "unit": unit, "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
@@ -618,7 +794,12 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "whole step (all levels) on rank 0: algorithmic bytes / step time"},
         "placement": placement,
+        # attempt 0 of the placement choice = plain first allocations (3 untimed steps): what a caller that ignores placement gets
+        "value_first_placement": round(units / (placement["attempts"][0]["ms_per_step"] * 1e-3) / 1e9, 3),
     }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    return line
 
 
 def run_rank(args):
@@ -692,46 +873,52 @@ def run_rank(args):
                 c = min(chunk, nb - k)
                 dwt.transform2d_batch("cdf97_s", 0, src[k:k + c], dst[k:k + c], img_bytes, c, n * 4, n, n, J)
 
-    # Placement of the batch (untimed, before the warm-up).  The rate of the SAME binary on the SAME
-    # virtual addresses depends on which physical memory backs the two buffers: scripts/probes/r03_state_probe.py
-    # and r03_alloc_probe*.py show the level-0 kernel at 5.2, 5.4, 5.75 or 6.1 TB/s from one allocation of
-    # the batch to the next inside one process (a plain device copy between the same buffers does not
-    # move) -- DESIGN s5 "fast / slow state".  A caller who keeps a batch resident picks its buffers once;
-    # so does the bench: up to `--placements` allocations of the batch (behind spacers of different sizes),
-    # three untimed steps each, and the one whose level-0 launches ran fastest is kept.  Every attempt is
-    # reported in the line (`placement`); `--placements 1` turns the choice off.
-    spacers_gib = [0, 7, 2.6, 50]
-    tried, keep = [], []
-    for k in range(max(1, args.placements)):
-        sp_gib = spacers_gib[k % len(spacers_gib)]
-        free_b, _total_b = torch.cuda.mem_get_info(dev)
-        need = 2 * nb * img_bytes + int(sp_gib * (1 << 30)) + (8 << 30)
-        if k > 0 and free_b < need:
-            break
-        spacer = torch.empty(int(sp_gib * (1 << 30)), dtype=torch.uint8, device=dev) if sp_gib else None
-        s_k = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
-        d_k = s_k.clone() if args.inplace else torch.empty_like(s_k)
-        run_once(s_k, d_k)
-        torch.cuda.synchronize()
+    # ---- first placement: plain allocations, the library's placement search off (reported beside `value`) ----
+    def level0_rate(fn, reps):
         dwt.prof_enable(True)
-        for _ in range(3):
-            run_once(s_k, d_k)
+        for _ in range(reps):
+            fn()
         torch.cuda.synchronize()
         p_ms, p_n = dwt.prof_read()
         dwt.prof_enable(False)
-        rate = 2 * 4 * n * n * (1 if args.inplace else min(chunk, nb)) / (p_ms / max(p_n, 1) * 1e-3) / 1e9 if p_n else 0.0
-        tried.append({"spacer_GiB": sp_gib, "level0_GBps": round(rate, 1)})
-        keep.append((rate, spacer, s_k, d_k))
-        if rate >= 0.74 * HBM_PEAK_GBS or args.placements <= 1:
-            break
-    best = max(range(len(keep)), key=lambda i: keep[i][0])
-    _, _spacer_kept, src, dst = keep[best]  # (the spacer stays allocated: it is what holds the placement)
-    for i, (_, sp_i, s_i, d_i) in enumerate(keep):
-        if i != best:
-            del sp_i, s_i, d_i
-    keep = None
-    torch.cuda.empty_cache()
-    placement = {"attempts": tried, "chosen": best, "how": "untimed: level-0 rate of 3 steps per candidate allocation of the batch; DESIGN s5"}
+        per = 1 if args.inplace else min(chunk, nb)
+        return 2 * 4 * n * n * per / (p_ms / max(p_n, 1) * 1e-3) / 1e9 if p_n else 0.0
+
+    first = None
+    placed = args.placements > 1 and not args.inplace
+    dwt.set_option("place_tries", 1)
+    src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
+    dst = src.clone() if args.inplace else torch.empty_like(src)
+    for _ in range(2):
+        run_once(src, dst)
+    torch.cuda.synchronize()
+    if placed:
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run_once(src, dst)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        first = {"gsamples_per_s_this_rank": round(nb * n * n / dt / 1e9, 2), "ms_per_step": round(dt * 1e3, 4),
+                 "level0_GBps": round(level0_rate(lambda: run_once(src, dst), 3), 1),
+                 "how": "plain first allocations of the shard and of the library's scratch, no placement search, 5 steps (untimed for `value`)"}
+        # ---- the placed shard: dwt_hip_alloc_batch (destination + scratch chosen by timing), same data ----
+        src = dst = None
+        dwt.dwt_util_finish()  # drops the plainly placed scratch
+        torch.cuda.empty_cache()
+        dwt.set_option("place_tries", args.placements)
+        t0 = time.perf_counter()
+        p_src, p_dst = dwt.alloc_batch("cdf97_s", nb, n, n, J)
+        alloc_s = time.perf_counter() - t0
+        src, dst = raw_tensor(torch, dev, p_src, (nb, n, n)), raw_tensor(torch, dev, p_dst, (nb, n, n))
+        gen.manual_seed(1234 + rank)
+        torch.rand((nb, n, n), generator=gen, out=src)
+        placement = {"by": "dwt_hip_alloc_batch", "seconds_total": round(alloc_s, 2)}
+        placement.update(dwt.alloc_batch_report())
+        placement["how"] = ("untimed: an arena of most of the free memory; the destination tried at every 4 GiB step (one level against "
+                            "the source), the LL scratch at every step for the three best destinations (the shard's transform itself); "
+                            "the best arrangement kept, the rest of the arena returned; DESIGN s5")
+    else:
+        placement = {"by": "none (--placements 1 or --inplace): plain first allocations"}
 
     def step():
         run_once(src, dst)
@@ -802,11 +989,21 @@ def run_rank(args):
                          "bytes_per_launch": l0_bytes, "avg_launch_ms": round(l0_ms, 5), "launches": k_launches},
         }
         out["placement"] = placement
+        if first is not None:
+            # whole-job figure of the first placement: this rank's shard rate x ranks (each rank measured its own; rank 0's is shown)
+            out["value_first_placement"] = round(first["gsamples_per_s_this_rank"] * world, 3)
+            out["first_placement"] = first
         if use_dist:
             out["control_plane"] = control
         if shared:
             out["devices_shared"] = True
         STATE["line"] = dict(out)  # from here on the watchdog has something to print
+        if world == 1 and not args.inplace and not args.no_sweep and chunk >= nb:
+            try:
+                out["shard_sweep"], out["projected_scaling"] = shard_sweep(torch, dwt, src, dst, n, J, nb)
+            except Exception as e:  # noqa: BLE001
+                out["shard_sweep"] = {"error": f"{type(e).__name__}: {e}"}
+            STATE["line"] = dict(out)
         if not args.no_single and not args.inplace:
             try:
                 out["single_image"] = single_image_stats(torch, dwt, src, dst, n, J)
@@ -889,9 +1086,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="images per batched call (0 = the rank's whole shard)")
     ap.add_argument("--inplace", action="store_true", help="time the in-place entry dwt_cdf97_2f_s instead of _s2")
     ap.add_argument("--placements", type=int, default=4,
-                    help="candidate allocations of the batch tried before the warm-up, the fastest kept (1 = take the first)")
+                    help="candidates of (destination, LL scratch) the library's placement-aware allocator may time (1 = plain first allocations)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-image entry timings")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the shard-size sweep (N = 1)")
     ap.add_argument("--no-split", action="store_true", help="skip the RCCL scatter/gather timing (N > 1)")
     ap.add_argument("--timeout", type=float, default=420.0,
                     help="whole-run deadline in seconds: the launcher terminates its ranks, a rank prints what it has and leaves")

@@ -69,6 +69,28 @@ void dwt_hip_set_stream(void *hip_stream);
 int dwt_hip_set_workspace(void *band0, size_t bytes0, void *band1, size_t bytes1);
 void dwt_hip_sync(void);
 
+/* Placement.  The rate of a forward level depends on where in PHYSICAL memory its three streams lie
+ * relative to each other (source rows, detail subbands, running LL band: DESIGN.md s5,
+ * profiles/r04_placement.md).  The reference hands its callers a placement-aware allocator for the same
+ * kind of reason -- dwt_util_get_opt_stride / dwt_util_get_stride, src/libdwt.c:20641-20707 -- and so does
+ * this library:
+ *   - the library's own LL scratch: the first forward call (batch or single image, distinct source and
+ *     destination, two levels or more) that needs "place_min_mib" (option, default 1024) MiB or more of it
+ *     tries up to "place_tries" (option, default 4; 1 = off) allocations, times the call itself on each
+ *     and keeps the fastest.  Once per size; later calls allocate nothing and never
+ *     synchronise.  dwt_hip_placement_report returns what the last search measured (ms per candidate,
+ *     return value = number of candidates, 0 = no search ran).
+ *   - dwt_hip_alloc_batch: source and destination of a resident batch of `n_images` dense size_x x size_y
+ *     images (pitch size_x elements, images size_x * size_y elements apart) together with the scratch, placed
+ *     by measurement: most of the card's free memory is mapped as one arena, the destination is tried at
+ *     every 4 GiB step of it (one level against the source), the scratch at every step for the best
+ *     destinations (the `levels`-level forward transform of the whole batch; < 0: full depth), the best
+ *     arrangement is kept and the rest of the arena returned.  Seconds, once, for a batch that stays
+ *     resident; dwt_hip_alloc_batch_report says what was measured.  Free both with dwt_hip_free. */
+int dwt_hip_alloc_batch(int wavelet, int n_images, int size_x, int size_y, int levels, void **src, void **dst);
+int dwt_hip_placement_report(double *ms, int n);
+void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int *dst_at, int *ll_at, double *ms4, double *seconds);
+
 /* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).
  * Names: "generic" (1 = force the exact line-pass kernels), "cpt" (0/4/8),
  * "wave_horiz" (0/1), "ring" (8/16), "nt" and "nt_inv" (bit 0 nt stores, bit 1 nt loads),

@@ -67,6 +67,11 @@ lib.dwt_hip_last_error.restype = C.c_char_p
 lib.dwt_hip_set_stream.argtypes = [_P]
 lib.dwt_hip_set_workspace.argtypes = [_P, C.c_size_t, _P, C.c_size_t]
 lib.dwt_hip_set_workspace.restype = _I
+lib.dwt_hip_alloc_batch.argtypes = [_I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_P)]
+lib.dwt_hip_alloc_batch.restype = _I
+lib.dwt_hip_placement_report.argtypes = [C.POINTER(C.c_double), _I]
+lib.dwt_hip_placement_report.restype = _I
+lib.dwt_hip_alloc_batch_report.argtypes = [C.POINTER(_I)] * 5 + [C.POINTER(C.c_double)] * 2
 lib.dwt_hip_probe_pair_us.argtypes = [_P, _P, C.c_size_t]
 lib.dwt_hip_probe_pair_us.restype = C.c_double
 lib.dwt_hip_probe_copy_us.argtypes = [_P, _P, C.c_size_t]
@@ -74,9 +79,6 @@ lib.dwt_hip_probe_copy_us.restype = C.c_double
 lib.dwt_hip_malloc_mapped.argtypes = [C.c_size_t, C.c_size_t, _I, C.c_size_t]
 lib.dwt_hip_malloc_mapped.restype = _P
 lib.dwt_hip_free_mapped.argtypes = [_P]
-lib.dwt_hip_alloc_placed.argtypes = [C.POINTER(C.c_size_t), _I, C.POINTER(C.c_size_t), _I, C.POINTER(_P), C.POINTER(_P)]
-lib.dwt_hip_alloc_placed.restype = _I
-lib.dwt_hip_placed_stats.argtypes = [C.POINTER(_I)] * 3 + [C.POINTER(C.c_double)] * 3
 lib.dwt_hip_malloc_spread.argtypes = [C.c_size_t, C.c_size_t]
 lib.dwt_hip_malloc_spread.restype = _P
 lib.dwt_hip_set_option.argtypes = [C.c_char_p, _I]
@@ -561,19 +563,27 @@ def prof_read():
     return ms.value, n.value
 
 
-def alloc_placed(bytes_a, bytes_b):
-    """Device buffers of two different physical classes (dwt_hip_alloc_placed): `bytes_a` sizes from one
-    class, `bytes_b` from another.  Returns (pointers_a, pointers_b, stats); free each with
-    lib.dwt_hip_free_mapped."""
-    na, nbb = len(bytes_a), len(bytes_b)
-    a = (C.c_size_t * max(na, 1))(*bytes_a)
-    b = (C.c_size_t * max(nbb, 1))(*bytes_b)
-    oa = (_P * max(na, 1))()
-    ob = (_P * max(nbb, 1))()
-    _check(lib.dwt_hip_alloc_placed(a, na, b, nbb, oa, ob), "dwt_hip_alloc_placed")
-    w, s_, o = _I(), _I(), _I()
-    lo, hi, sec = C.c_double(), C.c_double(), C.c_double()
-    lib.dwt_hip_placed_stats(C.byref(w), C.byref(s_), C.byref(o), C.byref(lo), C.byref(hi), C.byref(sec))
-    stats = {"chunks_walked": w.value, "same_class": s_.value, "other_class": o.value,
-             "probe_us_fastest": round(lo.value, 1), "probe_us_slowest": round(hi.value, 1), "seconds": round(sec.value, 2)}
-    return [oa[i] for i in range(na)], [ob[i] for i in range(nbb)], stats
+def placement_report():
+    """Milliseconds the last placement search measured per candidate (empty: no search ran) and the index kept."""
+    ms = (C.c_double * 8)()
+    n = lib.dwt_hip_placement_report(ms, 8)
+    return [round(ms[i], 4) for i in range(n)], lib.dwt_hip_get_option(b"place_last_best")
+
+
+def alloc_batch_report():
+    """What the last dwt_hip_alloc_batch of this thread measured (chunks == 0: plain allocations)."""
+    v = [_I() for _ in range(5)]
+    ms = (C.c_double * 5)()
+    sec = C.c_double()
+    lib.dwt_hip_alloc_batch_report(*[C.byref(x) for x in v], ms, C.byref(sec))
+    return {"arena_GiB": v[0].value, "dst_positions_tried": v[1].value, "scratch_positions_tried": v[2].value,
+            "dst_at_GiB": v[3].value, "scratch_at_GiB": v[4].value,
+            "dst_one_level_ms_best_worst": [round(ms[0], 4), round(ms[1], 4)],
+            "whole_call_ms_best_worst": [round(ms[2], 4), round(ms[3], 4)], "kept_arrangement_ms": round(ms[4], 4), "seconds": round(sec.value, 2)}
+
+
+def alloc_batch(wavelet, n_images, size_x, size_y, levels=-1):
+    """dwt_hip_alloc_batch: (src, dst) device pointers of a resident batch, placed; free with lib.dwt_hip_free."""
+    s_, d_ = _P(), _P()
+    _check(lib.dwt_hip_alloc_batch(WAVELET_ID.get(wavelet, wavelet), n_images, size_x, size_y, levels, C.byref(s_), C.byref(d_)), "dwt_hip_alloc_batch")
+    return s_.value, d_.value

@@ -69,6 +69,14 @@ struct Ctx {
 	int inplace_overlap = 0; // 1: the copy-back (forward) / copy-aside (inverse) of an in-place call on a side stream beside the deeper levels (measured 8-10 us slower than in line)
 	int il_lazy_strips = 1; // interleaved 9/7 forward: the exact border strips on the side stream beside the next level's sweep (0: in line)
 	long ll_offset = 0; // bytes between the start of an LL scratch allocation and the band (placement experiments)
+	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of
+	// scratch, up to `place_tries` allocations of it -- each behind a spacer that moves it into other
+	// physical memory -- are timed with the call's own first two levels and the fastest kept
+	int place_tries = 4;
+	int place_min_mib = 1024;
+	bool placing = false;       // inside a timed trial: no nested search
+	double place_ms[8] = {0};   // what the last search measured, per candidate
+	int place_n = 0, place_best = -1;
 	int ll_pad = 0; // elements added to the row pitch of the LL scratch bands (placement experiments)
 	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
 	// profiling
@@ -126,6 +134,7 @@ struct Geom {
 };
 
 int grow(void **p, size_t *have, size_t need);
+void dev_free(void *p); // hipFree, or the release of a buffer mapped by dwt_placement.hip
 int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
 int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
 int zero_rect(Img img, long x, long y, long w, long h);
@@ -136,6 +145,12 @@ int host_upload(const void *hp, int stride_x, int stride_y, int es, int w, int h
 int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, const void *dp, long pitch);
 // one exact out-of-place 1-D pass over the lines of a frame (in == out is staged)
 int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_w, int frame_h, int n_lines, int N, int hoff);
+// placement (dwt_backend.hip / dwt_placement.hip)
+size_t ll_band_bytes(const Geom &ge, int k, int batch, int es); // bytes of LL scratch band k (0: level-1 band, 1: level-2 band)
+int timed_forward(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db, double *ms); // ms of the 2nd of two calls
+int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db);
+bool stream_is_capturing();
+int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompose_one, int zero_padding, int batch, long src_bstride, long dst_bstride);
 void prof_before(int level = 0);
 void prof_after(int level = 0);
 int check_inited();

@@ -42,7 +42,7 @@ int grow(void **p, size_t *have, size_t need)
 		return 0;
 	if (*p) {
 		HIP_TRY(hipStreamSynchronize(g.stream));
-		HIP_TRY(hipFree(*p));
+		dev_free(*p);
 		*p = nullptr;
 		*have = 0;
 	}
@@ -443,6 +443,11 @@ void swap_lane(Ctx::Lane &l)
 long ll_pitch_elems(int w) { return align_up(w, 4) + g.ll_pad; }
 static char *ll_band(int k) { return (char *)g.ll[k] + g.ll_offset; }
 
+size_t ll_band_bytes(const Geom &ge, int k, int batch, int es)
+{
+	return (size_t)ll_pitch_elems(ge.Wo(k + 1)) * ge.Ho(k + 1) * es * batch + 64 + (size_t)g.ll_offset;
+}
+
 int ensure_ll(const Geom &ge, int batch, int es)
 {
 	for (int k = 0; k < 2; k++) {
@@ -460,7 +465,6 @@ int ensure_ll(const Geom &ge, int batch, int es)
 }
 
 thread_local bool g_elems_are_32bit = true;
-extern thread_local int g_placed_prefer;
 
 // the fused sweeps exist for the 32-bit types and, since round 2, for the double-precision wavelets
 // (dwt_sweep2d_d.hip; option "fused_d" = 0 sends those back to the exact line passes)
@@ -769,6 +773,130 @@ int check_inited()
 	return 0;
 }
 
+// ---- placement of the LL scratch ------------------------------------------------------------------
+// The rate of a forward level depends on where in PHYSICAL memory its three streams lie relative to each
+// other -- source rows, detail subbands, running LL band (profiles/r04_placement.md: coarse regions of
+// three classes; +13 % when the two write streams are in different ones) -- and nothing finer than that
+// matters.  The caller owns source and destination; the LL scratch is the library's.  So the first
+// forward call that needs a large scratch tries a few allocations of it, each behind a spacer that pushes
+// it into other physical memory, times the call itself on each (it writes exactly what the call will
+// write: idempotent for distinct source and destination), and keeps the fastest.  Once per
+// size: later calls find the scratch in place, allocate nothing and never synchronise.
+int timed_forward(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db, double *ms)
+{
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	int rc = 0;
+	g.placing = true;
+	for (int r = 0; r < 2 && !rc; r++) {
+		int j = levels;
+		hipEventRecord(e0, g.stream);
+		rc = forward2d(w, s, d, ge, &j, 0, 0, batch, sb, db);
+		hipEventRecord(e1, g.stream);
+	}
+	g.placing = false;
+	float t = 0;
+	if (!rc && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess))
+		rc = fail("timing a placement trial failed: %s", hipGetErrorString(hipGetLastError()));
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	*ms = t;
+	return rc;
+}
+
+// spacer in front of candidate k of a placement search
+static size_t place_jump(int k)
+{
+	return k <= 0 ? 0 : ((size_t)14 << 30) << (k > 3 ? 2 : k - 1);
+}
+
+bool stream_is_capturing()
+{
+	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing(g.stream, &st) != hipSuccess) {
+		(void)hipGetLastError();
+		return true; // unknown: do nothing that synchronises
+	}
+	return st != hipStreamCaptureStatusNone;
+}
+
+int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db)
+{
+	const int es = elem_size(w);
+	const size_t need[2] = {ll_band_bytes(ge, 0, batch, es), ll_band_bytes(ge, 1, batch, es)};
+	g.place_n = 0;
+	g.place_best = -1;
+	if (g.placing || g.ll_external || g.place_tries < 2 || s.p == d.p || (g.ll_bytes[0] >= need[0] && g.ll_bytes[1] >= need[1]) ||
+		need[0] + need[1] < ((size_t)g.place_min_mib << 20) || !ge.dense() || ge.Wo(2) < 2 || ge.Ho(2) < 2 || g.force_generic ||
+		stream_is_capturing())
+		return 0;
+	struct Cand {
+		void *ll[2], *spacer;
+		double ms;
+	};
+	std::vector<Cand> cands;
+	int rc = 0;
+	for (int k = 0; k < g.place_tries && k < 8 && !rc; k++) {
+		Cand c{{nullptr, nullptr}, nullptr, 0};
+		// the spacers stay allocated during the search, so the jumps add up: candidates 14, 44, 104 ... GiB
+		// further on (the classes come in 16 GiB granules, runs of one class can be 64 GiB long)
+		const size_t jump = place_jump(k);
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need[0] + need[1] + (k ? jump : 0) + ((size_t)2 << 30))
+			break;
+		if (k && hipMalloc(&c.spacer, jump) != hipSuccess) {
+			(void)hipGetLastError();
+			break;
+		}
+		if (hipMalloc(&c.ll[0], need[0]) != hipSuccess || hipMalloc(&c.ll[1], need[1]) != hipSuccess) {
+			(void)hipGetLastError();
+			for (void *p : {c.ll[0], c.ll[1], c.spacer})
+				if (p)
+					hipFree(p);
+			break;
+		}
+		// the context works on this candidate for the trial
+		if (g.ll[0] || g.ll[1])
+			HIP_TRY(hipStreamSynchronize(g.stream));
+		for (int b = 0; b < 2; b++) {
+			if (cands.empty() && g.ll[b])
+				dev_free(g.ll[b]); // the too-small scratch of earlier calls
+			g.ll[b] = c.ll[b];
+			g.ll_bytes[b] = need[b];
+		}
+		rc = timed_forward(w, s, d, ge, levels, batch, sb, db, &c.ms);
+		cands.push_back(c);
+	}
+	if (cands.empty()) {
+		g.ll[0] = g.ll[1] = nullptr;
+		g.ll_bytes[0] = g.ll_bytes[1] = 0;
+		return rc; // nothing allocated here: the call allocates plainly
+	}
+	int best = 0;
+	for (size_t k = 0; k < cands.size(); k++) {
+		if (cands[k].ms < cands[best].ms)
+			best = (int)k;
+		g.place_ms[k] = cands[k].ms;
+	}
+	g.place_n = (int)cands.size();
+	g.place_best = best;
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	for (size_t k = 0; k < cands.size(); k++) {
+		if (cands[k].spacer)
+			hipFree(cands[k].spacer);
+		if ((int)k != best) {
+			hipFree(cands[k].ll[0]);
+			hipFree(cands[k].ll[1]);
+		}
+	}
+	for (int b = 0; b < 2; b++) {
+		g.ll[b] = cands[best].ll[b];
+		g.ll_bytes[b] = need[b];
+	}
+	return rc;
+}
+
 } // namespace dwtb
 
 using namespace dwtb;
@@ -847,7 +975,7 @@ void dwt_hip_finish(void)
 	void **bufs[] = {&g.stage_img, &g.ll[0], &g.ll[1], &g.host_a, &g.host_b, &g.vol_out, &g.vol_host[0], &g.vol_host[1]};
 	for (void **b : bufs) {
 		if (*b)
-			hipFree(*b);
+			dev_free(*b);
 		*b = nullptr;
 	}
 	g.stage_bytes = g.ll_bytes[0] = g.ll_bytes[1] = g.host_a_bytes = g.host_b_bytes = g.vol_out_bytes = 0;
@@ -917,6 +1045,14 @@ int dwt_hip_set_workspace(void *band0, size_t bytes0, void *band1, size_t bytes1
 	return 0;
 }
 
+int dwt_hip_placement_report(double *ms, int n)
+{
+	for (int i = 0; i < n && i < g.place_n; i++)
+		ms[i] = g.place_ms[i];
+	return g.place_n;
+}
+
+
 void dwt_hip_sync(void)
 {
 	if (g.inited)
@@ -961,8 +1097,10 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fused_d = value;
 	else if (!strcmp(name, "ll_offset_kib"))
 		g.ll_offset = value < 0 ? 0 : (long)value * 1024;
-	else if (!strcmp(name, "placed_prefer"))
-		g_placed_prefer = value;
+	else if (!strcmp(name, "place_tries"))
+		g.place_tries = value;
+	else if (!strcmp(name, "place_min_mib"))
+		g.place_min_mib = value < 0 ? 0 : value;
 	else if (!strcmp(name, "ll_pad"))
 		g.ll_pad = value < 0 ? 0 : (value + 3) / 4 * 4;
 	else if (!strcmp(name, "inplace_overlap"))
@@ -1050,6 +1188,14 @@ int dwt_hip_get_option(const char *name)
 		return g.vol.whole;
 	if (!strcmp(name, "vol_inplace_fused"))
 		return g.vol.inplace_fused;
+	if (!strcmp(name, "place_tries"))
+		return g.place_tries;
+	if (!strcmp(name, "place_min_mib"))
+		return g.place_min_mib;
+	if (!strcmp(name, "place_last_tries")) // candidates the last placement search timed (0: none ran)
+		return g.place_n;
+	if (!strcmp(name, "place_last_best"))
+		return g.place_best;
 	return -1;
 }
 
@@ -1078,8 +1224,7 @@ void *dwt_hip_malloc(size_t bytes)
 
 void dwt_hip_free(void *p)
 {
-	if (p)
-		hipFree(p);
+	dev_free(p);
 }
 
 void *dwt_hip_malloc_host(size_t bytes)
@@ -1182,6 +1327,8 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 		if (stride_y != es || (stride_x % es) || stride_x < sox * es)
 			return fail("device images need stride_y == %d and stride_x a multiple of it >= width*%d (got %d, %d)", es, es, stride_x, stride_y);
 		Img s{(char *)src, stride_x, es}, d{(char *)dst, stride_x, es};
+		if (!inverse && !decompose_one && (*j < 0 || *j >= 2) && place_ll_scratch(w, s, d, ge, *j, 1, 0, 0))
+			return 1;
 		return inverse ? inverse2d(w, s, d, ge, *j, decompose_one, zero_padding, 1, 0, 0)
 		               : forward2d(w, s, d, ge, j, decompose_one, zero_padding, 1, 0, 0);
 	}
@@ -1272,6 +1419,8 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 		}
 		return rc;
 	}
+	if (!inverse && (*j < 0 || *j >= 2) && place_ll_scratch((Wavelet)wavelet, s, d, ge, *j, batch, (long)batch_stride, (long)batch_stride))
+		return 1;
 	return inverse ? inverse2d((Wavelet)wavelet, s, d, ge, *j, 0, 0, batch, (long)batch_stride, (long)batch_stride)
 	               : forward2d((Wavelet)wavelet, s, d, ge, j, 0, 0, batch, (long)batch_stride, (long)batch_stride);
 }

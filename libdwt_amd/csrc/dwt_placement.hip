@@ -1,22 +1,20 @@
-// dwt_placement.hip -- placement-aware device memory for the sweeps.
+// dwt_placement.hip -- instruments of the placement diagnosis (profiles/r04_placement.md).
 //
-// Why.  The sweeps run three streams at once: they read the source rows and write the detail
-// subbands and the running LL band.  On MI355X the rate of the SAME launch on the SAME virtual
-// addresses moves between plateaus (level 0 of 64 images: 5.2 / 5.4 / 5.75 / 6.15 TB/s) with WHERE in
-// physical memory the three buffers lie (profiles/r04_placement.md): physical memory falls into
-// three classes of coarse regions (tens of GiB; consistent with the three stack-ID ranks of the 12-high
-// HBM3E stacks), and streams that run at the same time in regions of the SAME class slow each other
-// down -- two write streams by 13 %, a read and a write stream by 3-4 % -- while nothing at all depends
-// on fine address bits (offsets of 1 KiB .. 1 GiB inside an allocation, row pitch, image stride).
-// Same requests, same TLB misses, more DRAM-credit stalls at the L2's memory side.
-//
-// The reference hands its callers a placement-aware allocator for the same kind of reason
-// (dwt_util_get_opt_stride / dwt_util_get_stride, src/libdwt.c:20641-20707: power-of-two pitches alias
-// in the CPU caches).  The analogue here: memory of a chosen CLASS.  Physical memory is taken in chunks
-// through HIP's virtual-memory API (hipMemCreate), each chunk is classified by timing a small two-stream
-// write kernel against three reference chunks of mutually different classes, and a buffer is a virtual
-// range mapped from chunks of one class only.  A caller that keeps source, destination and the
-// library's workspace in three different classes sits on the fast plateau by construction.
+// The sweeps run three streams at once -- source rows, detail subbands, running LL band -- and their rate
+// depends on WHERE in physical memory those lie relative to each other: physical memory falls into coarse
+// regions (16 GiB granules) of three classes, and streams that run at the same time in regions of the same
+// class slow each other down (level 0 of 64 images: 5.2 ... 6.2 TB/s on the same virtual addresses), while
+// nothing depends on fine address bits.  The product's answer is a timed choice among candidate
+// allocations (place_ll_scratch / dwt_hip_alloc_batch in dwt_backend.hip).  This file holds what the
+// diagnosis was made with and what scripts/probes/r04_*.py call:
+//   - dwt_hip_probe_pair_us / dwt_hip_probe_copy_us: dense two-stream write / copy probes (they do NOT see
+//     the classes the sweeps see: their DRAM pages stay open);
+//   - dwt_hip_malloc_mapped: a buffer mapped (HIP virtual-memory API) from physical pieces taken in groups
+//     that come from far-apart physical memory, interleaved piece by piece;
+//   - dwt_hip_malloc_spread: pieces at even distances through ALL free physical memory -- every such buffer
+//     is the same mix of the classes: the same rate in every process, but the rate of the mix (5.7 TB/s),
+//     not of the best arrangement (6.2).
+// Buffers of either kind are freed by dwt_hip_free like any other.
 #include "dwt_backend.h"
 
 #include <algorithm>
@@ -87,9 +85,15 @@ static double probe_us(void *a, void *b, size_t bytes, int reps = 5, bool copy =
 }
 
 // ---- buffers mapped from physical pieces (HIP virtual-memory API) ---------------------------------
+struct VmmArena { // one address reservation shared by several buffers (dwt_hip_alloc_batch)
+	void *base;
+	size_t bytes;
+	int live;
+};
 struct VmmBuf {
 	size_t bytes = 0, piece = 0;
 	std::vector<hipMemGenericAllocationHandle_t> handles;
+	VmmArena *arena = nullptr; // set: the range is part of that reservation, which goes when its last part goes
 };
 static std::map<void *, VmmBuf> g_vmm;
 static std::mutex g_vmm_mu;
@@ -100,8 +104,15 @@ static int vmm_release(void *va, VmmBuf &b, size_t mapped_pieces)
 		hipMemUnmap((char *)va + i * b.piece, b.piece);
 	for (auto h : b.handles)
 		hipMemRelease(h);
-	if (va)
+	if (b.arena) {
+		std::lock_guard<std::mutex> lk(g_vmm_mu);
+		if (--b.arena->live == 0) {
+			hipMemAddressFree(b.arena->base, b.arena->bytes);
+			delete b.arena;
+		}
+	} else if (va) {
 		hipMemAddressFree(va, b.bytes);
+	}
 	return 1;
 }
 
@@ -282,65 +293,51 @@ static bool vmm_free(void *va)
 }
 
 
-// ---- placed allocation: buffers of two different physical classes -----------------------------------
-// The sweep itself is the probe (nothing simpler shows the classes: a dense copy or two dense write
-// streams keep their DRAM pages open and do not care; the sweeps' thousands of concurrent row streams
-// open a page per access): one level of the float 9/7 on a few 4096^2 images, source in the reference
-// chunk, all four subbands into the candidate chunk.  Same class: ~6 % slower.
-static double probe_level_us(void *ref, void *cand, size_t chunk)
+// ---- dwt_hip_alloc_batch: source, destination and LL scratch of a resident batch, placed by measurement ---------
+// An ARENA -- most of the free memory of the card, mapped from 1 GiB physical chunks into one virtual
+// range -- holds every candidate arrangement at once, so trying one costs a transform and nothing else:
+//   1. the source at the start of the arena; the destination at every 4 GiB step behind it, timed with
+//      ONE level (read stream against write stream, no scratch);
+//   2. for the best destinations, the two LL bands at every 4 GiB step that overlaps neither, timed with
+//      the `levels`-level transform of the whole batch;
+//   3. the chunks under the best (destination, scratch) and under the source stay mapped where they are --
+//      the four buffers ARE the arrangement that was measured -- and every other chunk is unmapped and goes
+//      back to the system.
+struct ArenaStats {
+	int chunks = 0, dst_tried = 0, ll_tried = 0, dst_at = 0, ll_at = 0;
+	double dst_best_ms = 0, dst_worst_ms = 0, ll_best_ms = 0, ll_worst_ms = 0, final_ms = 0, seconds = 0;
+};
+static thread_local ArenaStats g_arena;
+
+static int alloc_batch_plain(size_t total, void **src, void **dst)
 {
-	const int W = 4096, H = 4096;
-	dwt::FwdLevelArgs a;
-	a.in = ref;
-	a.in_pitch = W;
-	a.in_bstride = (long)W * H;
-	a.out_ll = a.out_h = cand;
-	a.ll_pitch = a.h_pitch = W;
-	a.ll_bstride = a.h_bstride = (long)W * H;
-	a.W = W;
-	a.H = H;
-	a.batch = (int)(chunk / ((size_t)W * H * 4));
-	hipEvent_t e0, e1;
-	if (a.batch < 1 || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-		return -1;
-	dwt::SweepTuning tune; // the defaults, whatever the caller has set
-	float best[4];
-	int n = 0;
-	for (int r = 0; r < 4; r++) {
-		hipEventRecord(e0, g.stream);
-		if (dwt::launch_fwd_level(dwt::kCdf97S, a, tune, g.stream) != hipSuccess)
-			break;
-		hipEventRecord(e1, g.stream);
-		if (hipEventSynchronize(e1) != hipSuccess)
-			break;
-		float ms = 0;
-		hipEventElapsedTime(&ms, e0, e1);
-		if (r)
-			best[n++] = ms * 1e3f;
+	*src = *dst = nullptr;
+	if (hipMalloc(src, total) != hipSuccess || hipMalloc(dst, total) != hipSuccess) {
+		(void)hipGetLastError();
+		if (*src)
+			hipFree(*src);
+		*src = nullptr;
+		return fail("hipMalloc(%zu) failed", total);
 	}
-	hipEventDestroy(e0);
-	hipEventDestroy(e1);
-	if (n < 3)
-		return -1;
-	std::sort(best, best + n);
-	return best[n / 2];
+	return 0;
 }
 
-struct PlacedStats {
-	int walked = 0, same = 0, other = 0;
-	double us_lo = 0, us_hi = 0, seconds = 0;
-};
-static thread_local PlacedStats g_placed_stats;
-thread_local int g_placed_prefer = 0; // experiments: 1 = group A must be the reference chunk's class, 2 = the other
-
-// Buffers `bytes_a[0..n_a)` from ONE physical class and `bytes_b[0..n_b)` from ANOTHER.  Physical memory
-// is taken chunk by chunk (256 MiB), each chunk timed against the first one; the walk goes on until both
-// groups can be filled, then every buffer is one virtual range mapped from chunks of its group and the
-// rest is released.  Where the card does not offer two classes within the walk (or is nearly full)
-// the groups are filled with what there is: the memory is valid either way.
-static int placed_alloc(const size_t *bytes_a, int n_a, const size_t *bytes_b, int n_b, void **out_a, void **out_b)
+static int alloc_batch_arena(Wavelet w, int n_images, int size_x, int size_y, int levels, void **src_out, void **dst_out)
 {
-	const size_t C = (size_t)256 << 20;
+	const int es = elem_size(w);
+	const size_t C = (size_t)1 << 30;
+	const size_t pitch = (size_t)size_x * es, img = pitch * size_y, total = img * n_images;
+	const Geom ge{size_x, size_y, size_x, size_y};
+	const size_t need_ll[2] = {ll_band_bytes(ge, 0, n_images, es), ll_band_bytes(ge, 1, n_images, es)};
+	const size_t nS = (total + C - 1) / C, nL0 = (need_ll[0] + C - 1) / C, nL1 = (need_ll[1] + C - 1) / C, nL = nL0 + nL1;
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	const size_t reserve = (size_t)8 << 30;
+	size_t n_chunks = free_b > reserve ? (free_b - reserve) / C : 0;
+	n_chunks = std::min<size_t>(n_chunks, std::max<size_t>(192, 4 * (2 * nS + nL)));
+	if (n_chunks < 2 * (2 * nS + nL))
+		return -1; // not enough room for a choice: the caller allocates plainly
+	const auto t_start = std::chrono::steady_clock::now();
 	hipMemAllocationProp prop = {};
 	prop.type = hipMemAllocationTypePinned;
 	prop.location.type = hipMemLocationTypeDevice;
@@ -348,152 +345,164 @@ static int placed_alloc(const size_t *bytes_a, int n_a, const size_t *bytes_b, i
 	hipMemAccessDesc acc = {};
 	acc.location = prop.location;
 	acc.flags = hipMemAccessFlagsProtReadWrite;
-	size_t need_a = 0, need_b = 0;
-	for (int i = 0; i < n_a; i++)
-		need_a += (bytes_a[i] + C - 1) / C;
-	for (int i = 0; i < n_b; i++)
-		need_b += (bytes_b[i] + C - 1) / C;
-	size_t free_b = 0, total_b = 0;
-	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-	const size_t reserve = (size_t)2 << 30;
-	if (free_b < (need_a + need_b) * C + reserve)
-		return fail("placed allocation of %zu MiB: only %zu MiB free", (need_a + need_b) * (C >> 20), free_b >> 20);
-	const size_t max_walk = (free_b - reserve) / C;
-	const auto t_start = std::chrono::steady_clock::now();
-
-	void *pva = nullptr; // probe window: [reference chunk | candidate chunk]
-	HIP_TRY(hipMemAddressReserve(&pva, 2 * C, 0, nullptr, 0));
-	struct Chunk {
+	std::vector<hipMemGenericAllocationHandle_t> chunk;
+	for (size_t i = 0; i < n_chunks; i++) {
 		hipMemGenericAllocationHandle_t h;
-		double us;
-	};
-	std::vector<Chunk> chunks;
-	auto release_all = [&]() {
-		for (auto &c : chunks)
-			hipMemRelease(c.h);
-		chunks.clear();
-	};
-	bool ref_mapped = false, failed = false;
-	double lo = 0, hi = 0;
-	auto split = [&](size_t &same, size_t &other) {
-		// two clusters when the spread exceeds 3 %: chunks slower than the midpoint share the reference's class
-		same = other = 0;
-		const bool two = hi > lo * 1.03;
-		for (auto &c : chunks)
-			(!two || c.us > 0.5 * (lo + hi) ? same : other)++;
-	};
-	while (chunks.size() < max_walk) {
-		Chunk c{};
-		if (hipMemCreate(&c.h, C, &prop, 0) != hipSuccess) {
+		if (hipMemCreate(&h, C, &prop, 0) != hipSuccess) {
 			(void)hipGetLastError();
 			break;
 		}
-		if (!ref_mapped) {
-			if (hipMemMap(pva, C, 0, c.h, 0) != hipSuccess || hipMemSetAccess(pva, C, &acc, 1) != hipSuccess) {
-				hipMemRelease(c.h);
-				failed = true;
-				break;
-			}
-			ref_mapped = true;
-			c.us = 1e30; // the reference is of its own class by definition
-			chunks.push_back(c);
-			continue;
-		}
-		char *cva = (char *)pva + C;
-		if (hipMemMap(cva, C, 0, c.h, 0) != hipSuccess || hipMemSetAccess(cva, C, &acc, 1) != hipSuccess) {
-			hipMemRelease(c.h);
-			failed = true;
-			break;
-		}
-		c.us = probe_level_us(pva, cva, C);
-		hipMemUnmap(cva, C);
-		if (c.us <= 0) {
-			hipMemRelease(c.h);
-			failed = true;
-			break;
-		}
-		lo = chunks.size() == 1 ? c.us : std::min(lo, c.us);
-		hi = chunks.size() == 1 ? c.us : std::max(hi, c.us);
-		chunks.push_back(c);
-		size_t same, other;
-		split(same, other);
-		const bool fit1 = same >= need_a && other >= need_b, fit2 = same >= need_b && other >= need_a;
-		if ((fit1 && g_placed_prefer != 2) || (fit2 && g_placed_prefer != 1))
-			break;
+		chunk.push_back(h);
 	}
-	if (ref_mapped)
-		hipMemUnmap(pva, C);
-	hipMemAddressFree(pva, 2 * C);
-	if (failed || chunks.size() < need_a + need_b) {
-		release_all();
-		return fail("placed allocation: walking the physical memory failed (%s)", hipGetErrorString(hipGetLastError()));
-	}
-	chunks[0].us = hi > lo * 1.03 ? hi : 1e30;
-	size_t same, other;
-	split(same, other);
-	// group A takes the reference's class unless only the other arrangement fits
-	const bool fit1 = same >= need_a && other >= need_b, fit2 = same >= need_b && other >= need_a;
-	const bool a_is_same = g_placed_prefer == 1 ? true : g_placed_prefer == 2 ? false : (fit1 || !fit2);
-	const double mid = hi > lo * 1.03 ? 0.5 * (lo + hi) : -1;
-	std::vector<hipMemGenericAllocationHandle_t> pool_same, pool_other;
-	for (auto &c : chunks)
-		(c.us > mid ? pool_same : pool_other).push_back(c.h);
-	std::vector<hipMemGenericAllocationHandle_t> &pa = a_is_same ? pool_same : pool_other, &pb = a_is_same ? pool_other : pool_same;
-	auto take = [&](std::vector<hipMemGenericAllocationHandle_t> &own, std::vector<hipMemGenericAllocationHandle_t> &alt) {
-		std::vector<hipMemGenericAllocationHandle_t> &from = own.empty() ? alt : own;
-		hipMemGenericAllocationHandle_t h = from.front(); // front: keep the walk's order inside a buffer
-		from.erase(from.begin());
-		return h;
+	auto release_chunks = [&]() {
+		for (auto h : chunk)
+			hipMemRelease(h);
+		chunk.clear();
 	};
-	std::vector<void *> made;
-	auto build = [&](size_t bytes, bool group_a, void **out) -> int {
-		const size_t n = (bytes + C - 1) / C;
+	n_chunks = chunk.size();
+	if (n_chunks < 2 * (2 * nS + nL)) {
+		release_chunks();
+		return -1;
+	}
+	char *arena = nullptr;
+	if (hipMemAddressReserve((void **)&arena, n_chunks * C, 0, nullptr, 0) != hipSuccess) {
+		release_chunks();
+		return fail("hipMemAddressReserve(%zu) failed", n_chunks * C);
+	}
+	size_t mapped = 0;
+	bool ok = true;
+	for (size_t i = 0; i < n_chunks && ok; i++) {
+		ok = hipMemMap(arena + i * C, C, 0, chunk[i], 0) == hipSuccess;
+		if (ok)
+			mapped++;
+	}
+	ok = ok && hipMemSetAccess(arena, n_chunks * C, &acc, 1) == hipSuccess;
+	auto drop_arena = [&]() {
+		for (size_t i = 0; i < mapped; i++)
+			hipMemUnmap(arena + i * C, C);
+		hipMemAddressFree(arena, n_chunks * C);
+		release_chunks();
+	};
+	if (!ok) {
+		drop_arena();
+		return fail("mapping the placement arena failed: %s", hipGetErrorString(hipGetLastError()));
+	}
+	// the context's own scratch makes room for the arena's candidates during the search
+	hipStreamSynchronize(g.stream);
+	for (int b = 0; b < 2; b++) {
+		if (g.ll[b])
+			dev_free(g.ll[b]);
+		g.ll[b] = nullptr;
+		g.ll_bytes[b] = 0;
+	}
+	const Img s{arena, (long)pitch, es};
+	auto dst_img = [&](size_t D) { return Img{arena + D * C, (long)pitch, es}; };
+	int rc = 0;
+	const size_t step = 4;
+	// 1. destinations against the source: one level, no scratch
+	std::vector<std::pair<double, size_t>> dsts;
+	// (a one-level call never touches the scratch; the context is pointed at the source region so that it
+	// does not allocate one of its own meanwhile)
+	g.ll[0] = g.ll[1] = arena;
+	g.ll_bytes[0] = g.ll_bytes[1] = nS * C;
+	g.ll_external = true;
+	for (size_t D = nS; D + nS <= n_chunks && !rc; D += step) {
+		double ms = 0;
+		rc = timed_forward(w, s, dst_img(D), ge, 1, n_images, (long)img, (long)img, &ms);
+		dsts.push_back({ms, D});
+	}
+	g.ll_external = false;
+	g.ll[0] = g.ll[1] = nullptr;
+	g.ll_bytes[0] = g.ll_bytes[1] = 0;
+	double best_ms = 1e30, worst_ll = 0;
+	size_t best_D = nS, best_P = 2 * nS;
+	int ll_tried = 0;
+	if (!rc) {
+		std::vector<std::pair<double, size_t>> order = dsts;
+		std::sort(order.begin(), order.end());
+		const size_t top = std::min<size_t>(order.size(), 3);
+		for (size_t t = 0; t < top && !rc; t++) {
+			const size_t D = order[t].second;
+			// 2. both LL bands, contiguous, wherever they overlap neither the source nor this destination
+			for (size_t P = 0; P + nL <= n_chunks && !rc; P += step) {
+				if (P < nS || (P < D + nS && D < P + nL))
+					continue;
+				g.ll[0] = arena + P * C;
+				g.ll[1] = arena + (P + nL0) * C;
+				g.ll_bytes[0] = nL0 * C;
+				g.ll_bytes[1] = nL1 * C;
+				g.ll_external = true; // not to be grown or freed while it points into the arena
+				double ms = 0;
+				rc = timed_forward(w, s, dst_img(D), ge, levels, n_images, (long)img, (long)img, &ms);
+				g.ll_external = false;
+				g.ll[0] = g.ll[1] = nullptr;
+				g.ll_bytes[0] = g.ll_bytes[1] = 0;
+				ll_tried++;
+				worst_ll = std::max(worst_ll, ms);
+				if (ms < best_ms) {
+					best_ms = ms;
+					best_D = D;
+					best_P = P;
+				}
+			}
+		}
+	}
+	hipStreamSynchronize(g.stream);
+	if (rc || best_ms >= 1e30) {
+		drop_arena();
+		return rc ? rc : -1;
+	}
+	// 3. the chosen chunks stay where they are mapped -- the buffers ARE the arrangement that was measured,
+	//    physical chunks and virtual addresses alike (mapping the same chunks again at other addresses gave
+	//    other rates: 8.5-8.8 ms for arrangements that had measured 7.5-7.7) -- and every other chunk is
+	//    unmapped and returned; the address reservation goes when the last of the four buffers is freed
+	struct Part {
+		size_t first, count;
+		void *va;
+	} parts[4] = {{0, nS, nullptr}, {best_D, nS, nullptr}, {best_P, nL0, nullptr}, {best_P + nL0, nL1, nullptr}};
+	std::vector<char> used(n_chunks, 0);
+	VmmArena *ar = new VmmArena{arena, n_chunks * C, 4};
+	for (auto &p : parts) {
 		VmmBuf b;
 		b.piece = C;
-		b.bytes = n * C;
-		void *va = nullptr;
-		if (hipMemAddressReserve(&va, b.bytes, 0, nullptr, 0) != hipSuccess)
-			return fail("hipMemAddressReserve(%zu) failed", b.bytes);
-		size_t mapped = 0;
-		bool ok = true;
-		for (size_t i = 0; i < n && ok; i++) {
-			hipMemGenericAllocationHandle_t h = group_a ? take(pa, pb) : take(pb, pa);
-			b.handles.push_back(h);
-			ok = hipMemMap((char *)va + i * C, C, 0, h, 0) == hipSuccess;
-			if (ok)
-				mapped++;
+		b.bytes = p.count * C;
+		b.arena = ar;
+		for (size_t i = 0; i < p.count; i++) {
+			b.handles.push_back(chunk[p.first + i]);
+			used[p.first + i] = 1;
 		}
-		ok = ok && hipMemSetAccess(va, b.bytes, &acc, 1) == hipSuccess;
-		if (!ok) {
-			vmm_release(va, b, mapped);
-			return fail("mapping a placed buffer of %zu bytes failed: %s", bytes, hipGetErrorString(hipGetLastError()));
-		}
+		p.va = arena + p.first * C;
 		std::lock_guard<std::mutex> lk(g_vmm_mu);
-		g_vmm[va] = std::move(b);
-		*out = va;
-		made.push_back(va);
-		return 0;
-	};
-	int rc = 0;
-	for (int i = 0; i < n_a && !rc; i++)
-		rc = build(bytes_a[i], true, &out_a[i]);
-	for (int i = 0; i < n_b && !rc; i++)
-		rc = build(bytes_b[i], false, &out_b[i]);
-	for (auto h : pool_same)
-		hipMemRelease(h);
-	for (auto h : pool_other)
-		hipMemRelease(h);
-	if (rc) {
-		for (void *p : made)
-			vmm_free(p);
-		return rc;
+		g_vmm[p.va] = std::move(b);
 	}
-	g_placed_stats.walked = (int)chunks.size();
-	g_placed_stats.same = (int)same;
-	g_placed_stats.other = (int)other;
-	g_placed_stats.us_lo = lo;
-	g_placed_stats.us_hi = hi;
-	g_placed_stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	for (size_t i = 0; i < n_chunks; i++)
+		if (!used[i]) {
+			hipMemUnmap(arena + i * C, C);
+			hipMemRelease(chunk[i]);
+		}
+	g.ll[0] = parts[2].va;
+	g.ll[1] = parts[3].va;
+	g.ll_bytes[0] = nL0 * C;
+	g.ll_bytes[1] = nL1 * C;
+	*src_out = parts[0].va;
+	*dst_out = parts[1].va;
+	// the arrangement as the caller will use it, timed once more
+	double final_ms = 0;
+	timed_forward(w, Img{(char *)parts[0].va, (long)pitch, es}, Img{(char *)parts[1].va, (long)pitch, es}, ge, levels, n_images, (long)img, (long)img, &final_ms);
+	g_arena.final_ms = final_ms;
+	std::sort(dsts.begin(), dsts.end());
+	const double fin = g_arena.final_ms;
+	g_arena.chunks = (int)n_chunks;
+	g_arena.final_ms = fin;
+	g_arena.dst_tried = (int)dsts.size();
+	g_arena.ll_tried = ll_tried;
+	g_arena.dst_at = (int)best_D;
+	g_arena.ll_at = (int)best_P;
+	g_arena.dst_best_ms = dsts.front().first;
+	g_arena.dst_worst_ms = dsts.back().first;
+	g_arena.ll_best_ms = best_ms;
+	g_arena.ll_worst_ms = worst_ll;
+	g_arena.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	return 0;
 }
 
@@ -542,25 +551,49 @@ void *dwt_hip_malloc_spread(size_t bytes, size_t piece_bytes)
 	return spread_alloc(bytes, piece_bytes ? piece_bytes : (size_t)2 << 20, (size_t)1 << 30);
 }
 
-int dwt_hip_alloc_placed(const size_t *bytes_a, int n_a, const size_t *bytes_b, int n_b, void **out_a, void **out_b)
+// Source and destination of a resident batch, allocated WITH their placement -- the analogue of the
+// reference's dwt_util_get_opt_stride / dwt_util_get_stride for its callers (src/libdwt.c:20641-20707).  Dense
+// pitch (size_x elements), images size_x * size_y elements apart; the LL scratch stays with the calling
+// thread's context.  Batches below "place_min_mib" MiB, "place_tries" < 2, a card too full for a choice:
+// plain allocations (the first forward call then runs the library's own scratch search).
+int dwt_hip_alloc_batch(int wavelet, int n_images, int size_x, int size_y, int levels, void **src_out, void **dst_out)
 {
 	if (check_inited())
 		return 1;
-	if (n_a < 0 || n_b < 0 || n_a + n_b < 1 || (n_a && (!bytes_a || !out_a)) || (n_b && (!bytes_b || !out_b)))
-		return fail("dwt_hip_alloc_placed: bad argument");
-	return placed_alloc(bytes_a, n_a, bytes_b, n_b, out_a, out_b);
+	if (wavelet < 0 || wavelet > 5 || n_images < 1 || n_images > 65535 || size_x < 1 || size_y < 1 || !src_out || !dst_out)
+		return fail("dwt_hip_alloc_batch: bad argument");
+	const Wavelet w = (Wavelet)wavelet;
+	const int es = elem_size(w);
+	g_elems_are_32bit = es == 4;
+	const size_t total = (size_t)size_x * es * size_y * n_images;
+	const Geom ge{size_x, size_y, size_x, size_y};
+	g_arena = ArenaStats();
+	const bool search = g.place_tries >= 2 && total >= ((size_t)g.place_min_mib << 20) && ge.Wo(2) >= 2 && ge.Ho(2) >= 2 && !g.ll_external &&
+		!g.force_generic && es == 4 && !stream_is_capturing();
+	if (search) {
+		const int rc = alloc_batch_arena(w, n_images, size_x, size_y, levels, src_out, dst_out);
+		if (rc >= 0)
+			return rc;
+	}
+	return alloc_batch_plain(total, src_out, dst_out);
 }
 
-// what the last dwt_hip_alloc_placed of this thread saw: chunks walked, of the reference's class, of the
-// other class, probe time of the fastest and the slowest chunk (us), seconds spent
-void dwt_hip_placed_stats(int *walked, int *same, int *other, double *us_lo, double *us_hi, double *seconds)
+// what the last dwt_hip_alloc_batch of this thread measured (all zero: plain allocations)
+void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int *dst_at, int *ll_at, double *ms /* [5]: dst best, dst worst (one level), scratch best, scratch worst (whole call), the kept arrangement timed again */, double *seconds)
 {
-	if (walked) *walked = g_placed_stats.walked;
-	if (same) *same = g_placed_stats.same;
-	if (other) *other = g_placed_stats.other;
-	if (us_lo) *us_lo = g_placed_stats.us_lo;
-	if (us_hi) *us_hi = g_placed_stats.us_hi;
-	if (seconds) *seconds = g_placed_stats.seconds;
+	if (chunks) *chunks = g_arena.chunks;
+	if (dst_tried) *dst_tried = g_arena.dst_tried;
+	if (ll_tried) *ll_tried = g_arena.ll_tried;
+	if (dst_at) *dst_at = g_arena.dst_at;
+	if (ll_at) *ll_at = g_arena.ll_at;
+	if (ms) {
+		ms[0] = g_arena.dst_best_ms;
+		ms[1] = g_arena.dst_worst_ms;
+		ms[2] = g_arena.ll_best_ms;
+		ms[3] = g_arena.ll_worst_ms;
+		ms[4] = g_arena.final_ms;
+	}
+	if (seconds) *seconds = g_arena.seconds;
 }
 
 void dwt_hip_free_mapped(void *p)

@@ -917,6 +917,82 @@ def test_int_tile_variants_agree_over_the_whole_int32_range(dwt, oracle):
             dwt.set_option(k, v)
 
 
+def test_placement_entries(dwt, oracle):
+    """dwt_hip_alloc_batch (source + destination + LL scratch of a resident batch, the destination and the
+    scratch chosen by timing), the library's own scratch search on the first large forward call, and a
+    caller-owned workspace (dwt_hip_set_workspace): the transforms give the oracle's bits on all of them;
+    a workspace that is too small is refused; two NULLs hand the scratch back."""
+    import ctypes as C
+
+    L = dwt.lib
+    nb, h, w, J = 3, 520, 1030, 3
+    rng = np.random.default_rng(41)
+    imgs = rng.random((nb, h, w), dtype=np.float32)
+    want = imgs.copy()
+    for k in range(nb):
+        oracle.fwd("cdf97_2f_s", want[k], J)
+    try:
+        dwt.set_option("place_min_mib", 0)   # search whatever the size
+        dwt.set_option("place_tries", 3)
+        dwt.dwt_util_finish()                # no scratch from earlier tests
+        src, dst = dwt.alloc_batch("cdf97_s", nb, w, h, J)
+        rep = dwt.alloc_batch_report()
+        assert rep["arena_GiB"] >= 8 and rep["dst_positions_tried"] >= 1 and rep["scratch_positions_tried"] >= 1, rep
+        assert 0 < rep["whole_call_ms_best_worst"][0] <= rep["whole_call_ms_best_worst"][1]
+        assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
+        assert dwt.placement_report()[0] == [], "the scratch alloc_batch installed is in place: no second search"
+        got = np.empty_like(imgs)
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        # the library's own search: a fresh context, plain allocations of the caller
+        dwt.dwt_util_finish()
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
+        trials, kept = dwt.placement_report()
+        assert len(trials) >= 1 and 0 <= kept < len(trials)
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        # caller-owned workspace
+        b0 = nb * ((w + 1) // 2 + 3) * ((h + 1) // 2) * 4 + 64
+        b1 = nb * ((w + 3) // 4 + 3) * ((h + 3) // 4) * 4 + 64
+        w0, w1 = L.dwt_hip_malloc(b0), L.dwt_hip_malloc(b1)
+        assert L.dwt_hip_set_workspace(w0, b0, w1, b1) == 0, dwt.last_error()
+        assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        assert L.dwt_hip_set_workspace(w0, 4096, w1, 4096) == 0
+        with pytest.raises(dwt.DwtError):
+            dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J)
+        assert L.dwt_hip_set_workspace(None, 0, None, 0) == 0
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
+        for p in (w0, w1, src, dst):
+            L.dwt_hip_free(p)
+    finally:
+        L.dwt_hip_set_workspace(None, 0, None, 0)
+        dwt.set_option("place_min_mib", 1024)
+        dwt.set_option("place_tries", 3)
+
+
+def test_mapped_buffers_are_ordinary_device_memory(dwt, oracle):
+    """The diagnosis instruments (dwt_hip_malloc_mapped / _spread: buffers mapped from physical pieces
+    through HIP's virtual-memory API) hand out memory every entry accepts and dwt_hip_free releases."""
+    L = dwt.lib
+    h, w = 300, 700
+    img = np.random.default_rng(5).random((h, w), dtype=np.float32)
+    want = img.copy()
+    jw = oracle.fwd("cdf97_2f_s", want, 3)
+    for p in (L.dwt_hip_malloc_mapped(img.nbytes, 2 << 20, 2, 0), L.dwt_hip_malloc_spread(img.nbytes, 2 << 20)):
+        assert p, dwt.last_error()
+        assert L.dwt_hip_is_device_pointer(p)
+        assert L.dwt_hip_memcpy_h2d(p, img.ctypes.data, img.nbytes) == 0
+        assert dwt.dwt_cdf97_2f_s(p, w * 4, 4, w, h, w, h, 3) == jw
+        got = np.empty_like(img)
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, p, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        L.dwt_hip_free(p)
+
+
 def test_randomised_soak():
     """scripts/stress.py for 20 s: random shapes, levels, wavelets, entries and layouts; the fused
     kernels against the exact line-pass / two-pass kernels bit for bit, plus round trips."""

@@ -124,6 +124,16 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst,
 int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *dst,
 	size_t batch_stride, int batch, int stride_x, int size_x, int size_y, int *j);
 
+/* The same batch sharded over several GPUs of ONE process (images are independent: no
+ * collective in the transform).  `src` / `dst` lie in the memory of the calling thread's device, which must
+ * be devices[0]; image b belongs to slot b * n_devices / batch.  Slot 0's shard is transformed where it
+ * lies; every other slot is a persistent host thread with its own context on devices[k] (a device may be
+ * named more than once) that pulls its shard across (hipMemcpyPeerAsync over xGMI), transforms it with
+ * dwt_hip_transform2d_batch and pushes the result back -- all slots at the same time.  Synchronous: returns
+ * when `dst` is complete.  Bytes of `dst` outside the frames keep their values. */
+int dwt_hip_transform2d_batch_sharded(int wavelet, int inverse, const void *src, void *dst,
+	size_t batch_stride, int batch, int stride_x, int size_x, int size_y, int *j, const int *devices, int n_devices);
+
 /* 2-D transforms in the INTERLEAVED (in-place lifting) layout: no de-interleave, level j
  * works on the stride-2^j lattice of the image (even lattice index = low-pass).
  * `wavelet` is DWT_HIP_CDF97_S or DWT_HIP_CDF53_S (and, flavour 0 only, DWT_HIP_CDF97_I for

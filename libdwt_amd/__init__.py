@@ -67,6 +67,8 @@ lib.dwt_hip_last_error.restype = C.c_char_p
 lib.dwt_hip_set_stream.argtypes = [_P]
 lib.dwt_hip_set_workspace.argtypes = [_P, C.c_size_t, _P, C.c_size_t]
 lib.dwt_hip_set_workspace.restype = _I
+lib.dwt_hip_transform2d_batch_sharded.argtypes = [_I, _I, _P, _P, C.c_size_t, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I]
+lib.dwt_hip_transform2d_batch_sharded.restype = _I
 lib.dwt_hip_alloc_batch.argtypes = [_I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_P)]
 lib.dwt_hip_alloc_batch.restype = _I
 lib.dwt_hip_placement_report.argtypes = [C.POINTER(C.c_double), _I]
@@ -410,6 +412,16 @@ def transform2d_batch(wavelet, inverse, src, dst, batch_stride, batch, stride_x,
     rc = lib.dwt_hip_transform2d_batch(WAVELET_ID.get(wavelet, wavelet), int(inverse), _addr(src), _addr(dst),
                                        batch_stride, batch, stride_x, size_x, size_y, C.byref(j))
     _check(rc, "dwt_hip_transform2d_batch")
+    return j.value
+
+
+def transform2d_batch_sharded(wavelet, inverse, src, dst, batch_stride, batch, stride_x, size_x, size_y, j_max, devices):
+    """dwt_hip_transform2d_batch_sharded: the batch split over `devices` (one process, one host thread per slot)."""
+    j = _I(j_max)
+    dv = (_I * len(devices))(*devices)
+    rc = lib.dwt_hip_transform2d_batch_sharded(WAVELET_ID.get(wavelet, wavelet), int(inverse), _addr(src), _addr(dst),
+                                               batch_stride, batch, stride_x, size_x, size_y, C.byref(j), dv, len(devices))
+    _check(rc, "dwt_hip_transform2d_batch_sharded")
     return j.value
 
 

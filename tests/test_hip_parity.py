@@ -566,6 +566,14 @@ def test_c_example_program(dwt, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "volume round trip: success" in out.stderr and "interleaved round trip: success" in out.stderr
+    # examples/batch_multi.c: the batch split over the node's GPUs from one C process (3 slots: several
+    # contexts on the one GPU of the test box), bits equal to the single-GPU batched call
+    exe = tmp_path / "batch_multi"
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "batch_multi.c"), "-o", str(exe),
+                           "-L", libdir, "-l:libdwt_hip.so", "-Wl,-rpath," + libdir, "-lm"])
+    out = subprocess.run([str(exe), "7", "1024", "4", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bits equal the single-GPU call" in out.stdout, (out.stdout, out.stderr)
 
 
 def test_harness_helpers(dwt):
@@ -972,6 +980,44 @@ def test_placement_entries(dwt, oracle):
         L.dwt_hip_set_workspace(None, 0, None, 0)
         dwt.set_option("place_min_mib", 1024)
         dwt.set_option("place_tries", 3)
+
+
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
+def test_batch_sharded_over_devices_in_one_process(dwt, oracle, wname):
+    """dwt_hip_transform2d_batch_sharded (one process, one host thread + context per device, image
+    b -> slot b*G/B, peer copies for the split only): devices {0}, {0, 0} and {0, 0, 0} (several contexts on
+    the one GPU of the test box -- the same code path as several GPUs) give the oracle's bits, forward and
+    inverse, dense and padded pitch (bytes between the frames untouched), more slots than images."""
+    ff, fi, dt = NAMES[wname]
+    L = dwt.lib
+    nb, h, w, J = 5, 260, 520, 3
+    rng = np.random.default_rng(77)
+    for pitch_e in (w, w + 12):
+        buf = rand_img(rng, nb * h, pitch_e, dt).reshape(nb, h, pitch_e)
+        want = buf.copy()
+        for k in range(nb):
+            oracle.fwd(ff, want[k][:, :w], J)
+        rec = want.copy()
+        for k in range(nb):
+            oracle.inv(fi, rec[k][:, :w], J)
+        src, dst = L.dwt_hip_malloc(buf.nbytes), L.dwt_hip_malloc(buf.nbytes)
+        bs = h * pitch_e * 4
+        for devices in ([0], [0, 0], [0, 0, 0], [0] * 7):
+            fill = np.full_like(buf, 7)
+            assert L.dwt_hip_memcpy_h2d(src, buf.ctypes.data, buf.nbytes) == 0 and L.dwt_hip_memcpy_h2d(dst, fill.ctypes.data, fill.nbytes) == 0
+            assert dwt.transform2d_batch_sharded(wname, 0, src, dst, bs, nb, pitch_e * 4, w, h, J, devices) == J
+            got = np.empty_like(buf)
+            assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+            assert np.array_equal(bits(got[:, :, :w]), bits(want[:, :, :w])), (devices, pitch_e)
+            assert np.all(got[:, :, w:] == 7), "bytes outside the frames keep their values"
+            # inverse: coefficients in dst -> src
+            assert dwt.transform2d_batch_sharded(wname, 1, dst, src, bs, nb, pitch_e * 4, w, h, J, devices) == J
+            assert L.dwt_hip_memcpy_d2h(got.ctypes.data, src, got.nbytes) == 0
+            assert np.array_equal(bits(got[:, :, :w]), bits(rec[:, :, :w])), (devices, pitch_e)
+        with pytest.raises(dwt.DwtError):
+            dwt.transform2d_batch_sharded(wname, 0, src, dst, bs, nb, pitch_e * 4, w, h, J, [0, 99])
+        L.dwt_hip_free(src)
+        L.dwt_hip_free(dst)
 
 
 def test_mapped_buffers_are_ordinary_device_memory(dwt, oracle):

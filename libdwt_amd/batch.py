@@ -101,7 +101,12 @@ def transform_sharded(batch_on_root, n_items, item_shape, wavelet="cdf97_s", lev
     `transform(block, levels)` defaults to the HIP batch entry (device tensors); the CPU
     tests inject the oracle here, the product never does."""
     rank, world = _world()
-    dtype = torch.int32 if wavelet in ("cdf53_i", "cdf97_i") else torch.float32
+    dtypes = {"cdf97_s": torch.float32, "cdf53_s": torch.float32, "cdf53_i": torch.int32, "cdf97_i": torch.int32,
+              "cdf97_d": torch.float64, "cdf53_d": torch.float64}
+    if wavelet not in dtypes:
+        raise ValueError(f"transform_sharded: unknown wavelet {wavelet!r} (one of {sorted(dtypes)})")
+    dtype = dtypes[wavelet]
+    es = 8 if dtype == torch.float64 else 4
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     local = scatter_images(batch_on_root, n_items, item_shape, dtype, device, root)
@@ -116,7 +121,7 @@ def transform_sharded(batch_on_root, n_items, item_shape, wavelet="cdf97_s", lev
                 raise TypeError(f"block dtype {block.dtype} does not match {wavelet}")
             out = torch.empty_like(block)
             dwt.use_torch_stream()
-            dwt.transform2d_batch(wavelet, int(inverse), block, out, h * w * 4, block.shape[0], w * 4, w, h, lv)
+            dwt.transform2d_batch(wavelet, int(inverse), block, out, h * w * es, block.shape[0], w * es, w, h, lv)
             return out
     local_out = transform(local, levels)
     return gather_images(local_out, n_items, root)

@@ -422,6 +422,16 @@ def test_double_precision_batch(dwt, oracle):
     finally:
         dwt.lib.dwt_hip_free(src)
         dwt.lib.dwt_hip_free(dst)
+    # the Python batch split (libdwt_amd/batch.py, here one rank) keeps the 8-byte element strides
+    torch = pytest.importorskip("torch")
+    from libdwt_amd import batch as B
+
+    got = B.transform_sharded(torch.from_numpy(imgs).cuda(), nb, (n, n), "cdf97_d", 4)
+    torch.cuda.synchronize()
+    for k in range(nb):
+        want = imgs[k].copy()
+        oracle.fwd("cdf97_2f_d", want, 4)
+        assert np.array_equal(bits(got[k].cpu().numpy()), bits(want)), k
 
 
 def test_config4_per_gpu_shape_32x4096(dwt, oracle):

@@ -39,9 +39,11 @@ def _worker(rank, world, port, n_items, h, w, out_path, wavelet="cdf97_s"):
         orc = Oracle()
         orc.set_threads(1)
         rng = np.random.default_rng(2024)
-        fname = {"cdf97_s": "cdf97_2f_s", "cdf53_i": "cdf53_2f_i", "cdf97_i": "cdf97_2f_i"}[wavelet]
+        fname = {"cdf97_s": "cdf97_2f_s", "cdf53_i": "cdf53_2f_i", "cdf97_i": "cdf97_2f_i", "cdf97_d": "cdf97_2f_d"}[wavelet]
         if wavelet == "cdf97_s":
             full = torch.from_numpy(rng.random((n_items, h, w), dtype=np.float32))  # same on every rank; only root's is used
+        elif wavelet == "cdf97_d":
+            full = torch.from_numpy(rng.random((n_items, h, w)))
         else:
             full = torch.from_numpy(rng.integers(-32768, 32768, size=(n_items, h, w), dtype=np.int32))
 
@@ -61,7 +63,7 @@ def _worker(rank, world, port, n_items, h, w, out_path, wavelet="cdf97_s"):
             want = full.clone().numpy()
             for k in range(n_items):
                 orc.fwd(fname, want[k], 3)
-            ok = got.dtype == full.dtype and np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+            ok = got.dtype == full.dtype and np.array_equal(got.numpy().view(np.uint8), want.view(np.uint8))
             with open(out_path, "w") as f:
                 f.write("ok" if ok else "mismatch")
         else:
@@ -80,9 +82,14 @@ def test_sharded_batch_roundtrip_gloo(tmp_path, world, n_items):
     assert out.read_text() == "ok"
 
 
-@pytest.mark.parametrize("wavelet", ["cdf53_i", "cdf97_i"])
+@pytest.mark.parametrize("wavelet", ["cdf53_i", "cdf97_i", "cdf97_d"])
 def test_sharded_int_wavelets_keep_their_dtype(tmp_path, wavelet):
-    """int32 wavelets (reversible 5/3, fixed-point 9/7) through the batch split: blocks stay int32."""
+    """int32 wavelets (reversible 5/3, fixed-point 9/7) and the double-precision 9/7 through the batch split:
+    blocks keep their element type (and, for double, their 8-byte strides); an unknown name is refused."""
+    from libdwt_amd import batch as B
+
+    with pytest.raises(ValueError):
+        B.transform_sharded(None, 1, (8, 8), "cdf97_x")
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(2, _free_port(), 3, 48, 64, str(out), wavelet), nprocs=2, join=True)
     assert out.read_text() == "ok"

@@ -150,9 +150,9 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 /* Single-level 3-D CDF 9/7 float over the interleaved in-place layout of
  * cdf97_3f_ip_sep_horizontal_s / cdf97_3i_ip_sep_horizontal_s
  * (src/volume-dwt.c:677, 1115); `levels` > 1 re-applies it on the LLL lattice
- * (strides doubled) as SURVEY.md s8 a11 describes.  Device pointer, dense x.  Volumes of about
- * 448^3 and more run every level in ONE pass in place (tile halos read from a snapshot, ~10.5 B per
- * voxel), smaller ones in two passes through a scratch volume. */
+ * (strides doubled) as SURVEY.md s8 a11 describes.  Device pointer, dense x.  Levels of 512^3 and
+ * more (256 tiles of 256 x 64 voxel columns or more) run in ONE pass in place (tile halos read from a
+ * snapshot, ~10.8 B per voxel), smaller ones in two passes through a scratch volume. */
 int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z,
 	int size_x, int size_y, int size_z, int levels);
 

@@ -96,6 +96,7 @@ struct Ctx {
 // dwt_hip_set_device(d) first ("single process, 8 devices, one host thread per
 // device").  Options set through dwt_hip_set_option / dwt_util_set_accel are per thread too.
 extern thread_local Ctx g;
+extern thread_local char g_err[512];
 extern thread_local bool g_elems_are_32bit; // set per call: the fused sweeps exist for 4-byte elements only
 
 int fail(const char *fmt, ...);

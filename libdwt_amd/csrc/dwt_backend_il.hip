@@ -238,8 +238,26 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 	return 0;
 }
 
+static int interleaved2d_body(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
+	int *jp, int decompose_one, int dirs);
+
+// (a failure half way through the forward chain must not leave the side stream forked: under a HIP-graph
+// capture an unjoined fork invalidates the capture)
 static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
 	int *jp, int decompose_one, int dirs = 3)
+{
+	const int rc = interleaved2d_body(w, inverse, scale_single, src, dst, sox, soy, six, siy, jp, decompose_one, dirs);
+	if (rc && g.side_pending) {
+		char keep[sizeof(g_err)];
+		memcpy(keep, g_err, sizeof(keep)); // the first error is the one to report
+		side_join();
+		memcpy(g_err, keep, sizeof(keep));
+	}
+	return rc;
+}
+
+static int interleaved2d_body(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
+	int *jp, int decompose_one, int dirs)
 {
 	const int j_limit = ceil_log2(decompose_one ? (sox > soy ? sox : soy) : (sox < soy ? sox : soy));
 	int J = *jp;
@@ -267,6 +285,8 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			pool += (size_t)L[j].pitch * L[j].ly;
 	}
 	if (J > 1) {
+		if (g.ll_external)
+			return fail("the interleaved entries keep their level pyramid in the library's own scratch: hand it back first (dwt_hip_set_workspace(NULL, 0, NULL, 0))");
 		if (grow(&g.ll[0], &g.ll_bytes[0], pool * 4) || grow(&g.ll[1], &g.ll_bytes[1], pool * 4))
 			return 1;
 		float *pa = (float *)g.ll[0], *pb = (float *)g.ll[1];

@@ -258,6 +258,19 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 			break;
 		}
 
+	if (inverse) {
+		// the shell of the one-pass levels, sized ONCE for the largest of them (the loop below runs from the
+		// smallest level up: growing it level by level meant a stream sync + free + malloc per level)
+		size_t shell = 0;
+		for (int j = 0; j < levels; j++)
+			if (ip_level(L[j].p, L[j].sy, L[j].sz, L[j].lx, L[j].ly, L[j].lz)) {
+				VolFusedArgs fa{L[j].p, L[j].sy, L[j].sz, L[j].p, L[j].sy, L[j].sz, nullptr, 0, 0, L[j].lx, L[j].ly, L[j].lz};
+				shell = std::max(shell, vol_level_ip_scratch(fa, g.vol));
+			}
+		if (shell && grow(&g.vol_out, &g.vol_out_bytes, shell))
+			return 1;
+	}
+
 	auto one_level = [&](const Lvl &b, const Lvl *next) -> int {
 		// x then y fused per slice, then z (src/volume-dwt.c:677-725; inverse :1115-1163)
 		hipError_t e;

@@ -171,6 +171,10 @@ __global__ __launch_bounds__(512) void k_il_strip(IlStripArgs a)
 	// lazy strips of il_level); the band's artificial edge, 23-24 samples from the border, reaches 4.
 	constexpr int kKeep = 104, kMargin = 12, kBand = 24, kKeepTop = 8, kKeepRight = 8, kLong = kKeep + 2 * kMargin;
 	constexpr int kOwn = 8, kHalo = 4, kPiece = kOwn + 2 * kHalo;
+	// the lazy strips (dwt_backend_il.hip) rely on this: a forward output depends on inputs at most K away, so what the
+	// next level computes from not-yet-corrected low-pass samples (rows 0..K-1, the last K columns) stays inside ITS kept
+	// region of 2 K rows / columns and is recomputed by its own strips (a race-check tool will flag that read)
+	static_assert(kKeepTop >= 2 * W::K && kKeepRight >= 2 * W::K, "kept region must close over the lifting reach");
 	__shared__ T buf[2][kBand * kLong];
 	// blocks [0, n_top): tiles of the top strip; the rest: tiles of the right strip
 	const bool top = (int)blockIdx.x < a.n_top;

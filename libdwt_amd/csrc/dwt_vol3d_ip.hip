@@ -136,7 +136,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_vol_level_ip(VolFu
 		// that set are reached only by reflections that feed no valid output.)
 		const int u = r + HL, b = u / TY - 1, o = u % TY;
 		const bool inrs = !own && o < 7 && b >= 0 && b < nty - 1;
-		rowinfo = r | (ip && own ? 1 << 16 : 0) | (ip && inrs ? (1 << 17) | ((7 * b + o) << 18) : 0);
+		// (the shell row index takes bits 18..31: decoded as UNSIGNED, good for 7 * 2340 rows of tiles)
+		rowinfo = (int)((unsigned)r | (ip && own ? 1u << 16 : 0u) | (ip && inrs ? (1u << 17) | ((unsigned)(7 * b + o) << 18) : 0u));
 	}
 	// Likewise the single columns a row needs beside its 16-byte pieces: lanes 8..15 fetch the tile's
 	// halo columns (c0-4 .. c0-1, c0+256 .. c0+259), lanes 0..3 the reflected columns right of the
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_vol_level_ip(VolFu
 				const int r = info & 0xffff;
 				const float *grow = sl + (long)r * sy;
 				if (live && (info & (1 << 17)))
-					grow = rsl + (long)(info >> 18) * sh.rs_sy;
+					grow = rsl + (long)((unsigned)info >> 18) * sh.rs_sy;
 				// the volume's own row: its foreign columns come from the column shell
 				const bool shell_cols = live && (info & (1 << 16));
 				const float *crow = csl + (long)r * sh.cs_sy;

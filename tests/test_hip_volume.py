@@ -272,6 +272,28 @@ def test_one_pass_in_place_levels(dwt, oracle, shape, levels, tile_pairs):
     d.free()
 
 
+def test_one_pass_in_place_tall_thin_volume(dwt, oracle):
+    """A volume with more than 8192 / 7 tile rows of 32 (the shell row index of k_vol_level_ip fills the top
+    14 bits of a packed word and is decoded unsigned): 6 x 38000 x 130, tiles of 32 rows (vol_ip_waves = 4),
+    forward and inverse in one pass in place -- the oracle's bits."""
+    shape = (6, 38000, 130)
+    vol = np.random.default_rng(12).random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), 1, False)
+    d = DevVol(dwt, vol)
+    dwt.set_option("vol_fused", 2)
+    dwt.set_option("vol_ip_waves", 4)
+    try:
+        d.run(0, 1)
+        assert np.array_equal(bits(d.get()), bits(want)), "forward"
+        d.run(1, 1)
+        rec = d.get()
+    finally:
+        dwt.set_option("vol_fused", 1)
+        dwt.set_option("vol_ip_waves", 0)
+    assert np.array_equal(bits(rec), bits(oracle_multilevel(oracle, want.copy(), 1, True))), "inverse"
+    d.free()
+
+
 def test_one_pass_in_place_padded_strides(dwt, oracle):
     """The in-place levels address through volume_t strides: padding between rows and slices stays
     untouched, forward and inverse."""

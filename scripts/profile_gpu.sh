@@ -10,7 +10,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu --no-single ${BENCH_ARGS:-}"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu --no-single --no-sweep ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1

@@ -26,10 +26,17 @@ with open(f"{out}/{tag}_kernel_stats.csv", "w", newline="") as f:
 trace = list(csv.DictReader(open(newest(f"{src}/trace/*/*_kernel_trace.csv")[0])))
 sweeps = [r for r in trace if "k_fwd_sweep" in r["Kernel_Name"]]
 gmax = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in sweeps)
-l0 = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sweeps if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == gmax]
-l0 = l0[2:] if len(l0) > 4 else l0  # drop the warm-up launches
+l0_rows = [r for r in sweeps if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == gmax]
+l0_rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the TIMED steps are the last launches of the run (before them: first-placement run, the placement search of
+# dwt_hip_alloc_batch -- hundreds of launches on other arrangements -- and the warm-up)
+STEPS = int(os.environ.get("STEPS", 5))
+l0_rows = l0_rows[-STEPS:]
+l0 = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in l0_rows]
+l0_name = l0_rows[-1]["Kernel_Name"].split("(")[0].replace("void ", "")
 per_level = collections.OrderedDict()
-for r in sweeps:
+sweeps.sort(key=lambda r: int(r["Start_Timestamp"]))
+for r in sweeps[-5 * STEPS:]:  # the timed steps' five levels
     key = (int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]), r["Kernel_Name"].split("(")[0])
     per_level.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
@@ -43,10 +50,11 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         continue
     g = max(int(r["Grid_Size"]) for r in rows)
     acc = collections.defaultdict(list)
-    for r in rows:
+    for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
         if int(r["Grid_Size"]) == g:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
+        v = v[-STEPS:]  # the timed steps (see above)
         pmc[k] = sum(v) / len(v)
 
 # images per launch = grid.y of the level-0 launch (one blockIdx.y per image); env overrides
@@ -54,7 +62,7 @@ gy = max(int(r["Grid_Size_Y"]) for r in sweeps if int(r["Grid_Size_X"]) * int(r[
 images = int(os.environ.get("IMAGES_PER_LAUNCH", gy))
 summary = {
     "tag": tag,
-    "kernel": f"dwt::k_fwd_sweep<dwt::Cdf97S, 8, 16, 7> (level 0: {images} images of 8192x8192 float per launch)",
+    "kernel": f"{l0_name} (level 0: {images} images of 8192x8192 float per launch; the template that ran, from the trace)",
     "level0_avg_ns": sum(l0) / len(l0), "level0_launches": len(l0),
     "algorithmic_bytes_per_launch": 2 * 4 * 8192 * 8192 * images,
     "pmc_per_launch": pmc,
@@ -73,7 +81,7 @@ if "TCC_HIT_sum" in pmc:
 json.dump(summary, open(f"{out}/{tag}_pmc_level0.json", "w"), indent=1)
 
 with open(f"{out}/{tag}_summary.md", "w") as f:
-    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-single` "
+    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-single --no-sweep` "
             f"(+ separate `--pmc` passes), MI355X, see scripts/profile_gpu.sh.\n\n## per-kernel (kernel-trace --stats)\n\n")
     f.write("| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
     for r in keep:

@@ -192,6 +192,9 @@ int dwt_util_save_to_pgm_s(const char *filename, float max_value, const void *pt
 	int size_i_big_x, int size_i_big_y);
 int dwt_util_save_to_pgm_i(const char *filename, int max_value, const void *ptr, int stride_x, int stride_y,
 	int size_i_big_x, int size_i_big_y);
+/* src/libdwt.h:1799 (src/libdwt.c:19727-19792): log(1 + |x|) of every sample (dwt_util_conv_show_s), scaled
+ * to the largest of them, as an ASCII PGM; returns 0 */
+int dwt_util_save_log_to_pgm_s(const char *path, const void *ptr, int stride_x, int stride_y, int size_x, int size_y);
 /* ASCII PGM readers: allocate the image with the optimal stride (src/libdwt.h:1894, 1926);
  * 0 on success, 1 open, 2 header, 3 depth, 4 data, 5 sample out of range */
 int dwt_util_load_from_pgm_s(const char *filename, float max_value, void **pptr, int *pstride_x, int *pstride_y,

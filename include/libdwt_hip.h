@@ -91,23 +91,23 @@ int dwt_hip_alloc_batch(int wavelet, int n_images, int size_x, int size_y, int l
 int dwt_hip_placement_report(double *ms, int n);
 void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int *dst_at, int *ll_at, double *ms4, double *seconds);
 
-/* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).
- * Names: "generic" (1 = force the exact line-pass kernels), "cpt" (0/4/8),
- * "wave_horiz" (0/1), "ring" (8/16), "nt" and "nt_inv" (bit 0 nt stores, bit 1 nt loads),
- * "tile_pairs" (0 = auto), "waves" (1..4), "xcd_swizzle" (0/1), "fma", "fused_d", "nt_auto" (1 = the
- * LL band's stores non-temporal too when a launch's LL bands exceed 1 GiB), "il_lazy_strips" (1 = the
- * interleaved 9/7 forward's exact border strips on a side stream beside the next level's sweep).
- * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two
- * passes), "vol_whole" (1 = the buffer-addressed kernel variant, 0 = the general one as a cross-check),
- * "vol_direct" (levels >= 1 into their lattice of the destination: 2 = rows shared by levels 0
- * and 1 written once, 1 = sample-wise stores, 0 = dense results + scatter passes), "vol_nt"
- * (-1 = default: cacheable loads, non-temporal stores; bit 0 nt stores, bit 1 nt loads, bit 2
- * halo columns exempt), "vol_rows" (8 / 6 output rows per wave), "vol_tile_pairs",
- * "vol_swizzle", "vol_ip_waves" (0 = auto / 4 / 8 waves per workgroup of the one-pass levels: tiles of
- * 32 or 64 rows), "vol_fwd_tall" (1 = out-of-place level 0 in the 64-row tiles), "vol_inplace_fused"
- * (in-place calls: 1 = one fused pass per level in place over a
- * snapshot of the tile halos, forward and inverse; 2 = forward through the out-of-place levels + one
- * copy back; 0 = two passes per level).  Every setting gives the same bits. */
+/* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).  Every setting gives the
+ * same bits; what is left after round 4's pruning is what the tests use as cross-checks or a caller may need.
+ * 2-D: "generic" (1 = force the exact line-pass kernels), "cpt" (0 = auto / 4 / 8 columns per lane),
+ * "tile_pairs" (0 = auto), "waves" (1..4 per workgroup), "xcd_swizzle" (0/1), "ring" (0 = auto / 8 / 16 LDS
+ * rows per wave, forward) and "ring_inv" (8 / 16), "nt" (7 = default cache policy, 3 = the LL band's stores
+ * non-temporal too, 15 = 7 with the neighbour taps by wavefront shifts instead of LDS reads), "nt_auto"
+ * (1 = policy 3 by itself when a launch's LL bands exceed 1 GiB), "fma" (1 = contracted lifting steps:
+ * NOT the reference's rounding, within 1e-5), "fused_d" (0 = double precision through the exact line passes),
+ * "il_lazy_strips" (1 = the interleaved 9/7 forward's exact border strips on a side stream),
+ * "place_tries" / "place_min_mib" (placement search, below).
+ * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two passes),
+ * "vol_whole" (0 = the general kernel variant as a cross-check), "vol_direct" (levels >= 1 into their lattice
+ * of the destination: 2 = rows shared by levels 0 and 1 written once, 1 = sample-wise stores, 0 = dense
+ * results + scatter passes), "vol_nt", "vol_rows" (8 / 6), "vol_tile_pairs", "vol_swizzle", "vol_cpt",
+ * "vol_ip_waves" (0 = auto / 4 / 8 waves per workgroup of the one-pass levels: tiles of 32 or 64 rows),
+ * "vol_inplace_fused" (in-place calls: 1 = one fused pass per level in place over a snapshot of the tile
+ * halos, forward and inverse; 0 = two passes per level). */
 int dwt_hip_set_option(const char *name, int value);
 int dwt_hip_get_option(const char *name);
 

@@ -47,6 +47,8 @@ int volume_copy_s(struct volume_t *volume_dst, struct volume_t *volume_src);
 int volume_compare_s(struct volume_t *volume_l, struct volume_t *volume_r);
 /* src/volume.c:134-163: one PGM per slice, `path` is a printf format taking the slice number */
 void volume_save_to_pgm_s(struct volume_t *volume, const char *path);
+/* src/volume.h:70 (src/volume.c:165-193): the same in a logarithmic scale (dwt_util_save_log_to_pgm_s per slice) */
+void volume_save_log_to_pgm_s(struct volume_t *volume, const char *path);
 /* src/volume.c:221-225: nothing to flush on the device path; kept for source compatibility */
 void volume_invalidate_cache(struct volume_t *volume);
 

@@ -42,31 +42,15 @@ struct Ctx {
 	hipEvent_t dl_ev[8] = {}; // strip events of host_download, created once
 	void *pin = nullptr; // pinned host staging for host-pointer calls with awkward strides
 	size_t pin_bytes = 0;
-	// pipeline lanes for batches: image k runs all its levels on lane k % lanes, so the
-	// small tail levels of one image overlap the big levels of the next
-	struct Lane {
-		hipStream_t stream = nullptr;
-		void *ll[2] = {nullptr, nullptr};
-		size_t ll_bytes[2] = {0, 0};
-		void *stage_img = nullptr;
-		size_t stage_bytes = 0;
-		hipEvent_t done = nullptr;
-	};
-	static constexpr int kMaxLanes = 4;
-	Lane lanes[kMaxLanes];
-	hipEvent_t fork = nullptr;
-	// side stream: the copy-back of an in-place level 0 (and the copy-aside of an in-place
-	// final inverse level) overlaps the small levels instead of preceding/following them
+	// side stream: the exact border strips of the interleaved 9/7 forward beside the next level's sweep
 	hipStream_t side = nullptr;
 	hipEvent_t side_a = nullptr, side_b = nullptr, side_c = nullptr;
 	bool side_pending = false;
-	int pipeline = 0; // 0: one launch per level for the whole batch; n>=2: n lanes
 	// options
 	SweepTuning tune;
 	VolTuning vol;
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
-	int inplace_overlap = 0; // 1: the copy-back (forward) / copy-aside (inverse) of an in-place call on a side stream beside the deeper levels (measured 8-10 us slower than in line)
 	int il_lazy_strips = 1; // interleaved 9/7 forward: the exact border strips on the side stream beside the next level's sweep (0: in line)
 	long ll_offset = 0; // bytes between the start of an LL scratch allocation and the band (placement experiments)
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of

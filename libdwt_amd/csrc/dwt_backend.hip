@@ -428,18 +428,6 @@ int prof_drain()
 	return 0;
 }
 
-// make a lane's stream and scratch the active ones (and back)
-void swap_lane(Ctx::Lane &l)
-{
-	std::swap(g.stream, l.stream);
-	std::swap(g.ll[0], l.ll[0]);
-	std::swap(g.ll[1], l.ll[1]);
-	std::swap(g.ll_bytes[0], l.ll_bytes[0]);
-	std::swap(g.ll_bytes[1], l.ll_bytes[1]);
-	std::swap(g.stage_img, l.stage_img);
-	std::swap(g.stage_bytes, l.stage_bytes);
-}
-
 long ll_pitch_elems(int w) { return align_up(w, 4) + g.ll_pad; }
 static char *ll_band(int k) { return (char *)g.ll[k] + g.ll_offset; }
 
@@ -546,12 +534,10 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				return fail("forward level %d launch failed: %s", j, hipGetErrorString(e));
 			if (detour) {
 				// copy the staged subbands to their place: right half, bottom-left, and the LL
-				// quadrant too when it was written here.  On the side stream: the deeper levels
-				// only touch the top-left quadrant and run meanwhile.
-				if (g.inplace_overlap && side_fork())
-					return 1;
+				// quadrant too when it was written here (in line: on a side stream beside the deeper
+				// levels it measured 8-10 us slower, profiles/r03_entries_summary.md)
 				const Rect rc[3] = {{Wd, 0, Wd, 0, Wo - Wd, Ho}, {0, Hd, 0, Hd, Wd, Ho - Hd}, {0, 0, 0, 0, last ? Wd : 0, Hd}};
-				if (copy_rects_on(g.inplace_overlap ? g.side : g.stream, dst, hdst, rc, 3))
+				if (copy_rects_on(g.stream, dst, hdst, rc, 3))
 					return 1;
 			}
 			ll_in = ll_out;
@@ -632,27 +618,6 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 	long cur_bstride = src_bstride;
 	int ll_in = -1;         // -1: LL band is in `cur`; else scratch index
 	bool copied = false;
-	// In place with every level fused: the detail subbands of level 1 have to be moved
-	// aside before the final level overwrites them.  Start that copy now, on the side
-	// stream, so that it overlaps the deeper (small) levels.
-	bool aside_early = false;
-	if (src.p == dst.p && J >= 2 && batch == 1) {
-		bool all_fused = true;
-		for (int j = 1; j <= J; j++)
-			all_fused = all_fused && fused_ok(j);
-		if (all_fused && g.inplace_overlap) {
-			const int Ws = ge.Wo(1), Hs = ge.Ho(1), Wo = ge.Wo(0), Ho = ge.Ho(0);
-			if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
-				return 1;
-			Img st{(char *)g.stage_img, dst.sx, es};
-			if (side_fork())
-				return 1;
-			const Rect rc[2] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}};
-			if (copy_rects_on(g.side, st, src, rc, 2))
-				return 1;
-			aside_early = true;
-		}
-	}
 	for (int j = J; j >= 1; j--) {
 		const int Ws = ge.Wo(j), Hs = ge.Ho(j);       // subband sizes (= Mallat offsets)
 		const int Wo = ge.Wo(j - 1), Ho = ge.Ho(j - 1); // produced frame
@@ -688,14 +653,11 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 					if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 						return 1;
 					Img st{(char *)g.stage_img, dst.sx, es};
-					if (aside_early) {
-						if (side_join()) // the copy started before the deeper levels
-							return 1;
-					} else {
-						const Rect rc[3] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}, {0, 0, 0, 0, ll_in < 0 ? Ws : 0, Hs}};
-						if (copy_rects_on(g.stream, st, cur, rc, 3))
-							return 1;
-					}
+					// (in line, like the forward copy-back: started early on a side stream beside the deeper levels it
+					// measured slower)
+					const Rect rc[3] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}, {0, 0, 0, 0, ll_in < 0 ? Ws : 0, Hs}};
+					if (copy_rects_on(g.stream, st, cur, rc, 3))
+						return 1;
 					a.in_h = st.p;
 					a.h_bstride = 0;
 					if (ll_in < 0)
@@ -989,15 +951,6 @@ void dwt_hip_finish(void)
 		hipHostFree(g.pin);
 	g.pin = nullptr;
 	g.pin_bytes = 0;
-	for (auto &l : g.lanes) {
-		void **lb[] = {&l.ll[0], &l.ll[1], &l.stage_img};
-		for (void **p : lb) {
-			if (*p)
-				hipFree(*p);
-			*p = nullptr;
-		}
-		l.ll_bytes[0] = l.ll_bytes[1] = l.stage_bytes = 0;
-	}
 	for (auto &ev : g.prof_events) {
 		hipEventDestroy(ev.first);
 		hipEventDestroy(ev.second);
@@ -1071,8 +1024,6 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.waves = value;
 	else if (!strcmp(name, "xcd_swizzle"))
 		g.tune.xcd_swizzle = value;
-	else if (!strcmp(name, "wave_horiz"))
-		g.tune.wave_horiz = value;
 	else if (!strcmp(name, "ring"))
 		g.tune.ring = value;
 	else if (!strcmp(name, "nt_auto"))
@@ -1081,16 +1032,10 @@ int dwt_hip_set_option(const char *name, int value)
 		g.il_lazy_strips = value;
 	else if (!strcmp(name, "vol_ip_waves"))
 		g.vol.ip_waves = value;
-	else if (!strcmp(name, "vol_fwd_tall"))
-		g.vol.fwd_tall = value;
 	else if (!strcmp(name, "nt"))
 		g.tune.nt = value;
-	else if (!strcmp(name, "nt_inv"))
-		g.tune.nt_inv = value;
 	else if (!strcmp(name, "ring_inv"))
 		g.tune.ring_inv = value;
-	else if (!strcmp(name, "wave_horiz_inv"))
-		g.tune.wave_horiz_inv = value;
 	else if (!strcmp(name, "fma"))
 		g.fma = value;
 	else if (!strcmp(name, "fused_d"))
@@ -1103,8 +1048,6 @@ int dwt_hip_set_option(const char *name, int value)
 		g.place_min_mib = value < 0 ? 0 : value;
 	else if (!strcmp(name, "ll_pad"))
 		g.ll_pad = value < 0 ? 0 : (value + 3) / 4 * 4;
-	else if (!strcmp(name, "inplace_overlap"))
-		g.inplace_overlap = value;
 	else if (!strcmp(name, "vol_cpt"))
 		g.vol.cpt = value;
 	else if (!strcmp(name, "vol_tile_pairs"))
@@ -1118,13 +1061,11 @@ int dwt_hip_set_option(const char *name, int value)
 	else if (!strcmp(name, "vol_whole"))
 		g.vol.whole = value;
 	else if (!strcmp(name, "vol_inplace_fused"))
-		g.vol.inplace_fused = value;
+		g.vol.inplace_fused = value ? 1 : 0;
 	else if (!strcmp(name, "vol_swizzle"))
 		g.vol.swizzle = value;
 	else if (!strcmp(name, "vol_rows"))
 		g.vol.rows = value;
-	else if (!strcmp(name, "pipeline"))
-		g.pipeline = value < 2 ? 0 : (value > Ctx::kMaxLanes ? Ctx::kMaxLanes : value);
 	else
 		return fail("unknown option '%s'", name);
 	return 0;
@@ -1142,8 +1083,6 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.waves;
 	if (!strcmp(name, "xcd_swizzle"))
 		return g.tune.xcd_swizzle;
-	if (!strcmp(name, "wave_horiz"))
-		return g.tune.wave_horiz;
 	if (!strcmp(name, "ring"))
 		return g.tune.ring;
 	if (!strcmp(name, "nt_auto"))
@@ -1152,28 +1091,18 @@ int dwt_hip_get_option(const char *name)
 		return g.il_lazy_strips;
 	if (!strcmp(name, "vol_ip_waves"))
 		return g.vol.ip_waves;
-	if (!strcmp(name, "vol_fwd_tall"))
-		return g.vol.fwd_tall;
 	if (!strcmp(name, "nt"))
 		return g.tune.nt;
-	if (!strcmp(name, "nt_inv"))
-		return g.tune.nt_inv;
 	if (!strcmp(name, "ring_inv"))
 		return g.tune.ring_inv;
-	if (!strcmp(name, "wave_horiz_inv"))
-		return g.tune.wave_horiz_inv;
 	if (!strcmp(name, "vol_swizzle"))
 		return g.vol.swizzle;
 	if (!strcmp(name, "vol_rows"))
 		return g.vol.rows;
-	if (!strcmp(name, "pipeline"))
-		return g.pipeline;
 	if (!strcmp(name, "fma"))
 		return g.fma;
 	if (!strcmp(name, "fused_d"))
 		return g.fused_d;
-	if (!strcmp(name, "inplace_overlap"))
-		return g.inplace_overlap;
 	if (!strcmp(name, "vol_cpt"))
 		return g.vol.cpt;
 	if (!strcmp(name, "vol_tile_pairs"))
@@ -1386,39 +1315,6 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 		return fail("in-place batches are not supported; use distinct src and dst");
 	const Geom ge{size_x, size_y, size_x, size_y};
 	Img s{(char *)src, stride_x, es}, d{(char *)dst, stride_x, es};
-	if (g.pipeline >= 2 && batch >= 2) {
-		// per-image pipelines on internal streams, forked from and joined to the caller's stream
-		const int nl = g.pipeline < batch ? g.pipeline : batch;
-		if (!g.fork)
-			HIP_TRY(hipEventCreateWithFlags(&g.fork, hipEventDisableTiming));
-		for (int l = 0; l < nl; l++) {
-			if (!g.lanes[l].stream) {
-				HIP_TRY(hipStreamCreateWithFlags(&g.lanes[l].stream, hipStreamNonBlocking));
-				HIP_TRY(hipEventCreateWithFlags(&g.lanes[l].done, hipEventDisableTiming));
-			}
-		}
-		HIP_TRY(hipEventRecord(g.fork, g.stream));
-		for (int l = 0; l < nl; l++)
-			HIP_TRY(hipStreamWaitEvent(g.lanes[l].stream, g.fork, 0));
-		int rc = 0;
-		const int j_in = *j;
-		for (int k = 0; k < batch && !rc; k++) {
-			Ctx::Lane &lane = g.lanes[k % nl];
-			Img sk{s.p + (size_t)k * batch_stride, s.sx, es}, dk{d.p + (size_t)k * batch_stride, d.sx, es};
-			int jk = j_in;
-			swap_lane(lane);
-			rc = inverse ? inverse2d((Wavelet)wavelet, sk, dk, ge, jk, 0, 0, 1, 0, 0)
-			             : forward2d((Wavelet)wavelet, sk, dk, ge, &jk, 0, 0, 1, 0, 0);
-			swap_lane(lane);
-			if (!inverse)
-				*j = jk;
-		}
-		for (int l = 0; l < nl; l++) {
-			HIP_TRY(hipEventRecord(g.lanes[l].done, g.lanes[l].stream));
-			HIP_TRY(hipStreamWaitEvent(g.stream, g.lanes[l].done, 0));
-		}
-		return rc;
-	}
 	if (!inverse && (*j < 0 || *j >= 2) && place_ll_scratch((Wavelet)wavelet, s, d, ge, *j, batch, (long)batch_stride, (long)batch_stride))
 		return 1;
 	return inverse ? inverse2d((Wavelet)wavelet, s, d, ge, *j, 0, 0, batch, (long)batch_stride, (long)batch_stride)

@@ -84,7 +84,7 @@ static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long
 				if (grow(&g.vol_out, &g.vol_out_bytes, vol_level_ip_scratch(fa, g.vol)))
 					return 1;
 				e = launch_vol_level_ip(false, fa, (float *)g.vol_out, g.vol, g.stream);
-			} else if (g.vol.fwd_tall && (fa.mode == 0 || fa.mode == 2) && g.vol.whole && g.vol.rows != 6 && vol_level_ip_can(fa)) {
+			} else if ((fa.mode == 0 || fa.mode == 2) && g.vol.whole && g.vol.rows != 6 && vol_level_ip_can(fa)) {
 				// dense / withholding levels: the 64-row tiles of dwt_vol3d_ip.hip's kernel, out of place
 				e = launch_vol_level_op(false, fa, g.vol, g.stream);
 			} else {
@@ -183,44 +183,6 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 	};
 	if (!inverse && levels <= kMaxVolLevels && ip_level((const float *)vol, vsy0, vsz0, nx, ny, nz))
 		return vol_forward_op((const float *)vol, vsy0, vsz0, (float *)vol, vsy0, vsz0, nx, ny, nz, levels);
-	// Round 2's forward route (option vol_inplace_fused = 2): the out-of-place levels into a dense
-	// result volume, then ONE copy back -- 8 + 8 B per voxel for level 0 like the two passes, but the
-	// deeper levels, their lattice packing and unpacking ride along and both halves run at better
-	// rates (1024^3: 3.1 against 3.3-3.4 ms for one level, 3.9 against 4.4-4.6 for three).
-	if (!inverse && g.vol.inplace_fused == 2 && !g.force_generic && g.vol.fused >= 1) {
-		VolFusedArgs t{(const float *)vol, (long)stride_y / 4, (long)stride_z / 4, nullptr, 0, 0, nullptr, 0, 0, nx, ny, nz};
-		// pays from about 2 GiB on: below, the two passes run partly out of the 256 MiB Infinity Cache
-		// (512^3: 0.44 ms in two passes, 0.29 + 0.2 fused + copy)
-		const bool big = (size_t)nx * ny * nz >= ((size_t)1 << 29);
-		if (levels <= kMaxVolLevels && (g.vol.fused >= 2 || (big && vol_fused_applies(t)))) {
-			const long osy = align_up(nx, 4), osz = osy * ny;
-			if (grow(&g.vol_out, &g.vol_out_bytes, (size_t)osz * nz * 4))
-				return 1;
-			float *out = (float *)g.vol_out;
-			if (vol_forward_op((const float *)vol, (long)stride_y / 4, (long)stride_z / 4, out, osy, osz, nx, ny, nz, levels))
-				return 1;
-			// copy back: all rows at once when the slices of the caller's volume are contiguous rows,
-			// and as rows of 64 KiB when the volume is one contiguous block
-			const size_t row = (size_t)nx * 4, total = row * ny * nz;
-			const bool flat = stride_z == stride_y * (size_t)ny && (long)ny * nz <= 0x7fffffffL;
-			const bool block = flat && stride_y == row && (size_t)osy * 4 == row && total % 65536 == 0 && total / 65536 <= 0x7fffffffUL;
-			const int nrect = flat ? 1 : nz;
-			for (int k = 0; k < nrect; k++) {
-				CopyRects r{};
-				r.n = 1;
-				r.src[0] = (const char *)(out + (long)k * osz);
-				r.dst[0] = (char *)vol + (size_t)k * stride_z;
-				r.spitch[0] = block ? 65536 : osy * 4;
-				r.dpitch[0] = block ? 65536 : (long)stride_y;
-				r.wbytes[0] = block ? 65536 : (int)row;
-				r.h[0] = block ? (int)(total / 65536) : flat ? ny * nz : ny;
-				hipError_t e = launch_copy_rects(r, g.stream);
-				if (e != hipSuccess)
-					return fail("volume copy-back launch failed: %s", hipGetErrorString(e));
-			}
-			return 0;
-		}
-	}
 	// scratch: S (pass-to-pass buffer) and, for levels >= 1, dense copies P[j] of the
 	// level-j lattice (even-even-even samples of level j-1), all carved from one buffer
 	const long s_sy = align_up(nx, 4), s_sz = s_sy * ny;

@@ -19,14 +19,11 @@ struct SweepTuning {
 	int tile_pairs = 0; // output row pairs per wave tile; 0 = choose from the level height
 	int waves = 4;      // waves per workgroup (each wave owns one tile)
 	int xcd_swizzle = 1; // remap workgroups so neighbouring tiles share an XCD's L2
-	int wave_horiz = -1; // waves of a workgroup side by side (1) or stacked (0); -1 = auto
 	int ring = 0;        // LDS ring rows per wave (8 or 16); 0 = auto
-	int nt = 7;          // forward: bit 0 non-temporal stores, bit 1 non-temporal LDS-DMA loads,
-	                     // bit 2 keep the LL band's stores temporal (the next level reads it)
+	int nt = 7;          // forward cache policy: loads and detail stores are non-temporal; bit 2 keeps the LL band's
+	                     // stores temporal (the next level reads it), bit 3 takes the neighbour taps by wavefront shifts
 	int nt_auto = 1;     // forward: drop bit 2 of `nt` when the launch's LL bands exceed the Infinity Cache
-	int nt_inv = 1;      // inverse sweep: non-temporal stores only (measured best)
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
-	int wave_horiz_inv = 0;
 };
 
 // One decomposition level, forward, dense frame (size_o == size_i, W,H >= 2).
@@ -84,14 +81,13 @@ struct VolTuning {
 	int nt = -1;        // bit 0 non-temporal stores, bit 1 non-temporal loads; -1 = measured default
 	                    // (z pass: 0, fused level: stores non-temporal, +9 %)
 	int inplace_fused = 1; // in-place calls: 1 = one fused pass per level in place over a snapshot of the tile halos (forward and inverse),
-	                       // 2 = forward: out-of-place fused levels into a result volume + one copy back (round 2), 0 = two passes per level
+	                       // 0 = two passes per level (the cross-check)
 	int whole = 1;      // whole-tile variant of the fused kernel where the volume allows (0: the general one)
 	int direct = 2;     // fused levels >= 1 write into their lattice of the destination: 2 = level 1 merged with level 0's withheld rows where the sizes allow, 1 = strided stores, 0 = dense volume + scatter pass
 	int fused = 1;      // out-of-place forward levels: 1 = one fused pass where it pays, 2 = wherever it can run, 0 = two passes
 	int swizzle = 1;    // fused level: hand contiguous runs of tiles to one XCD
 	int rows = 8;       // fused level: output rows per wave, 8 (measured best) or 6 (two workgroups per CU)
 	int ip_waves = 0;   // k_vol_level_ip: waves per workgroup, 4 (tiles of 32 rows, two workgroups per CU) or 8 (64 rows, one); 0 = 8 where the volume has more than 32 rows
-	int fwd_tall = 1;   // out-of-place forward levels 0 (dense / withholding) through k_vol_level_ip's 64-row tiles instead of k_vol_fwd_fused
 };
 
 // z pass of the 3-D path: CDF 9/7 float along the slice axis of an interleaved volume,

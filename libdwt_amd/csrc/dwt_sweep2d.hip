@@ -787,33 +787,23 @@ static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 gri
 template <class W, int CPT>
 static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, const SweepTuning &t, hipStream_t s)
 {
-	// bits 0-2: cache policy (all eight built for A/B runs); bit 3 (wavefront shuffles
-	// for the neighbour taps) is built on top of the default policy 7 and of policy 0
-	int nt = t.nt & 15;
-	if ((nt & 8) && nt != 15 && nt != 8)
-		nt = 15;
-#define DWT_FWD_CASE(R, N) case N: return fwd_launch<W, CPT, R, N>(a, g, grid, waves, s)
-	if (nt == 7 && (t.ring == 10 || t.ring == 12 || t.ring == 14)) {
-		if (t.ring == 10)
-			return fwd_launch<W, CPT, 10, 7>(a, g, grid, waves, s);
-		if (t.ring == 12)
-			return fwd_launch<W, CPT, 12, 7>(a, g, grid, waves, s);
-		return fwd_launch<W, CPT, 14, 7>(a, g, grid, waves, s);
-	}
+	// cache policy 7 (non-temporal loads and detail stores, the LL band's stores temporal), 3 (the LL band
+	// non-temporal too: launches whose LL bands exceed the Infinity Cache), 15 (= 7 with the neighbour taps
+	// by wavefront shifts instead of LDS reads: bit-identical, 0.8 % slower, the cross-check variant).  The
+	// other policies and ring depths of rounds 1-3 measured slower and are gone (profiles/r02_experiments.md).
+	const int nt = (t.nt & 8) ? 15 : (t.nt & 4) ? 7 : 3;
 	if (t.ring == 16) {
 		switch (nt) {
-			DWT_FWD_CASE(16, 0); DWT_FWD_CASE(16, 1); DWT_FWD_CASE(16, 2); DWT_FWD_CASE(16, 3);
-			DWT_FWD_CASE(16, 4); DWT_FWD_CASE(16, 5); DWT_FWD_CASE(16, 6); DWT_FWD_CASE(16, 7);
-			DWT_FWD_CASE(16, 8); DWT_FWD_CASE(16, 15);
+		case 3: return fwd_launch<W, CPT, 16, 3>(a, g, grid, waves, s);
+		case 7: return fwd_launch<W, CPT, 16, 7>(a, g, grid, waves, s);
+		default: return fwd_launch<W, CPT, 16, 15>(a, g, grid, waves, s);
 		}
 	}
 	switch (nt) {
-		DWT_FWD_CASE(8, 0); DWT_FWD_CASE(8, 1); DWT_FWD_CASE(8, 2); DWT_FWD_CASE(8, 3);
-		DWT_FWD_CASE(8, 4); DWT_FWD_CASE(8, 5); DWT_FWD_CASE(8, 6); DWT_FWD_CASE(8, 7);
-		DWT_FWD_CASE(8, 8); DWT_FWD_CASE(8, 15);
+	case 3: return fwd_launch<W, CPT, 8, 3>(a, g, grid, waves, s);
+	case 7: return fwd_launch<W, CPT, 8, 7>(a, g, grid, waves, s);
+	default: return fwd_launch<W, CPT, 8, 15>(a, g, grid, waves, s);
 	}
-#undef DWT_FWD_CASE
-	return hipErrorInvalidValue;
 }
 
 template <class W>
@@ -836,11 +826,10 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	// side-by-side waves beat 8 waves/CU with an 8-row ring (5.5 -> 6.0 TB/s at level 0);
 	// smaller launches prefer more resident waves.
 	SweepTuning tt = t;
-	if (tt.ring != 8 && tt.ring != 16 && tt.ring != 10 && tt.ring != 12 && tt.ring != 14)
+	if (tt.ring != 8 && tt.ring != 16)
 		tt.ring = (g.ntx >= waves && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
-	if (tt.wave_horiz < 0)
-		tt.wave_horiz = tt.ring >= 10;
-	g.wave_horiz = tt.wave_horiz;
+	// deep ring: the waves of a workgroup take side-by-side tiles (+ 7 %); shallow: stacked tiles
+	g.wave_horiz = tt.ring == 16;
 	dim3 grid;
 	if (g.wave_horiz)
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
@@ -863,7 +852,7 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	// one process, alternated: level 0 5863-5882 -> 5959-5964 GB/s, level 1 5323-5341 -> 5381-5409, step
 	// 8.08-8.10 -> 8.00-8.02 ms).  At 0.5 GB of LL (8 images) the two policies tie (level 0 loses what
 	// level 1 gains), below that temporal wins: switch from 1 GiB on.  Option nt_auto = 0 turns it off.
-	if (tt.nt_auto && (tt.nt & 15) == 7 && (size_t)a.batch * ((a.W + 1) / 2) * ((a.H + 1) / 2) * sizeof(typename W::T) >= ((size_t)1 << 30))
+	if (tt.nt_auto && (tt.nt & 12) == 4 && (size_t)a.batch * ((a.W + 1) / 2) * ((a.H + 1) / 2) * sizeof(typename W::T) >= ((size_t)1 << 30))
 		tt.nt = 3;
 	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, tt, s) : fwd_pick<W, 4>(a, g, grid, waves, tt, s);
 }
@@ -879,15 +868,13 @@ static hipError_t inv_launch(const InvLevelArgs &a, const SweepGeom &g, dim3 gri
 }
 
 template <class W, int CPT>
-static hipError_t inv_pick(const InvLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, int ring, int nt, hipStream_t s)
+static hipError_t inv_pick(const InvLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, int ring, hipStream_t s)
 {
-#define DWT_INV_CASE(R, N) case N: return inv_launch<W, CPT, R, N, false>(a, g, grid, waves, s)
-	if (ring == 16) {
-		switch (nt & 3) { DWT_INV_CASE(16, 0); DWT_INV_CASE(16, 1); DWT_INV_CASE(16, 2); DWT_INV_CASE(16, 3); }
-	}
-	switch (nt & 3) { DWT_INV_CASE(8, 0); DWT_INV_CASE(8, 1); DWT_INV_CASE(8, 2); DWT_INV_CASE(8, 3); }
-#undef DWT_INV_CASE
-	return hipErrorInvalidValue;
+	// non-temporal stores, cacheable loads (the four source segments of a row pair live on L2 hits: non-temporal
+	// loads measured 4.37 against 5.35 TB/s); ring 16 is the cross-check variant (5.21)
+	if (ring == 16)
+		return inv_launch<W, CPT, 16, 1, false>(a, g, grid, waves, s);
+	return inv_launch<W, CPT, 8, 1, false>(a, g, grid, waves, s);
 }
 
 template <class W>
@@ -905,7 +892,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + g.tile_pairs - 1) / g.tile_pairs;
 	int ring = t.ring_inv == 16 ? 16 : 8;
-	g.wave_horiz = t.wave_horiz_inv > 0;
+	g.wave_horiz = 0;
 	dim3 grid;
 	if (g.wave_horiz)
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
@@ -918,7 +905,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 			return hipErrorInvalidValue;
 		}
 	}
-	return cpt == 8 ? inv_pick<W, 8>(a, g, grid, waves, ring, t.nt_inv, s) : inv_pick<W, 4>(a, g, grid, waves, ring, t.nt_inv, s);
+	return cpt == 8 ? inv_pick<W, 8>(a, g, grid, waves, ring, s) : inv_pick<W, 4>(a, g, grid, waves, ring, s);
 }
 
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s)

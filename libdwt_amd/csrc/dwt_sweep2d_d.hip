@@ -231,7 +231,7 @@ static hipError_t fwd_level_d_t(const FwdLevelArgs &a, const SweepTuning &t, hip
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + tp - 1) / tp;
 	const int ring = (t.ring == 8 || t.ring == 16) ? t.ring : ((g.ntx >= waves && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8);
-	g.wave_horiz = t.wave_horiz < 0 ? ring == 16 : t.wave_horiz;
+	g.wave_horiz = ring == 16;
 	dim3 grid;
 	if (g.wave_horiz)
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
@@ -472,7 +472,7 @@ static hipError_t inv_level_d_t(const InvLevelArgs &a, const SweepTuning &t, hip
 	g.swz = t.xcd_swizzle;
 	const int waves = t.waves >= 1 && t.waves <= 4 ? t.waves : 4;
 	const int nty = (Hd + tp - 1) / tp;
-	g.wave_horiz = t.wave_horiz_inv > 0;
+	g.wave_horiz = 0;
 	dim3 grid;
 	if (g.wave_horiz)
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);

@@ -411,6 +411,25 @@ void dwt_util_conv_show_i(const void *src, void *dst, int stride_x, int stride_y
 		}
 }
 
+/* src/libdwt.c:19727-19792: temp = conv_show(input); scale = the largest sample of temp (dwt_util_find_min_max_s,
+ * :25426); ASCII PGM of temp against that scale */
+int dwt_util_save_log_to_pgm_s(const char *path, const void *ptr, int stride_x, int stride_y, int size_x, int size_y)
+{
+	void *temp = NULL;
+	dwt_util_alloc_image(&temp, stride_x, stride_y, size_x, size_y);
+	dwt_util_conv_show_s(ptr, temp, stride_x, stride_y, size_x, size_y);
+	float maxv = ld_s(px(temp, 0, 0, stride_x, stride_y));
+	for (int y = 0; y < size_y; y++)
+		for (int x = 0; x < size_x; x++) {
+			const float v = ld_s(px(temp, y, x, stride_x, stride_y));
+			if (v > maxv)
+				maxv = v;
+		}
+	dwt_util_save_to_pgm_s(path, maxv, temp, stride_x, stride_y, size_x, size_y);
+	dwt_util_free_image(&temp);
+	return 0;
+}
+
 /* ---- ASCII PGM (src/libdwt.c:19794-19872 float, :19728-19792 int) ---- */
 int dwt_util_save_to_pgm_s(const char *filename, float max_value, const void *ptr, int stride_x, int stride_y,
 	int size_i_big_x, int size_i_big_y)

@@ -185,6 +185,19 @@ void volume_save_to_pgm_s(struct volume_t *volume, const char *path)
 	host_view_done(volume, h, 0);
 }
 
+/* src/volume.c:165-193 */
+void volume_save_log_to_pgm_s(struct volume_t *volume, const char *path)
+{
+	char *h = host_view(volume, 1);
+	for (int z = 0; z < volume->size_z; z++) {
+		char file_name[4096];
+		snprintf(file_name, sizeof file_name, path, z);
+		dwt_util_save_log_to_pgm_s(file_name, h + (size_t)z * volume->stride_z, (int)volume->stride_y, (int)volume->stride_x,
+			volume->size_x, volume->size_y);
+	}
+	host_view_done(volume, h, 0);
+}
+
 void volume_invalidate_cache(struct volume_t *volume)
 {
 	(void)volume; /* src/volume.c:221-225 flushes the CPU's caches before a timed run; HBM has no such state to reset */

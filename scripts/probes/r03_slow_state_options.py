@@ -29,8 +29,8 @@ for k, sp in enumerate([0, 1.3, 0.7, 2.6, 7, 11, 3.3, 5.1, 17, 23]):
         del src, dst, spacer; torch.cuda.empty_cache()
     if len(found) == 2:
         break
-D = dict(cpt=0, tile_pairs=0, waves=4, xcd_swizzle=1, wave_horiz=-1, ring=0, nt=7, nt_auto=1)
-variants = ["", "xcd_swizzle=0", "wave_horiz=0", "tile_pairs=32", "tile_pairs=128", "ring=8", "nt=7,nt_auto=0", "nt=1,nt_auto=0", "nt=0,nt_auto=0", "nt=5,nt_auto=0", "cpt=4", "waves=2", "waves=1"]
+D = dict(cpt=0, tile_pairs=0, waves=4, xcd_swizzle=1, ring=0, nt=7, nt_auto=1)
+variants = ["", "xcd_swizzle=0", "tile_pairs=32", "tile_pairs=128", "ring=8", "nt=7,nt_auto=0", "nt=1,nt_auto=0", "nt=0,nt_auto=0", "nt=5,nt_auto=0", "cpt=4", "waves=2", "waves=1"]
 for v in variants:
     for k_, d_ in D.items(): dwt.set_option(k_, d_)
     for kv in [x for x in v.split(",") if x]:

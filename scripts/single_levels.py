@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt
 
-DEFAULTS = dict(generic=0, cpt=0, tile_pairs=0, waves=4, xcd_swizzle=1, wave_horiz=-1, ring=0, nt=7)
+DEFAULTS = dict(generic=0, cpt=0, tile_pairs=0, waves=4, xcd_swizzle=1, ring=0, nt=7)
 n = int(os.environ.get("SIZE", 8192)); J = int(os.environ.get("LEVELS", 5)); nb = 8; reps = int(os.environ.get("REPS", 40))
 dwt.dwt_util_init(); dwt.use_torch_stream()
 src = torch.rand((nb, n, n), device="cuda"); dst = torch.empty_like(src)

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 import libdwt_amd as dwt
 
-DEFAULTS = dict(generic=0, cpt=0, tile_pairs=0, waves=4, xcd_swizzle=1, wave_horiz=-1, ring=0, nt=7, nt_inv=1, pipeline=0, ring_inv=8, wave_horiz_inv=0, fma=0)
+DEFAULTS = dict(generic=0, cpt=0, tile_pairs=0, waves=4, xcd_swizzle=1, ring=0, nt=7, ring_inv=8, fma=0)
 
 def main():
     n = int(os.environ.get("SIZE", 8192)); J = int(os.environ.get("LEVELS", 5)); nb = int(os.environ.get("IMAGES", 4))

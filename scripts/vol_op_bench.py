@@ -11,7 +11,7 @@ lv = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dwt.dwt_util_init(); dwt.use_torch_stream()
 a = torch.rand((n, n, n), device="cuda"); b = torch.empty_like(a)
 variants = os.environ.get("VARIANTS", "vol_fused=1;vol_fused=0;vol_fused=1,vol_nt=0;vol_fused=1,vol_nt=2;vol_fused=1,vol_tile_pairs=64;vol_fused=1,vol_tile_pairs=256;vol_fused=1").split(";")
-D = dict(vol_fused=1, vol_nt=-1, vol_tile_pairs=0, vol_swizzle=1, vol_rows=8, vol_direct=2, vol_whole=1, vol_fwd_tall=1, vol_ip_waves=0)
+D = dict(vol_fused=1, vol_nt=-1, vol_tile_pairs=0, vol_swizzle=1, vol_rows=8, vol_direct=2, vol_whole=1, vol_ip_waves=0)
 for opts in variants:
     for k, v in D.items(): dwt.set_option(k, v)
     for kv in [x for x in opts.split(",") if x]:

@@ -25,7 +25,7 @@ def dwt():
     d.dwt_util_init()
     yield d
     for k, v in (("generic", 0), ("cpt", 0), ("tile_pairs", 0), ("waves", 4), ("xcd_swizzle", 1), ("ring", 0),
-                 ("wave_horiz", -1), ("nt", 7), ("nt_inv", 1), ("pipeline", 0), ("fused_d", 1)):
+                 ("nt", 7), ("ring_inv", 8), ("fused_d", 1)):
         d.set_option(k, v)
     d.dwt_util_finish()
 
@@ -209,7 +209,8 @@ def test_tile_variants_agree(dwt, oracle, wname):
 
 
 def test_ring_layout_and_cache_policy_variants_agree(dwt, oracle):
-    """ring depth, wave layout and nt policy change scheduling only, never the bits."""
+    """ring depth (with it the layout of a workgroup's waves), cache policy and the wavefront-shift variant of
+    the neighbour taps change scheduling only, never the bits."""
     h, w = 700, 2100
     rng = np.random.default_rng(23)
     img = rand_img(rng, h, w, np.float32)
@@ -219,51 +220,23 @@ def test_ring_layout_and_cache_policy_variants_agree(dwt, oracle):
     oracle.inv("cdf97_2i_s", rec_want, jw)
     try:
         for ring in (8, 16):
-            for horiz in (0, 1):
-                for nt in (0, 3, 7, 8, 15):
-                    for cpt in (4, 8):
-                        for k, v in (("ring", ring), ("wave_horiz", horiz), ("nt", nt), ("nt_inv", nt & 3), ("cpt", cpt), ("tile_pairs", 16)):
-                            dwt.set_option(k, v)
-                        a = dwt.DeviceImage(h, w).upload(img)
-                        b = dwt.DeviceImage(h, w).upload(np.zeros_like(img))
-                        j = dwt.dwt_cdf97_2f_s2(a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, 3)
-                        assert j == jw and np.array_equal(bits(b.download(np.float32)), bits(want)), (ring, horiz, nt, cpt)
-                        dwt.dwt_cdf97_2i_s2(b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, j)
-                        assert np.array_equal(bits(a.download(np.float32)), bits(rec_want)), (ring, horiz, nt, cpt)
-                        a.free()
-                        b.free()
+            for nt in (3, 7, 15):
+                for cpt in (4, 8):
+                    for k, v in (("ring", ring), ("ring_inv", ring), ("nt", nt), ("cpt", cpt), ("tile_pairs", 16)):
+                        dwt.set_option(k, v)
+                    a = dwt.DeviceImage(h, w).upload(img)
+                    b = dwt.DeviceImage(h, w).upload(np.zeros_like(img))
+                    j = dwt.dwt_cdf97_2f_s2(a.ptr, b.ptr, a.stride_x, 4, w, h, w, h, 3)
+                    assert j == jw and np.array_equal(bits(b.download(np.float32)), bits(want)), (ring, nt, cpt)
+                    dwt.dwt_cdf97_2i_s2(b.ptr, a.ptr, a.stride_x, 4, w, h, w, h, j)
+                    assert np.array_equal(bits(a.download(np.float32)), bits(rec_want)), (ring, nt, cpt)
+                    a.free()
+                    b.free()
     finally:
-        for k, v in (("ring", 0), ("wave_horiz", -1), ("nt", 7), ("nt_inv", 1), ("cpt", 0), ("tile_pairs", 0)):
+        for k, v in (("ring", 0), ("ring_inv", 8), ("nt", 7), ("cpt", 0), ("tile_pairs", 0)):
             dwt.set_option(k, v)
 
 
-def test_pipelined_batch_matches_batched_launch(dwt, oracle):
-    n, nb = 512, 5
-    rng = np.random.default_rng(31)
-    imgs = rng.random((nb, n, n), dtype=np.float32)
-    src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
-    dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
-    assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
-    outs = []
-    try:
-        for lanes in (0, 2, 3):
-            dwt.set_option("pipeline", lanes)
-            dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, 4)
-            dwt.sync()
-            out = np.empty_like(imgs)
-            assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
-            outs.append(out)
-    finally:
-        dwt.set_option("pipeline", 0)
-    want = imgs[2].copy()
-    oracle.fwd("cdf97_2f_s", want, 4)
-    assert np.array_equal(bits(outs[0][2]), bits(want))
-    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
-    dwt.lib.dwt_hip_free(src)
-    dwt.lib.dwt_hip_free(dst)
-
-
-# ---- BASELINE.json configs ------------------------------------------------------------
 def test_config1_simple_example_flow(dwt, oracle):
     """configs[0]: 512x512 float, libdwt pattern, prime pitch 2053 B, as examples/simple."""
     x = y = 512

@@ -44,7 +44,7 @@ def test_exports_every_declared_symbol(dwt, header):
             assert n in names
     if header == "volume.h":
         for n in ("volume_alloc_realiably", "volume_alloc_realiably_locked", "volume_free", "volume_fill_s", "volume_copy_s",
-                  "volume_compare_s", "volume_save_to_pgm_s", "volume_invalidate_cache"):
+                  "volume_compare_s", "volume_save_to_pgm_s", "volume_save_log_to_pgm_s", "volume_invalidate_cache"):
             assert n in names
     missing = [n for n in names if not hasattr(dwt.lib, n)]
     assert not missing, missing
@@ -330,5 +330,15 @@ def test_volume_housekeeping_on_host(dwt, tmp_path):
     assert L.volume_compare_s(v, w) != 0
     L.volume_save_to_pgm_s(v, str(tmp_path / "s%02d.pgm").encode())
     assert sorted(os.listdir(tmp_path)) == ["s%02d.pgm" % z for z in range(13)]
+    # volume_save_log_to_pgm_s (src/volume.h:70): byte-identical to the reference's files where it is built
+    L.volume_save_log_to_pgm_s(v, str(tmp_path / "l%02d.pgm").encode())
+    assert len([f for f in os.listdir(tmp_path) if f.startswith("l")]) == 13
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libdwt_ref.so")
+    if os.path.exists(ref_so):
+        R = C.CDLL(ref_so)
+        R.volume_save_log_to_pgm_s.argtypes = [C.c_void_p, C.c_char_p]
+        R.volume_save_log_to_pgm_s(C.cast(v, C.c_void_p), str(tmp_path / "r%02d.pgm").encode())
+        for z in range(13):
+            assert open(tmp_path / ("l%02d.pgm" % z), "rb").read() == open(tmp_path / ("r%02d.pgm" % z), "rb").read(), z
     L.volume_free(v)
     L.volume_free(w)

@@ -751,6 +751,26 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
         torch.rand((nb, n, n), generator=gen, out=bufs[0])
         placement = {"by": "dwt_hip_alloc_batch", "attempts": [{"spacer_GiB": 0, "ms_per_step": round(first_ms, 4)}]}
         placement.update(dwt.alloc_batch_report())
+    elif w == "config5" and args.placements > 1:
+        dwt.set_option("place_tries", 1)
+        plain = make()
+        run(plain)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run(plain)
+        torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) / 3 * 1e3
+        plain = None
+        dwt.dwt_util_finish()
+        torch.cuda.empty_cache()
+        dwt.set_option("place_tries", args.placements)
+        p_src, p_dst = dwt.alloc_volumes(n, n, n, J)
+        bufs = (raw_tensor(torch, dev, p_src, (n, n, n)), raw_tensor(torch, dev, p_dst, (n, n, n)))
+        gen.manual_seed(1234 + rank)
+        torch.rand((n, n, n), generator=gen, out=bufs[0])
+        placement = {"by": "dwt_hip_alloc_volumes", "attempts": [{"spacer_GiB": 0, "ms_per_step": round(first_ms, 4)}]}
+        placement.update(dwt.alloc_batch_report())
     else:
         bufs, _spacer, placement = choose_placement(torch, dev, min(args.placements, 3), make, run)
 

@@ -88,6 +88,8 @@ void dwt_hip_sync(void);
  *     arrangement is kept and the rest of the arena returned.  Seconds, once, for a batch that stays
  *     resident; dwt_hip_alloc_batch_report says what was measured.  Free both with dwt_hip_free. */
 int dwt_hip_alloc_batch(int wavelet, int n_images, int size_x, int size_y, int levels, void **src, void **dst);
+/* the same for the two dense volumes of an out-of-place 3-D call (dwt_hip_transform3d_op) of `levels` levels */
+int dwt_hip_alloc_volumes(int size_x, int size_y, int size_z, int levels, void **src, void **dst);
 int dwt_hip_placement_report(double *ms, int n);
 void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int *dst_at, int *ll_at, double *ms4, double *seconds);
 

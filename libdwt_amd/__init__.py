@@ -73,6 +73,8 @@ lib.dwt_hip_alloc_batch.argtypes = [_I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER
 lib.dwt_hip_alloc_batch.restype = _I
 lib.dwt_hip_placement_report.argtypes = [C.POINTER(C.c_double), _I]
 lib.dwt_hip_placement_report.restype = _I
+lib.dwt_hip_alloc_volumes.argtypes = [_I, _I, _I, _I, C.POINTER(_P), C.POINTER(_P)]
+lib.dwt_hip_alloc_volumes.restype = _I
 lib.dwt_hip_alloc_batch_report.argtypes = [C.POINTER(_I)] * 5 + [C.POINTER(C.c_double)] * 2
 lib.dwt_hip_probe_pair_us.argtypes = [_P, _P, C.c_size_t]
 lib.dwt_hip_probe_pair_us.restype = C.c_double
@@ -598,4 +600,11 @@ def alloc_batch(wavelet, n_images, size_x, size_y, levels=-1):
     """dwt_hip_alloc_batch: (src, dst) device pointers of a resident batch, placed; free with lib.dwt_hip_free."""
     s_, d_ = _P(), _P()
     _check(lib.dwt_hip_alloc_batch(WAVELET_ID.get(wavelet, wavelet), n_images, size_x, size_y, levels, C.byref(s_), C.byref(d_)), "dwt_hip_alloc_batch")
+    return s_.value, d_.value
+
+
+def alloc_volumes(size_x, size_y, size_z, levels):
+    """dwt_hip_alloc_volumes: (src, dst) dense device volumes of an out-of-place 3-D call, placed; free with lib.dwt_hip_free."""
+    s_, d_ = _P(), _P()
+    _check(lib.dwt_hip_alloc_volumes(size_x, size_y, size_z, levels, C.byref(s_), C.byref(d_)), "dwt_hip_alloc_volumes")
     return s_.value, d_.value

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -322,21 +323,36 @@ static int alloc_batch_plain(size_t total, void **src, void **dst)
 	return 0;
 }
 
-static int alloc_batch_arena(Wavelet w, int n_images, int size_x, int size_y, int levels, void **src_out, void **dst_out)
+// The search itself, for any workload with one source, one destination and a workspace of `n_ws` parts that
+// lie one behind the other: sizes in bytes; `quick(src, dst, &ms)` times the source / destination relation
+// alone (may be empty: then every destination position gets the full measurement's first workspace
+// position), `full(src, dst, ws_parts, &ms)` the workload itself.  On success out[0] = source, out[1] =
+// destination, out[2 ..] = the workspace parts, each a buffer of its own for dwt_hip_free.
+// Returns 0, > 0 on error, -1 when the card has no room for a choice (the caller allocates plainly).
+struct ArenaJob {
+	size_t src_bytes, dst_bytes;
+	std::vector<size_t> ws_bytes;
+	std::function<int(char *, char *, double *)> quick;
+	std::function<int(char *, char *, char *const *, double *)> full;
+};
+
+static int arena_place(const ArenaJob &job, void **out)
 {
-	const int es = elem_size(w);
 	const size_t C = (size_t)1 << 30;
-	const size_t pitch = (size_t)size_x * es, img = pitch * size_y, total = img * n_images;
-	const Geom ge{size_x, size_y, size_x, size_y};
-	const size_t need_ll[2] = {ll_band_bytes(ge, 0, n_images, es), ll_band_bytes(ge, 1, n_images, es)};
-	const size_t nS = (total + C - 1) / C, nL0 = (need_ll[0] + C - 1) / C, nL1 = (need_ll[1] + C - 1) / C, nL = nL0 + nL1;
+	const size_t nS = (job.src_bytes + C - 1) / C, nD = (job.dst_bytes + C - 1) / C;
+	std::vector<size_t> nW;
+	size_t nL = 0;
+	for (size_t b : job.ws_bytes) {
+		nW.push_back((b + C - 1) / C);
+		nL += nW.back();
+	}
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	const size_t reserve = (size_t)8 << 30;
 	size_t n_chunks = free_b > reserve ? (free_b - reserve) / C : 0;
-	n_chunks = std::min<size_t>(n_chunks, std::max<size_t>(192, 4 * (2 * nS + nL)));
-	if (n_chunks < 2 * (2 * nS + nL))
-		return -1; // not enough room for a choice: the caller allocates plainly
+	n_chunks = std::min<size_t>(n_chunks, std::max<size_t>(192, 4 * (nS + nD + nL)));
+	if (n_chunks < 2 * (nS + nD + nL))
+		return -1;
 	const auto t_start = std::chrono::steady_clock::now();
 	hipMemAllocationProp prop = {};
 	prop.type = hipMemAllocationTypePinned;
@@ -360,7 +376,7 @@ static int alloc_batch_arena(Wavelet w, int n_images, int size_x, int size_y, in
 		chunk.clear();
 	};
 	n_chunks = chunk.size();
-	if (n_chunks < 2 * (2 * nS + nL)) {
+	if (n_chunks < 2 * (nS + nD + nL)) {
 		release_chunks();
 		return -1;
 	}
@@ -387,58 +403,64 @@ static int alloc_batch_arena(Wavelet w, int n_images, int size_x, int size_y, in
 		drop_arena();
 		return fail("mapping the placement arena failed: %s", hipGetErrorString(hipGetLastError()));
 	}
-	// the context's own scratch makes room for the arena's candidates during the search
-	hipStreamSynchronize(g.stream);
-	for (int b = 0; b < 2; b++) {
-		if (g.ll[b])
-			dev_free(g.ll[b]);
-		g.ll[b] = nullptr;
-		g.ll_bytes[b] = 0;
-	}
-	const Img s{arena, (long)pitch, es};
-	auto dst_img = [&](size_t D) { return Img{arena + D * C, (long)pitch, es}; };
 	int rc = 0;
 	const size_t step = 4;
-	// 1. destinations against the source: one level, no scratch
+	auto ws_at = [&](size_t P, std::vector<char *> &parts) {
+		parts.clear();
+		for (size_t n : nW) {
+			parts.push_back(arena + P * C);
+			P += n;
+		}
+	};
+	// first workspace position that overlaps neither the source nor a destination at D
+	auto first_ws = [&](size_t D) {
+		for (size_t P = 0; P + nL <= n_chunks; P += step)
+			if (P >= nS && !(P < D + nD && D < P + nL))
+				return P;
+		return n_chunks;
+	};
+	std::vector<char *> parts;
+	// 1. destinations against the source
 	std::vector<std::pair<double, size_t>> dsts;
-	// (a one-level call never touches the scratch; the context is pointed at the source region so that it
-	// does not allocate one of its own meanwhile)
-	g.ll[0] = g.ll[1] = arena;
-	g.ll_bytes[0] = g.ll_bytes[1] = nS * C;
-	g.ll_external = true;
-	for (size_t D = nS; D + nS <= n_chunks && !rc; D += step) {
+	for (size_t D = nS; D + nD <= n_chunks && !rc; D += step) {
 		double ms = 0;
-		rc = timed_forward(w, s, dst_img(D), ge, 1, n_images, (long)img, (long)img, &ms);
+		if (job.quick) {
+			rc = job.quick(arena, arena + D * C, &ms);
+		} else {
+			const size_t P = first_ws(D);
+			if (P >= n_chunks)
+				continue;
+			ws_at(P, parts);
+			rc = job.full(arena, arena + D * C, parts.data(), &ms);
+		}
 		dsts.push_back({ms, D});
 	}
-	g.ll_external = false;
-	g.ll[0] = g.ll[1] = nullptr;
-	g.ll_bytes[0] = g.ll_bytes[1] = 0;
-	double best_ms = 1e30, worst_ll = 0;
-	size_t best_D = nS, best_P = 2 * nS;
-	int ll_tried = 0;
-	if (!rc) {
+	double best_ms = 1e30, worst_ws = 0;
+	size_t best_D = nS, best_P = nS + nD;
+	int ws_tried = 0;
+	if (!rc && !dsts.empty() && nW.empty()) {
+		// no workspace: the destination search is the whole search
+		for (auto &d : dsts)
+			if (d.first < best_ms) {
+				best_ms = d.first;
+				best_D = d.second;
+			}
+		best_P = 0;
+	} else if (!rc && !dsts.empty()) {
 		std::vector<std::pair<double, size_t>> order = dsts;
 		std::sort(order.begin(), order.end());
 		const size_t top = std::min<size_t>(order.size(), 3);
 		for (size_t t = 0; t < top && !rc; t++) {
 			const size_t D = order[t].second;
-			// 2. both LL bands, contiguous, wherever they overlap neither the source nor this destination
+			// 2. the workspace wherever it overlaps neither the source nor this destination
 			for (size_t P = 0; P + nL <= n_chunks && !rc; P += step) {
-				if (P < nS || (P < D + nS && D < P + nL))
+				if (P < nS || (P < D + nD && D < P + nL))
 					continue;
-				g.ll[0] = arena + P * C;
-				g.ll[1] = arena + (P + nL0) * C;
-				g.ll_bytes[0] = nL0 * C;
-				g.ll_bytes[1] = nL1 * C;
-				g.ll_external = true; // not to be grown or freed while it points into the arena
+				ws_at(P, parts);
 				double ms = 0;
-				rc = timed_forward(w, s, dst_img(D), ge, levels, n_images, (long)img, (long)img, &ms);
-				g.ll_external = false;
-				g.ll[0] = g.ll[1] = nullptr;
-				g.ll_bytes[0] = g.ll_bytes[1] = 0;
-				ll_tried++;
-				worst_ll = std::max(worst_ll, ms);
+				rc = job.full(arena, arena + D * C, parts.data(), &ms);
+				ws_tried++;
+				worst_ws = std::max(worst_ws, ms);
 				if (ms < best_ms) {
 					best_ms = ms;
 					best_D = D;
@@ -455,54 +477,189 @@ static int alloc_batch_arena(Wavelet w, int n_images, int size_x, int size_y, in
 	// 3. the chosen chunks stay where they are mapped -- the buffers ARE the arrangement that was measured,
 	//    physical chunks and virtual addresses alike (mapping the same chunks again at other addresses gave
 	//    other rates: 8.5-8.8 ms for arrangements that had measured 7.5-7.7) -- and every other chunk is
-	//    unmapped and returned; the address reservation goes when the last of the four buffers is freed
+	//    unmapped and returned; the address reservation goes when the last of the buffers is freed
 	struct Part {
 		size_t first, count;
-		void *va;
-	} parts[4] = {{0, nS, nullptr}, {best_D, nS, nullptr}, {best_P, nL0, nullptr}, {best_P + nL0, nL1, nullptr}};
+	};
+	std::vector<Part> keep = {{0, nS}, {best_D, nD}};
+	{
+		size_t P = best_P;
+		for (size_t n : nW) {
+			keep.push_back({P, n});
+			P += n;
+		}
+	}
 	std::vector<char> used(n_chunks, 0);
-	VmmArena *ar = new VmmArena{arena, n_chunks * C, 4};
-	for (auto &p : parts) {
+	VmmArena *ar = new VmmArena{arena, n_chunks * C, (int)keep.size()};
+	for (size_t k = 0; k < keep.size(); k++) {
 		VmmBuf b;
 		b.piece = C;
-		b.bytes = p.count * C;
+		b.bytes = keep[k].count * C;
 		b.arena = ar;
-		for (size_t i = 0; i < p.count; i++) {
-			b.handles.push_back(chunk[p.first + i]);
-			used[p.first + i] = 1;
+		for (size_t i = 0; i < keep[k].count; i++) {
+			b.handles.push_back(chunk[keep[k].first + i]);
+			used[keep[k].first + i] = 1;
 		}
-		p.va = arena + p.first * C;
+		out[k] = arena + keep[k].first * C;
 		std::lock_guard<std::mutex> lk(g_vmm_mu);
-		g_vmm[p.va] = std::move(b);
+		g_vmm[out[k]] = std::move(b);
 	}
 	for (size_t i = 0; i < n_chunks; i++)
 		if (!used[i]) {
 			hipMemUnmap(arena + i * C, C);
 			hipMemRelease(chunk[i]);
 		}
-	g.ll[0] = parts[2].va;
-	g.ll[1] = parts[3].va;
-	g.ll_bytes[0] = nL0 * C;
-	g.ll_bytes[1] = nL1 * C;
-	*src_out = parts[0].va;
-	*dst_out = parts[1].va;
 	// the arrangement as the caller will use it, timed once more
 	double final_ms = 0;
-	timed_forward(w, Img{(char *)parts[0].va, (long)pitch, es}, Img{(char *)parts[1].va, (long)pitch, es}, ge, levels, n_images, (long)img, (long)img, &final_ms);
-	g_arena.final_ms = final_ms;
+	ws_at(best_P, parts);
+	job.full(arena, arena + best_D * C, parts.data(), &final_ms);
 	std::sort(dsts.begin(), dsts.end());
-	const double fin = g_arena.final_ms;
+	g_arena = ArenaStats();
 	g_arena.chunks = (int)n_chunks;
-	g_arena.final_ms = fin;
+	g_arena.final_ms = final_ms;
 	g_arena.dst_tried = (int)dsts.size();
-	g_arena.ll_tried = ll_tried;
+	g_arena.ll_tried = ws_tried;
 	g_arena.dst_at = (int)best_D;
 	g_arena.ll_at = (int)best_P;
 	g_arena.dst_best_ms = dsts.front().first;
 	g_arena.dst_worst_ms = dsts.back().first;
 	g_arena.ll_best_ms = best_ms;
-	g_arena.ll_worst_ms = worst_ll;
+	g_arena.ll_worst_ms = worst_ws;
 	g_arena.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	return 0;
+}
+
+// the context's workspace pointed into the arena for one trial (never grown or freed meanwhile)
+struct TrialLL {
+	TrialLL(char *b0, size_t n0, char *b1, size_t n1)
+	{
+		g.ll[0] = b0;
+		g.ll[1] = b1;
+		g.ll_bytes[0] = n0;
+		g.ll_bytes[1] = n1;
+		g.ll_external = true;
+	}
+	~TrialLL()
+	{
+		g.ll_external = false;
+		g.ll[0] = g.ll[1] = nullptr;
+		g.ll_bytes[0] = g.ll_bytes[1] = 0;
+	}
+};
+
+static int alloc_batch_arena(Wavelet w, int n_images, int size_x, int size_y, int levels, void **src_out, void **dst_out)
+{
+	const int es = elem_size(w);
+	const size_t pitch = (size_t)size_x * es, img = pitch * size_y, total = img * n_images;
+	const Geom ge{size_x, size_y, size_x, size_y};
+	ArenaJob job;
+	job.src_bytes = job.dst_bytes = total;
+	job.ws_bytes = {ll_band_bytes(ge, 0, n_images, es), ll_band_bytes(ge, 1, n_images, es)};
+	const size_t C = (size_t)1 << 30;
+	const size_t cap0 = (job.ws_bytes[0] + C - 1) / C * C, cap1 = (job.ws_bytes[1] + C - 1) / C * C;
+	// the context's own scratch makes room for the arena's candidates
+	hipStreamSynchronize(g.stream);
+	for (int b = 0; b < 2; b++) {
+		if (g.ll[b])
+			dev_free(g.ll[b]);
+		g.ll[b] = nullptr;
+		g.ll_bytes[b] = 0;
+	}
+	job.quick = [&](char *s, char *d, double *ms) {
+		// (a one-level call never touches the scratch; the context is pointed at the source region so that
+		// it does not allocate one of its own meanwhile)
+		TrialLL t(s, total, s, total);
+		return timed_forward(w, Img{s, (long)pitch, es}, Img{d, (long)pitch, es}, ge, 1, n_images, (long)img, (long)img, ms);
+	};
+	job.full = [&](char *s, char *d, char *const *ws, double *ms) {
+		TrialLL t(ws[0], cap0, ws[1], cap1);
+		return timed_forward(w, Img{s, (long)pitch, es}, Img{d, (long)pitch, es}, ge, levels, n_images, (long)img, (long)img, ms);
+	};
+	void *out[4] = {nullptr, nullptr, nullptr, nullptr};
+	const int rc = arena_place(job, out);
+	if (rc)
+		return rc;
+	g.ll[0] = out[2];
+	g.ll[1] = out[3];
+	g.ll_bytes[0] = cap0;
+	g.ll_bytes[1] = cap1;
+	*src_out = out[0];
+	*dst_out = out[1];
+	return 0;
+}
+
+// workspace bytes (each of the two pools) of an out-of-place 3-D call: the dense level inputs / outputs of levels >= 1
+static size_t vol_pool_bytes(int nx, int ny, int nz, int levels)
+{
+	size_t pool = 0;
+	for (int j = 1; j < levels; j++) {
+		const size_t lx = ceil_div_pow2(nx, j), ly = ceil_div_pow2(ny, j), lz = ceil_div_pow2(nz, j);
+		pool += (size_t)align_up((long)lx, 4) * ly * lz;
+	}
+	return pool * 4;
+}
+
+static int timed_volume_op(const char *s, char *d, size_t sy, size_t sz, int nx, int ny, int nz, int levels, double *ms)
+{
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	int rc = 0;
+	for (int r = 0; r < 2 && !rc; r++) {
+		hipEventRecord(e0, g.stream);
+		rc = dwt_hip_transform3d_op(s, d, sy, sz, nx, ny, nz, levels);
+		hipEventRecord(e1, g.stream);
+	}
+	float t = 0;
+	if (!rc && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess))
+		rc = fail("timing a placement trial failed: %s", hipGetErrorString(hipGetLastError()));
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	*ms = t;
+	return rc;
+}
+
+static int alloc_volumes_arena(int nx, int ny, int nz, int levels, void **src_out, void **dst_out)
+{
+	const size_t sy = (size_t)nx * 4, sz = sy * ny, total = sz * nz;
+	const size_t pool = vol_pool_bytes(nx, ny, nz, levels);
+	const size_t C = (size_t)1 << 30;
+	const size_t cap = (pool + C - 1) / C * C;
+	ArenaJob job;
+	job.src_bytes = job.dst_bytes = total;
+	if (pool)
+		job.ws_bytes = {pool, pool};
+	hipStreamSynchronize(g.stream);
+	void **own[2] = {&g.host_a, &g.host_b};
+	size_t *own_bytes[2] = {&g.host_a_bytes, &g.host_b_bytes};
+	for (int b = 0; b < 2; b++) {
+		if (*own[b])
+			dev_free(*own[b]);
+		*own[b] = nullptr;
+		*own_bytes[b] = 0;
+	}
+	auto point = [&](char *a, char *b, size_t n) {
+		g.host_a = a;
+		g.host_b = b;
+		g.host_a_bytes = g.host_b_bytes = n;
+	};
+	if (pool) // (a one-level call has no workspace: the quick measurement of the destinations)
+		job.quick = [&](char *s, char *d, double *ms) { return timed_volume_op(s, d, sy, sz, nx, ny, nz, 1, ms); };
+	job.full = [&](char *s, char *d, char *const *ws, double *ms) {
+		if (pool)
+			point(ws[0], ws[1], cap);
+		const int rc = timed_volume_op(s, d, sy, sz, nx, ny, nz, levels, ms);
+		point(nullptr, nullptr, 0);
+		return rc;
+	};
+	void *out[4] = {nullptr, nullptr, nullptr, nullptr};
+	const int rc = arena_place(job, out);
+	if (rc)
+		return rc;
+	if (pool)
+		point((char *)out[2], (char *)out[3], cap);
+	*src_out = out[0];
+	*dst_out = out[1];
 	return 0;
 }
 
@@ -572,6 +729,25 @@ int dwt_hip_alloc_batch(int wavelet, int n_images, int size_x, int size_y, int l
 		!g.force_generic && es == 4 && !stream_is_capturing();
 	if (search) {
 		const int rc = alloc_batch_arena(w, n_images, size_x, size_y, levels, src_out, dst_out);
+		if (rc >= 0)
+			return rc;
+	}
+	return alloc_batch_plain(total, src_out, dst_out);
+}
+
+// The same for the volumes of an out-of-place 3-D call (dwt_hip_transform3d_op / cdf97_3f_op_sep_horizontal_s on
+// device volumes): dense strides (rows nx floats, slices nx * ny floats), the workspace of the deeper levels
+// placed with them and kept by the calling thread's context.
+int dwt_hip_alloc_volumes(int size_x, int size_y, int size_z, int levels, void **src_out, void **dst_out)
+{
+	if (check_inited())
+		return 1;
+	if (size_x < 1 || size_y < 1 || size_z < 1 || levels < 1 || levels > 24 || !src_out || !dst_out)
+		return fail("dwt_hip_alloc_volumes: bad argument");
+	const size_t total = (size_t)size_x * size_y * size_z * 4;
+	g_arena = ArenaStats();
+	if (g.place_tries >= 2 && total >= ((size_t)g.place_min_mib << 20) && !g.force_generic && !stream_is_capturing()) {
+		const int rc = alloc_volumes_arena(size_x, size_y, size_z, levels, src_out, dst_out);
 		if (rc >= 0)
 			return rc;
 	}

@@ -272,6 +272,31 @@ def test_one_pass_in_place_levels(dwt, oracle, shape, levels, tile_pairs):
     d.free()
 
 
+def test_placed_volumes(dwt, oracle):
+    """dwt_hip_alloc_volumes: source / destination / workspace of an out-of-place 3-D call chosen by measurement
+    (an arena of the card's free memory); the transform on them gives the oracle's bits; dwt_hip_free takes
+    them back."""
+    shape, levels = (24, 40, 256), 2
+    vol = np.random.default_rng(3).random(shape, dtype=np.float32)
+    want = oracle_multilevel(oracle, vol.copy(), levels, False)
+    L = dwt.lib
+    dwt.set_option("place_min_mib", 0)
+    try:
+        src, dst = dwt.alloc_volumes(shape[2], shape[1], shape[0], levels)
+        rep = dwt.alloc_batch_report()
+        assert rep["arena_GiB"] >= 8 and rep["dst_positions_tried"] >= 1, rep
+        assert L.dwt_hip_memcpy_h2d(src, vol.ctypes.data, vol.nbytes) == 0
+        dwt.transform3d_op(src, dst, shape[2] * 4, shape[2] * shape[1] * 4, shape[2], shape[1], shape[0], levels)
+        got = np.empty_like(vol)
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        L.dwt_hip_free(src)
+        L.dwt_hip_free(dst)
+    finally:
+        dwt.set_option("place_min_mib", 1024)
+        dwt.dwt_util_finish()
+
+
 def test_one_pass_in_place_tall_thin_volume(dwt, oracle):
     """A volume with more than 8192 / 7 tile rows of 32 (the shell row index of k_vol_level_ip fills the top
     14 bits of a packed word and is decoded unsigned): 6 x 38000 x 130, tiles of 32 rows (vol_ip_waves = 4),

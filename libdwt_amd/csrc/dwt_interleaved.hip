@@ -490,6 +490,7 @@ __global__ __launch_bounds__(256) void k_compare(const char *__restrict__ p1, co
 // (__amd_rocclr_copyBufferRectAligned) moves such rectangles at ~3.3 TB/s; this streams 16 B per
 // lane, non-temporal both ways (the bytes are not read again by a kernel), 4 KiB x 8 rows per
 // workgroup, any 4-byte alignment.
+template <bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void k_copy_rects(CopyRects r)
 {
 	int b = blockIdx.x, k = 0;
@@ -511,11 +512,11 @@ __global__ __launch_bounds__(256) void k_copy_rects(CopyRects r)
 	u4 v[kRows];
 #pragma unroll
 	for (int i = 0; i < kRows; i++)
-		v[i] = load16_row<true>(row_rsrc(s + (long)min(i, rows - 1) * r.spitch[k], (unsigned)r.wbytes[k]), x);
+		v[i] = load16_row<NTL>(row_rsrc(s + (long)min(i, rows - 1) * r.spitch[k], (unsigned)r.wbytes[k]), x);
 #pragma unroll
 	for (int i = 0; i < kRows; i++)
 		if (i < rows)
-			store16_row<true>(row_rsrc(d + (long)i * r.dpitch[k], (unsigned)r.wbytes[k]), x, v[i]);
+			store16_row<NTS>(row_rsrc(d + (long)i * r.dpitch[k], (unsigned)r.wbytes[k]), x, v[i]);
 }
 
 hipError_t launch_copy_rects(CopyRects r, hipStream_t s)
@@ -540,7 +541,10 @@ hipError_t launch_copy_rects(CopyRects r, hipStream_t s)
 		total += ((r.wbytes[k] + seg - 1) / seg) * ((r.h[k] + 7) / 8);
 	}
 	r.first_block[n] = total;
-	k_copy_rects<<<total, 256, 0, s>>>(r);
+	if ((r.policy & 3) == 0)
+		k_copy_rects<false, false><<<total, 256, 0, s>>>(r);
+	else
+		k_copy_rects<true, true><<<total, 256, 0, s>>>(r);
 	return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@ struct FwdLevelArgs {
 	int W, H, batch;
 	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path / in-place lifting layout)
 	int il_ll = 0;       // interleaved only: also write the LL samples densely to out_ll
+	int temporal = 0;    // 1: every store temporal (the outputs are read again at once: staging of an in-place call)
 };
 
 // One reconstruction level, inverse, dense frame.  Reads LL from `in_ll` and the
@@ -208,6 +209,7 @@ struct CopyRects {
 	int wbytes[3], h[3];
 	int first_block[4];
 	int n;
+	int policy = 3; // 3: non-temporal loads and stores (data moved once); 0: temporal both ways (the copy is read again at once)
 };
 hipError_t launch_copy_rects(CopyRects r, hipStream_t s);
 

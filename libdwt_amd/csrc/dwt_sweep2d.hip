@@ -787,19 +787,22 @@ static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 gri
 template <class W, int CPT>
 static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, const SweepTuning &t, hipStream_t s)
 {
-	// cache policy 7 (non-temporal loads and detail stores, the LL band's stores temporal), 3 (the LL band
+	// cache policy 6 (non-temporal loads, every store temporal: the staged outputs of an in-place call, read back
+	// at once), 7 (non-temporal loads and detail stores, the LL band's stores temporal), 3 (the LL band
 	// non-temporal too: launches whose LL bands exceed the Infinity Cache), 15 (= 7 with the neighbour taps
 	// by wavefront shifts instead of LDS reads: bit-identical, 0.8 % slower, the cross-check variant).  The
 	// other policies and ring depths of rounds 1-3 measured slower and are gone (profiles/r02_experiments.md).
-	const int nt = (t.nt & 8) ? 15 : (t.nt & 4) ? 7 : 3;
+	const int nt = a.temporal ? 6 : (t.nt & 8) ? 15 : (t.nt & 4) ? 7 : 3;
 	if (t.ring == 16) {
 		switch (nt) {
+		case 6: return fwd_launch<W, CPT, 16, 6>(a, g, grid, waves, s);
 		case 3: return fwd_launch<W, CPT, 16, 3>(a, g, grid, waves, s);
 		case 7: return fwd_launch<W, CPT, 16, 7>(a, g, grid, waves, s);
 		default: return fwd_launch<W, CPT, 16, 15>(a, g, grid, waves, s);
 		}
 	}
 	switch (nt) {
+	case 6: return fwd_launch<W, CPT, 8, 6>(a, g, grid, waves, s);
 	case 3: return fwd_launch<W, CPT, 8, 3>(a, g, grid, waves, s);
 	case 7: return fwd_launch<W, CPT, 8, 7>(a, g, grid, waves, s);
 	default: return fwd_launch<W, CPT, 8, 15>(a, g, grid, waves, s);

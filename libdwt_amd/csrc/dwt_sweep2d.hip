@@ -336,9 +336,16 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 				const unsigned cb = (unsigned)(c0 + lane * CPT) * 4; // byte offset in an interleaved row
 				const T *r0 = out_h + (long)(2 * k) * a.h_pitch;
 				const row_rsrc_t d0 = row_rsrc(r0, (unsigned)a.W * 4);
+				// multi-level: the compose pass reads this (even) row again soon -- temporal, so that it can stay in the
+				// Infinity Cache; the odd rows are final: non-temporal
 #pragma unroll
-				for (int e = 0; e < CPT; e += 4)
-					store16_row<kNtStore>(d0, cb + e * 4, u4{to_bits(lo[e]), to_bits(lo[e + 1]), to_bits(lo[e + 2]), to_bits(lo[e + 3])});
+				for (int e = 0; e < CPT; e += 4) {
+					const u4 v4{to_bits(lo[e]), to_bits(lo[e + 1]), to_bits(lo[e + 2]), to_bits(lo[e + 3])};
+					if (a.il_ll == 2)
+						store16_row<false>(d0, cb + e * 4, v4);
+					else
+						store16_row<kNtStore>(d0, cb + e * 4, v4);
+				}
 				if (2 * k + 1 < a.H) {
 					const row_rsrc_t d1 = row_rsrc(r0 + a.h_pitch, (unsigned)a.W * 4);
 #pragma unroll

@@ -1,0 +1,20 @@
+import os, sys, statistics
+sys.path.insert(0, os.getcwd())
+import torch
+import libdwt_amd as dwt
+n, J = 8192, 5
+dwt.dwt_util_init(); dwt.use_torch_stream()
+a = torch.rand((n, n), device="cuda"); b = torch.empty_like(a); c = a.clone()
+def t(fn, reps=60):
+    for _ in range(10): fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for x, y in evs:
+        x.record(); fn(); y.record()
+    torch.cuda.synchronize()
+    return statistics.median(x.elapsed_time(y) for x, y in evs) * 1e3
+for rnd in range(2):
+    for v in (1, 0):
+        dwt.set_option("il_temporal", v)
+        f = t(lambda: dwt.transform2d_interleaved("cdf97_s", 0, 0, a, b, n*4, 4, n, n, None, None, J))
+        fi = t(lambda: dwt.dwt_cdf97_2f_inplace_s(c, n*4, 4, n, n, n, n, J))
+        print(f"il_temporal={v}: fwd out-of-place {f:.1f} us, in place {fi:.1f} us", flush=True)

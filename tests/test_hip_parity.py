@@ -395,16 +395,38 @@ def test_double_precision_batch(dwt, oracle):
     finally:
         dwt.lib.dwt_hip_free(src)
         dwt.lib.dwt_hip_free(dst)
-    # the Python batch split (libdwt_amd/batch.py, here one rank) keeps the 8-byte element strides
-    torch = pytest.importorskip("torch")
-    from libdwt_amd import batch as B
 
-    got = B.transform_sharded(torch.from_numpy(imgs).cuda(), nb, (n, n), "cdf97_d", 4)
-    torch.cuda.synchronize()
-    for k in range(nb):
-        want = imgs[k].copy()
-        oracle.fwd("cdf97_2f_d", want, 4)
-        assert np.array_equal(bits(got[k].cpu().numpy()), bits(want)), k
+
+BATCH_D_SCRIPT = r"""
+import sys, numpy as np
+import torch                      # first: this process then shares torch's HIP runtime
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+from libdwt_amd import batch as B
+from oraclelib import Oracle
+n, nb = 384, 3
+imgs = np.random.default_rng(4).random((nb, n, n)) * 2 - 1
+got = B.transform_sharded(torch.from_numpy(imgs).cuda(), nb, (n, n), "cdf97_d", 4)
+torch.cuda.synchronize()
+orc = Oracle()
+for k in range(nb):
+    want = imgs[k].copy()
+    orc.fwd("cdf97_2f_d", want, 4)
+    assert np.array_equal(got[k].cpu().numpy().view(np.uint64), want.view(np.uint64)), k
+print("batch_d OK")
+"""
+
+
+def test_python_batch_split_keeps_double_precision_strides():
+    """libdwt_amd/batch.py (here one rank) with a double-precision wavelet: 8-byte element strides all the way
+    (round 3 passed `h*w*4`).  Own process: torch before the library, so that both use one HIP runtime."""
+    import os
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + BATCH_D_SCRIPT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "batch_d OK" in out.stdout, out.stderr[-2000:]
 
 
 def test_config4_per_gpu_shape_32x4096(dwt, oracle):

@@ -102,6 +102,8 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * (1 = policy 3 by itself when a launch's LL bands exceed 1 GiB), "fma" (1 = contracted lifting steps:
  * NOT the reference's rounding, within 1e-5), "fused_d" (0 = double precision through the exact line passes),
  * "il_lazy_strips" (1 = the interleaved 9/7 forward's exact border strips on a side stream),
+ * "il_exact_borders" (0 = no border strips at all: the top 8 rows / last 5 columns of a level keep the sweep's
+ * rows-then-columns rounding -- NOT the reference's bits there, a few ulp, far inside 1e-5; opt-in like "fma"),
  * "place_tries" / "place_min_mib" (placement search, below).
  * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two passes),
  * "vol_whole" (0 = the general kernel variant as a cross-check), "vol_direct" (levels >= 1 into their lattice

@@ -52,6 +52,7 @@ struct Ctx {
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
 	int il_temporal = 0; // set per interleaved call: the forward sweeps store their even rows temporal (the compose pass reads them again)
+	int il_exact_borders = 1; // interleaved 9/7: 0 = skip the exact border strips (opt-in: not bit-identical in the top 8 rows / last 5 columns of a level)
 	int il_lazy_strips = 1; // interleaved 9/7 forward: the exact border strips on the side stream beside the next level's sweep (0: in line)
 	long ll_offset = 0; // bytes between the start of an LL scratch allocation and the band (placement experiments)
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of

@@ -166,7 +166,9 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 		(((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
 	if (even_rows && !fused)
 		return fail("internal: split rows need the fused sweep");
-	const bool strips = fused && il_is_phased(w) && w != kCdf97SFma && !scale_single;
+	// (option il_exact_borders = 0: no strips -- the borders keep the sweep's rows-then-columns rounding, a few ulp off
+	// the reference's phase order there, far inside the 1e-5 relative tolerance; like "fma" an opt-in, never the default)
+	const bool strips = fused && il_is_phased(w) && w != kCdf97SFma && !scale_single && g.il_exact_borders;
 	const bool lazy = lazy_strips && strips && !inverse;
 	// any other path reads its whole input as it is: pending strips first
 	if (!lazy && side_join())

@@ -12,9 +12,19 @@ def t(fn, reps=60):
         x.record(); fn(); y.record()
     torch.cuda.synchronize()
     return statistics.median(x.elapsed_time(y) for x, y in evs) * 1e3
+d = torch.empty_like(a)
 for rnd in range(2):
     for v in (1, 0):
-        dwt.set_option("il_temporal", v)
+        dwt.set_option("il_exact_borders", v)
         f = t(lambda: dwt.transform2d_interleaved("cdf97_s", 0, 0, a, b, n*4, 4, n, n, None, None, J))
         fi = t(lambda: dwt.dwt_cdf97_2f_inplace_s(c, n*4, 4, n, n, n, n, J))
-        print(f"il_temporal={v}: fwd out-of-place {f:.1f} us, in place {fi:.1f} us", flush=True)
+        i = t(lambda: dwt.transform2d_interleaved("cdf97_s", 1, 0, b, d, n*4, 4, n, n, None, None, J))
+        ii = t(lambda: dwt.dwt_cdf97_2i_inplace_s(c, n*4, 4, n, n, n, n, J))
+        print(f"il_exact_borders={v}: fwd out-of-place {f:.1f} us, in place {fi:.1f} us; inv out-of-place {i:.1f} us, in place {ii:.1f} us", flush=True)
+dwt.set_option("il_exact_borders", 1)
+dwt.transform2d_interleaved("cdf97_s", 0, 0, a, b, n*4, 4, n, n, None, None, J)
+dwt.set_option("il_exact_borders", 0)
+dwt.transform2d_interleaved("cdf97_s", 0, 0, a, d, n*4, 4, n, n, None, None, J)
+torch.cuda.synchronize()
+diff = (b - d).abs()
+print("max |exact - fast| / max |coefficient|:", float(diff.max() / b.abs().max()), " differing samples:", int((diff > 0).sum()))

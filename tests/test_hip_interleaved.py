@@ -414,3 +414,34 @@ def test_lazy_border_strips_do_not_change_the_bits(dwt, oracle, shape, levels):
         oracle.fwd("cdf97_2f_inplace_s", want, levels)
         assert np.array_equal(bits(outs[0]), bits(want))
     src.free()
+
+
+@pytest.mark.parametrize("shape,levels", [((1500, 1000), 3), ((2048, 2048), 5), ((640, 2000), 2)], ids=lambda v: str(v))
+def test_fast_borders_option_within_tolerance(dwt, oracle, shape, levels):
+    """Option il_exact_borders = 0 (opt-in, like "fma"): the interleaved 9/7 without the exact border strips --
+    the top rows / last columns of every level keep the fused sweep's rows-then-columns rounding instead of the
+    reference's phase order.  NOT the reference's bits there, but within the north star's 1e-5 relative
+    tolerance everywhere, identical away from the borders, and the inverse restores the image; the default
+    stays bit-exact (every other test of this file)."""
+    h, w = shape
+    img = np.random.default_rng(h + 7 * w).random((h, w), dtype=np.float32)
+    want = img.copy()
+    jw = oracle.fwd("cdf97_2f_inplace_s", want, levels)
+    src = dwt.DeviceImage(h, w).upload(img)
+    dst = dwt.DeviceImage(h, w).upload(np.zeros_like(img))
+    dwt.set_option("il_exact_borders", 0)
+    try:
+        assert dwt.get_option("il_exact_borders") == 0
+        assert dwt.transform2d_interleaved("cdf97_s", 0, 0, src.ptr, dst.ptr, w * 4, 4, w, h, None, None, levels) == jw
+        got = dst.download(np.float32)
+        assert float(np.abs(got - want).max() / np.abs(want).max()) <= 1e-5
+        # away from the image's top / right border region (8 rows, 8 columns of the deepest level) nothing differs
+        reach = 8 << (levels - 1)
+        assert np.array_equal(bits(got[reach:, :w - reach]), bits(want[reach:, :w - reach]))
+        assert not np.array_equal(bits(got), bits(want)), "the option should have skipped the strips"
+        dwt.transform2d_interleaved("cdf97_s", 1, 0, dst.ptr, src.ptr, w * 4, 4, w, h, None, None, levels)
+        assert np.abs(src.download(np.float32) - img).max() < 1e-4
+    finally:
+        dwt.set_option("il_exact_borders", 1)
+    src.free()
+    dst.free()

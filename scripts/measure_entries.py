@@ -35,6 +35,10 @@ def main():
     m = timeit(lambda: dwt.dwt_cdf97_2f_inplace_s(c, n*4, 4, n, n, n, n, J)); rep("cdf97 interleaved fwd 8192^2 J=5, in-place", *m, n*n, alg)
     m = timeit(lambda: dwt.transform2d_interleaved("cdf97_s", 1, 0, b, c, n*4, 4, n, n, None, None, J)); rep("cdf97 interleaved inv 8192^2 J=5, out-of-place", *m, n*n, alg)
     m = timeit(lambda: dwt.dwt_cdf97_2i_inplace_s(c, n*4, 4, n, n, n, n, J)); rep("cdf97 interleaved inv 8192^2 J=5, in-place", *m, n*n, alg)
+    dwt.set_option("il_exact_borders", 0)  # opt-in: no exact border strips (within 1e-5, not the reference's bits at the borders)
+    m = timeit(lambda: dwt.transform2d_interleaved("cdf97_s", 0, 0, a, b, n*4, 4, n, n, None, None, J)); rep("  same, il_exact_borders=0: fwd out-of-place", *m, n*n, alg)
+    m = timeit(lambda: dwt.transform2d_interleaved("cdf97_s", 1, 0, b, c, n*4, 4, n, n, None, None, J)); rep("  same, il_exact_borders=0: inv out-of-place", *m, n*n, alg)
+    dwt.set_option("il_exact_borders", 1)
     nb = 8
     A = torch.rand((nb, n, n), device="cuda"); B = torch.empty_like(A)
     m = timeit(lambda: dwt.transform2d_batch("cdf97_s", 0, A, B, n*n*4, nb, n*4, n, n, J)); rep(f"cdf97 fwd 8192^2 J=5 batch of {nb}", *m, nb*n*n, nb*alg)

@@ -403,6 +403,7 @@ static int arena_place(const ArenaJob &job, void **out)
 		drop_arena();
 		return fail("mapping the placement arena failed: %s", hipGetErrorString(hipGetLastError()));
 	}
+	const double t_mapped = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	int rc = 0;
 	const size_t step = 4;
 	auto ws_at = [&](size_t P, std::vector<char *> &parts) {
@@ -435,6 +436,7 @@ static int arena_place(const ArenaJob &job, void **out)
 		}
 		dsts.push_back({ms, D});
 	}
+	const double t_dst = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	double best_ms = 1e30, worst_ws = 0;
 	size_t best_D = nS, best_P = nS + nD;
 	int ws_tried = 0;
@@ -526,6 +528,9 @@ static int arena_place(const ArenaJob &job, void **out)
 	g_arena.ll_best_ms = best_ms;
 	g_arena.ll_worst_ms = worst_ws;
 	g_arena.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	if (getenv("DWT_HIP_PLACE_VERBOSE"))
+		fprintf(stderr, "arena_place: %zu chunks mapped after %.2f s, destinations done after %.2f s, all after %.2f s\n", n_chunks, t_mapped, t_dst,
+			g_arena.seconds);
 	return 0;
 }
 

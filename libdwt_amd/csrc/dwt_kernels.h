@@ -115,6 +115,7 @@ struct VolFusedArgs {
 	// writing those rows whole (out_sy / out_sz the destination's strides times 2; `side` read)
 	int mode = 0;
 	long out_sx = 1;
+	int temporal_shared = 0; // mode 3: the rows the next level's merge pass reads again are stored temporal
 	float *side = nullptr;
 	long side_sy = 0, side_sz = 0;
 };

@@ -434,8 +434,15 @@ __global__ __launch_bounds__(256, RW == 8 ? 1 : 2) void k_vol_fwd_fused(VolFused
 					u4 s0, s1;
 					lds_read2(parked_off + (unsigned)(2 * r) * TW * 4 + lane * 16, parked_off + (unsigned)(2 * r + 1) * TW * 4 + lane * 16, s0, s1);
 					const row_rsrc_t d0 = row_rsrc(row0, (unsigned)a.nx * 8);
-					store16_row<kNtStore>(d0, (unsigned)c * 8, u4{to_bits(o0[0]), s0[0], to_bits(o0[1]), s0[1]});
-					store16_row<kNtStore>(d0, (unsigned)c * 8 + 16, u4{to_bits(o0[2]), s0[2], to_bits(o0[3]), s0[3]});
+					if (to_lll && a.temporal_shared) {
+						// a further level follows: its merge pass reads this row (even y, even slice of this level) again
+						// at once -- temporal, so that it can stay in the Infinity Cache
+						store16_row<false>(d0, (unsigned)c * 8, u4{to_bits(o0[0]), s0[0], to_bits(o0[1]), s0[1]});
+						store16_row<false>(d0, (unsigned)c * 8 + 16, u4{to_bits(o0[2]), s0[2], to_bits(o0[3]), s0[3]});
+					} else {
+						store16_row<kNtStore>(d0, (unsigned)c * 8, u4{to_bits(o0[0]), s0[0], to_bits(o0[1]), s0[1]});
+						store16_row<kNtStore>(d0, (unsigned)c * 8 + 16, u4{to_bits(o0[2]), s0[2], to_bits(o0[3]), s0[3]});
+					}
 					if (hz) {
 						const row_rsrc_t d1 = row_rsrc(row0 + a.out_sz, (unsigned)a.nx * 8);
 						store16_row<kNtStore>(d1, (unsigned)c * 8, u4{to_bits(o1[0]), s1[0], to_bits(o1[1]), s1[1]});

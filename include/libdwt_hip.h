@@ -108,7 +108,7 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two passes),
  * "vol_whole" (0 = the general kernel variant as a cross-check), "vol_direct" (levels >= 1 into their lattice
  * of the destination: 2 = rows shared by levels 0 and 1 written once, 1 = sample-wise stores, 0 = dense
- * results + scatter passes), "vol_nt", "vol_rows" (8 / 6), "vol_tile_pairs", "vol_swizzle", "vol_cpt",
+ * results + scatter passes), "vol_nt", "vol_rows" (8 / 6), "vol_tile_pairs", "vol_swizzle",
  * "vol_ip_waves" (0 = auto / 4 / 8 waves per workgroup of the one-pass levels: tiles of 32 or 64 rows),
  * "vol_inplace_fused" (in-place calls: 1 = one fused pass per level in place over a snapshot of the tile
  * halos, forward and inverse; 0 = two passes per level). */

@@ -54,7 +54,6 @@ struct Ctx {
 	int il_temporal = 0; // set per interleaved call: the forward sweeps store their even rows temporal (the compose pass reads them again)
 	int il_exact_borders = 1; // interleaved 9/7: 0 = skip the exact border strips (opt-in: not bit-identical in the top 8 rows / last 5 columns of a level)
 	int il_lazy_strips = 1; // interleaved 9/7 forward: the exact border strips on the side stream beside the next level's sweep (0: in line)
-	long ll_offset = 0; // bytes between the start of an LL scratch allocation and the band (placement experiments)
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of
 	// scratch, up to `place_tries` allocations of it -- each behind a spacer that moves it into other
 	// physical memory -- are timed with the call's own first two levels and the fastest kept
@@ -63,7 +62,6 @@ struct Ctx {
 	bool placing = false;       // inside a timed trial: no nested search
 	double place_ms[8] = {0};   // what the last search measured, per candidate
 	int place_n = 0, place_best = -1;
-	int ll_pad = 0; // elements added to the row pitch of the LL scratch bands (placement experiments)
 	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
 	// profiling
 	int prof_on = 0;

@@ -429,25 +429,23 @@ int prof_drain()
 	return 0;
 }
 
-long ll_pitch_elems(int w) { return align_up(w, 4) + g.ll_pad; }
-static char *ll_band(int k) { return (char *)g.ll[k] + g.ll_offset; }
+long ll_pitch_elems(int w) { return align_up(w, 4); }
+static char *ll_band(int k) { return (char *)g.ll[k]; }
 
 size_t ll_band_bytes(const Geom &ge, int k, int batch, int es)
 {
-	return (size_t)ll_pitch_elems(ge.Wo(k + 1)) * ge.Ho(k + 1) * es * batch + 64 + (size_t)g.ll_offset;
+	return (size_t)ll_pitch_elems(ge.Wo(k + 1)) * ge.Ho(k + 1) * es * batch + 64;
 }
 
 int ensure_ll(const Geom &ge, int batch, int es)
 {
 	for (int k = 0; k < 2; k++) {
-		const int w = ge.Wo(k + 1), h = ge.Ho(k + 1);
 		if (g.ll_external) {
-			if (g.ll_bytes[k] < (size_t)ll_pitch_elems(w) * h * es * batch + 64 + (size_t)g.ll_offset)
-				return fail("the caller's workspace (dwt_hip_set_workspace) is too small: band %d needs %zu bytes", k,
-					(size_t)ll_pitch_elems(w) * h * es * batch + 64 + (size_t)g.ll_offset);
+			if (g.ll_bytes[k] < ll_band_bytes(ge, k, batch, es))
+				return fail("the caller's workspace (dwt_hip_set_workspace) is too small: band %d needs %zu bytes", k, ll_band_bytes(ge, k, batch, es));
 			continue;
 		}
-		if (grow(&g.ll[k], &g.ll_bytes[k], (size_t)ll_pitch_elems(w) * h * es * batch + 64 + (size_t)g.ll_offset))
+		if (grow(&g.ll[k], &g.ll_bytes[k], ll_band_bytes(ge, k, batch, es)))
 			return 1;
 	}
 	return 0;
@@ -1046,16 +1044,10 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fma = value;
 	else if (!strcmp(name, "fused_d"))
 		g.fused_d = value;
-	else if (!strcmp(name, "ll_offset_kib"))
-		g.ll_offset = value < 0 ? 0 : (long)value * 1024;
 	else if (!strcmp(name, "place_tries"))
 		g.place_tries = value;
 	else if (!strcmp(name, "place_min_mib"))
 		g.place_min_mib = value < 0 ? 0 : value;
-	else if (!strcmp(name, "ll_pad"))
-		g.ll_pad = value < 0 ? 0 : (value + 3) / 4 * 4;
-	else if (!strcmp(name, "vol_cpt"))
-		g.vol.cpt = value;
 	else if (!strcmp(name, "vol_tile_pairs"))
 		g.vol.tile_pairs = value;
 	else if (!strcmp(name, "vol_nt"))
@@ -1111,8 +1103,6 @@ int dwt_hip_get_option(const char *name)
 		return g.fma;
 	if (!strcmp(name, "fused_d"))
 		return g.fused_d;
-	if (!strcmp(name, "vol_cpt"))
-		return g.vol.cpt;
 	if (!strcmp(name, "vol_tile_pairs"))
 		return g.vol.tile_pairs;
 	if (!strcmp(name, "vol_nt"))

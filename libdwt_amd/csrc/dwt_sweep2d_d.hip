@@ -99,14 +99,21 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 			char *lrow = ring + (size_t)(islot + rr) * RSB;
 			const T *grow = in + (long)r * a.in_pitch;
 			{
+				// (the rows around the tile's upper edge are read again by the tile above at the end of its march:
+				// temporal, so that they can wait in the Infinity Cache; every other row is read once.  dwt_sweep2d.hip)
 				const row_rsrc_t rs = row_rsrc(grow, (unsigned)a.W * 8);
-				dma16_row<2>(rs, (unsigned)c0 * 8 + lane * 16, lrow);
-				dma16_row<2>(rs, (unsigned)(c0 + 128) * 8 + lane * 16, lrow + 1024);
+				if (it < K && A > 0) {
+					dma16_row<0>(rs, (unsigned)c0 * 8 + lane * 16, lrow);
+					dma16_row<0>(rs, (unsigned)(c0 + 128) * 8 + lane * 16, lrow + 1024);
+				} else {
+					dma16_row<2>(rs, (unsigned)c0 * 8 + lane * 16, lrow);
+					dma16_row<2>(rs, (unsigned)(c0 + 128) * 8 + lane * 16, lrow + 1024);
+				}
 			}
 			if (lane < n_edge)
 				dma4<2>((const char *)(grow + edge_col) + 4 * word, lrow + (a.W - c0) * 8);
 			if (lane < 16)
-				dma4<2>((const char *)(grow + halo_col) + 4 * word, lrow + TW * 8);
+				dma4<0>((const char *)(grow + halo_col) + 4 * word, lrow + TW * 8);
 		}
 		islot = islot + 2 >= RING ? 0 : islot + 2;
 	};

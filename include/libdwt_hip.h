@@ -104,7 +104,9 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * "il_lazy_strips" (1 = the interleaved 9/7 forward's exact border strips on a side stream),
  * "il_exact_borders" (0 = no border strips at all: the top 8 rows / last 5 columns of a level keep the sweep's
  * rows-then-columns rounding -- NOT the reference's bits there, a few ulp, far inside 1e-5; opt-in like "fma"),
- * "place_tries" / "place_min_mib" (placement search, below).
+ * "tune_tiles" (1 = forward levels of 64 MiB and more measure their tile height -- 64 / 32 / 16 row pairs --
+ * once per shape, on the first call that may synchronise; 0 = the launcher's rule), "place_tries" /
+ * "place_min_mib" (placement search, below).
  * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two passes),
  * "vol_whole" (0 = the general kernel variant as a cross-check), "vol_direct" (levels >= 1 into their lattice
  * of the destination: 2 = rows shared by levels 0 and 1 written once, 1 = sample-wise stores, 0 = dense

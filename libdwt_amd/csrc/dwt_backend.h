@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <unistd.h>
@@ -57,6 +58,8 @@ struct Ctx {
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of
 	// scratch, up to `place_tries` allocations of it -- each behind a spacer that moves it into other
 	// physical memory -- are timed with the call's own first two levels and the fastest kept
+	int tune_tiles = 1; // large forward levels: tile height measured once per shape (tuned_tile_pairs)
+	std::map<unsigned long long, int> tile_cache;
 	int place_tries = 4;
 	int place_min_mib = 1024;
 	bool placing = false;       // inside a timed trial: no nested search
@@ -135,6 +138,7 @@ size_t ll_band_bytes(const Geom &ge, int k, int batch, int es); // bytes of LL s
 int timed_forward(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db, double *ms); // ms of the 2nd of two calls
 int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db);
 bool stream_is_capturing();
+int tuned_tile_pairs(Wavelet w, const FwdLevelArgs &a);
 int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompose_one, int zero_padding, int batch, long src_bstride, long dst_bstride);
 void prof_before(int level = 0);
 void prof_after(int level = 0);

@@ -461,6 +461,53 @@ bool level_fused_ok(const Geom &ge, int j)
 		ge.Ho(j) >= 2;
 }
 
+// ---- tile height of a large forward level: measured, once per shape ------------------------------------
+// The launcher's rule (64 row pairs per tile unless that leaves too few tiles) is within 1-2 % of the best
+// height for level 0 of most calls, but the best height of a level depends on more than its tile count --
+// level 1 of 32 images wants 32 pairs (735 against 765 us), level 0 of 8 images wants 64 (761 against 778),
+// both have 8192 tiles of 64 pairs; level 3 of 64 images wants 16 (113 against 141 us).  So a level that
+// moves 64 MiB or more is timed ONCE per (wavelet, width, height, batch) with 64, 32 and 16 pairs -- the level
+// is idempotent while its input stands, which it does until the next level runs -- and the fastest height is
+// remembered by the calling thread's context.  Same bits with every height (tests: tile variants).  Never
+// under a stream capture; option "tune_tiles" = 0 turns it off; a forced "tile_pairs" wins.
+int tuned_tile_pairs(Wavelet w, const FwdLevelArgs &a)
+{
+	if (!g.tune_tiles || a.interleaved || (size_t)a.W * a.H * a.batch * sizeof(float) < ((size_t)64 << 20) || a.W < 1024 || a.H < 256)
+		return 0;
+	const unsigned long long key = ((unsigned long long)w << 58) ^ ((unsigned long long)a.W << 38) ^ ((unsigned long long)a.H << 18) ^ (unsigned long long)a.batch;
+	auto it = g.tile_cache.find(key);
+	if (it != g.tile_cache.end())
+		return it->second;
+	if (g.placing || stream_is_capturing())
+		return 0; // decided later, by a call that may synchronise
+	hipEvent_t e0, e1;
+	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+		return 0;
+	int best = 0;
+	float best_ms = 0;
+	for (int tp : {64, 32, 16}) {
+		SweepTuning t = g.tune;
+		t.tile_pairs = tp;
+		float ms = 0;
+		bool ok = true;
+		for (int r = 0; r < 2 && ok; r++) {
+			hipEventRecord(e0, g.stream);
+			ok = launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, t, g.stream) == hipSuccess;
+			hipEventRecord(e1, g.stream);
+		}
+		ok = ok && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+		if (ok && (!best || ms < best_ms)) {
+			best = tp;
+			best_ms = ms;
+		}
+	}
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	(void)hipGetLastError();
+	g.tile_cache[key] = best;
+	return best;
+}
+
 // ---- forward ---------------------------------------------------------------------
 int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompose_one, int zero_padding,
 	int batch, long src_bstride, long dst_bstride)
@@ -528,9 +575,12 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				a.ll_pitch = ll_pitch_elems(Wd);
 				a.ll_bstride = a.ll_pitch * Hd;
 			}
+			SweepTuning tune = g.tune;
+			if (!dbl && tune.tile_pairs <= 0)
+				tune.tile_pairs = tuned_tile_pairs(w, a); // 0: the launcher's own rule
 			prof_before(j);
-			hipError_t e = dbl ? launch_fwd_level_d(w, a, g.tune, g.stream)
-			                   : launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
+			hipError_t e = dbl ? launch_fwd_level_d(w, a, tune, g.stream)
+			                   : launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, tune, g.stream);
 			prof_after(j);
 			if (e != hipSuccess)
 				return fail("forward level %d launch failed: %s", j, hipGetErrorString(e));
@@ -1044,7 +1094,10 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fma = value;
 	else if (!strcmp(name, "fused_d"))
 		g.fused_d = value;
-	else if (!strcmp(name, "place_tries"))
+	else if (!strcmp(name, "tune_tiles")) {
+		g.tune_tiles = value;
+		g.tile_cache.clear();
+	} else if (!strcmp(name, "place_tries"))
 		g.place_tries = value;
 	else if (!strcmp(name, "place_min_mib"))
 		g.place_min_mib = value < 0 ? 0 : value;
@@ -1115,6 +1168,8 @@ int dwt_hip_get_option(const char *name)
 		return g.vol.whole;
 	if (!strcmp(name, "vol_inplace_fused"))
 		return g.vol.inplace_fused;
+	if (!strcmp(name, "tune_tiles"))
+		return g.tune_tiles;
 	if (!strcmp(name, "place_tries"))
 		return g.place_tries;
 	if (!strcmp(name, "place_min_mib"))

@@ -1025,6 +1025,34 @@ def test_batch_sharded_over_devices_in_one_process(dwt, oracle, wname):
         L.dwt_hip_free(dst)
 
 
+def test_measured_tile_heights_do_not_change_the_bits(dwt, oracle):
+    """Large forward levels (64 MiB and more) pick their tile height by timing 64 / 32 / 16 row pairs once per
+    shape (option tune_tiles, default on): a scheduling choice only -- the batch's coefficients are the oracle's
+    with the tuner on, off, and on again (cache cleared in between)."""
+    L = dwt.lib
+    nb, n, J = 5, 2048, 3
+    imgs = np.random.default_rng(61).random((nb, n, n), dtype=np.float32)
+    src, dst = L.dwt_hip_malloc(imgs.nbytes), L.dwt_hip_malloc(imgs.nbytes)
+    assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+    want0, want4 = imgs[0].copy(), imgs[4].copy()
+    oracle.fwd("cdf97_2f_s", want0, J)
+    oracle.fwd("cdf97_2f_s", want4, J)
+    try:
+        for tune in (1, 0, 1):
+            dwt.set_option("tune_tiles", tune)
+            assert dwt.get_option("tune_tiles") == tune
+            assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+            for _ in range(2):  # the first call measures, the second finds the height remembered
+                assert dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J) == J
+            got = np.empty_like(imgs)
+            assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+            assert np.array_equal(bits(got[0]), bits(want0)) and np.array_equal(bits(got[4]), bits(want4)), tune
+    finally:
+        dwt.set_option("tune_tiles", 1)
+        L.dwt_hip_free(src)
+        L.dwt_hip_free(dst)
+
+
 def test_mapped_buffers_are_ordinary_device_memory(dwt, oracle):
     """The diagnosis instruments (dwt_hip_malloc_mapped / _spread: buffers mapped from physical pieces
     through HIP's virtual-memory API) hand out memory every entry accepts and dwt_hip_free releases."""

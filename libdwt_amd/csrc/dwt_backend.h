@@ -139,6 +139,7 @@ int timed_forward(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch
 int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db);
 bool stream_is_capturing();
 int tuned_tile_pairs(Wavelet w, const FwdLevelArgs &a);
+int tuned_tile_pairs(Wavelet w, const InvLevelArgs &a);
 int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompose_one, int zero_padding, int batch, long src_bstride, long dst_bstride);
 void prof_before(int level = 0);
 void prof_after(int level = 0);

@@ -1,20 +1,23 @@
-// dwt_placement.hip -- instruments of the placement diagnosis (profiles/r04_placement.md).
+// dwt_placement.hip -- placement-aware device memory (profiles/r04_placement.md).
 //
 // The sweeps run three streams at once -- source rows, detail subbands, running LL band -- and their rate
 // depends on WHERE in physical memory those lie relative to each other: physical memory falls into coarse
-// regions (16 GiB granules) of three classes, and streams that run at the same time in regions of the same
+// regions (16 GiB granules) of a few classes, and streams that run at the same time in regions of the same
 // class slow each other down (level 0 of 64 images: 5.2 ... 6.2 TB/s on the same virtual addresses), while
-// nothing depends on fine address bits.  The product's answer is a timed choice among candidate
-// allocations (place_ll_scratch / dwt_hip_alloc_batch in dwt_backend.hip).  This file holds what the
-// diagnosis was made with and what scripts/probes/r04_*.py call:
-//   - dwt_hip_probe_pair_us / dwt_hip_probe_copy_us: dense two-stream write / copy probes (they do NOT see
-//     the classes the sweeps see: their DRAM pages stay open);
-//   - dwt_hip_malloc_mapped: a buffer mapped (HIP virtual-memory API) from physical pieces taken in groups
-//     that come from far-apart physical memory, interleaved piece by piece;
-//   - dwt_hip_malloc_spread: pieces at even distances through ALL free physical memory -- every such buffer
-//     is the same mix of the classes: the same rate in every process, but the rate of the mix (5.7 TB/s),
-//     not of the best arrangement (6.2).
-// Buffers of either kind are freed by dwt_hip_free like any other.
+// nothing depends on fine address bits.  The reference hands its callers a placement-aware allocator for the
+// same kind of reason (dwt_util_get_opt_stride / dwt_util_get_stride, src/libdwt.c:20641-20707: power-of-two
+// pitches alias in the CPU caches).  This file holds
+//   - the product's allocators: dwt_hip_alloc_batch / dwt_hip_alloc_volumes over arena_place -- most of the
+//     free memory mapped as ONE arena (HIP virtual-memory API, 1 GiB physical chunks), every arrangement of
+//     destination and workspace measured with the workload itself, the best kept mapped where it was measured;
+//   - the instruments the diagnosis was made with and scripts/probes/r04_*.py call: dense two-stream write /
+//     copy probes (dwt_hip_probe_pair_us / _copy_us: they do NOT see the classes the sweeps see -- their DRAM
+//     pages stay open), buffers mapped from physical pieces of far-apart groups (dwt_hip_malloc_mapped) or from
+//     pieces at even distances through ALL free memory (dwt_hip_malloc_spread: the same mix of the classes for
+//     every buffer -- the same rate in every process, but the rate of the mix, 5.7 TB/s, not of the best
+//     arrangement, 6.2).
+// Buffers of every kind are freed by dwt_hip_free.  (The library's own scratch for callers who bring their
+// buffers: place_ll_scratch in dwt_backend.hip.)
 #include "dwt_backend.h"
 
 #include <algorithm>

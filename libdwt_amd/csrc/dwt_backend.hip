@@ -1088,6 +1088,7 @@ void dwt_hip_sync(void)
 
 int dwt_hip_set_option(const char *name, int value)
 {
+	g.tile_cache.clear(); // measured tile heights belong to the options they were measured under
 	if (!strcmp(name, "generic"))
 		g.force_generic = value;
 	else if (!strcmp(name, "cpt"))
@@ -1116,10 +1117,9 @@ int dwt_hip_set_option(const char *name, int value)
 		g.fma = value;
 	else if (!strcmp(name, "fused_d"))
 		g.fused_d = value;
-	else if (!strcmp(name, "tune_tiles")) {
+	else if (!strcmp(name, "tune_tiles"))
 		g.tune_tiles = value;
-		g.tile_cache.clear();
-	} else if (!strcmp(name, "place_tries"))
+	else if (!strcmp(name, "place_tries"))
 		g.place_tries = value;
 	else if (!strcmp(name, "place_min_mib"))
 		g.place_min_mib = value < 0 ? 0 : value;

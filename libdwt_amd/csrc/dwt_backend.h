@@ -43,10 +43,6 @@ struct Ctx {
 	hipEvent_t dl_ev[8] = {}; // strip events of host_download, created once
 	void *pin = nullptr; // pinned host staging for host-pointer calls with awkward strides
 	size_t pin_bytes = 0;
-	// side stream: the exact border strips of the interleaved 9/7 forward beside the next level's sweep
-	hipStream_t side = nullptr;
-	hipEvent_t side_a = nullptr, side_b = nullptr, side_c = nullptr;
-	bool side_pending = false;
 	// options
 	SweepTuning tune;
 	VolTuning vol;
@@ -54,7 +50,6 @@ struct Ctx {
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
 	int il_temporal = 0; // set per interleaved call: the forward sweeps store their even rows temporal (the compose pass reads them again)
 	int il_exact_borders = 1; // interleaved 9/7: 0 = skip the exact border strips (opt-in: not bit-identical in the top 8 rows / last 5 columns of a level)
-	int il_lazy_strips = 1; // interleaved 9/7 forward: the exact border strips on the side stream beside the next level's sweep (0: in line)
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of
 	// scratch, up to `place_tries` allocations of it -- each behind a spacer that moves it into other
 	// physical memory -- are timed with the call's own first two levels and the fastest kept
@@ -126,8 +121,6 @@ void dev_free(void *p); // hipFree, or the release of a buffer mapped by dwt_pla
 int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
 int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
 int zero_rect(Img img, long x, long y, long w, long h);
-int side_fork();
-int side_join();
 // host images <-> dense device images (any byte strides; awkward pitches go through a pinned buffer)
 int host_upload(const void *hp, int stride_x, int stride_y, int es, int w, int h, void *dp, long pitch);
 int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, const void *dp, long pitch);

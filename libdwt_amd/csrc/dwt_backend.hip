@@ -312,32 +312,6 @@ int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, lo
 	return copy_rect_on(g.stream, dst, dx, dy, src, sx_, sy_, w, h);
 }
 
-// fork: work queued on the side stream from now on starts after everything already
-// queued on the main stream; join: the main stream waits for the side stream
-int side_fork()
-{
-	if (!g.side) {
-		HIP_TRY(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
-		HIP_TRY(hipEventCreateWithFlags(&g.side_a, hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&g.side_b, hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&g.side_c, hipEventDisableTiming));
-	}
-	HIP_TRY(hipEventRecord(g.side_a, g.stream));
-	HIP_TRY(hipStreamWaitEvent(g.side, g.side_a, 0));
-	g.side_pending = true;
-	return 0;
-}
-
-int side_join()
-{
-	if (!g.side_pending)
-		return 0;
-	g.side_pending = false;
-	HIP_TRY(hipEventRecord(g.side_b, g.side));
-	HIP_TRY(hipStreamWaitEvent(g.stream, g.side_b, 0));
-	return 0;
-}
-
 int zero_rect(Img img, long x, long y, long w, long h)
 {
 	if (w <= 0 || h <= 0)
@@ -356,15 +330,10 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 	if (N == 1 && (w == kCdf53I || w == kCdf97I)) {
 		// the int kernels leave a lone sample as it is (src/libdwt.c:10961); out of place that
 		// still means the samples have to arrive in the destination
-		if (in.p != out.p) {
-			if (side_join())
-				return 1;
+		if (in.p != out.p)
 			return copy_rect(out, 0, 0, in, 0, 0, frame_w, frame_h);
-		}
 		return 0;
 	}
-	if (side_join())
-		return 1;
 	const bool alias = in.p == out.p;
 	Img dst = out;
 	if (alias) {
@@ -658,7 +627,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				return 1;
 		}
 	}
-	return side_join();
+	return 0;
 }
 
 // ---- inverse ---------------------------------------------------------------------
@@ -799,7 +768,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				return 1;
 		}
 	}
-	return side_join();
+	return 0;
 }
 
 int check_inited()
@@ -1103,8 +1072,6 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.ring = value;
 	else if (!strcmp(name, "nt_auto"))
 		g.tune.nt_auto = value;
-	else if (!strcmp(name, "il_lazy_strips"))
-		g.il_lazy_strips = value;
 	else if (!strcmp(name, "il_exact_borders"))
 		g.il_exact_borders = value;
 	else if (!strcmp(name, "vol_ip_waves"))
@@ -1160,8 +1127,6 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.ring;
 	if (!strcmp(name, "nt_auto"))
 		return g.tune.nt_auto;
-	if (!strcmp(name, "il_lazy_strips"))
-		return g.il_lazy_strips;
 	if (!strcmp(name, "il_exact_borders"))
 		return g.il_exact_borders;
 	if (!strcmp(name, "vol_ip_waves"))

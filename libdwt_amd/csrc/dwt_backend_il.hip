@@ -113,11 +113,11 @@ static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int
 // core, rows' epilog, columns' epilog) rounds differently only where a column phase runs
 // BEFORE a row phase that touches the same coefficients: the rows the columns' prolog reaches
 // (0 .. 7, forward and inverse) and the columns the rows' epilog updates (the last 5).  Both
-// strips are recomputed from the level's input in the reference's order (k_il_strip, one launch
-// for both) and written over the sweep's result and over the dense low-pass copy the next level reads.
+// strips are computed from the level's input in the reference's order by extra workgroups of the
+// sweep's own launch (dwt_il_strip.h), whose tiles leave those samples alone: every level leaves
+// its launch exact, the dense low-pass copy the next level reads included.
 //   in_even: rows 0, 2, 4, ... of the level input when they live packed in a buffer of their own
-static int il_exact_strips(Wavelet w, bool inverse, Img in, const Img *in_even, Img out, int lx, int ly, float *ll, long ll_pitch,
-	hipStream_t stream)
+static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, const Img *in_even, Img out, int lx, int ly, float *ll, long ll_pitch)
 {
 	const int K = w == kCdf53SNew ? 2 : 4;
 	IlStripArgs a;
@@ -136,27 +136,12 @@ static int il_exact_strips(Wavelet w, bool inverse, Img in, const Img *in_even, 
 		il_phase_ranges(lx, K, inverse, phase, &a.rph[phase - 1]);
 		il_phase_ranges(ly, K, inverse, phase, &a.cph[phase - 1]);
 	}
-	a.n_top = 0;
-	hipError_t e = launch_il_strip(w == kCdf97SFma ? kCdf97S : w, inverse, a, stream);
-	if (e != hipSuccess)
-		return fail("interleaved exact strip launch failed: %s", hipGetErrorString(e));
-	return 0;
+	return a;
 }
 
 // one level on dense images with a common pitch: rows completely, then columns
-//
-// lazy_strips (forward, multi-level): the exact strips of this level run on the SIDE stream, behind
-// this level's sweep and behind the previous level's strips, while the main stream goes on to the
-// next level's sweep.  That sweep may then read low-pass samples the strips have not corrected yet
-// -- rows 0..3 and the last 4 columns of the dense low-pass copy -- and what it computes from them is
-// wrong: but a forward output depends on inputs at most 4 away, so only its rows 0..7 and its last 8
-// columns can be, and the next level's strips (which read the CORRECTED input: they run behind this
-// level's) recompute exactly those.  The region does not grow from level to level (8 rows / 8 columns
-// -> 4 / 4 low-pass -> 8 / 8), so the chain of strips leaves the critical path.  (The inverse has no
-// such fixed point: its corrected region doubles per level.)  The caller joins the side stream
-// before anything else reads the results.
 static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
-	const Img *even_rows = nullptr, int dirs = 3, bool lazy_strips = false)
+	const Img *even_rows = nullptr, int dirs = 3)
 {
 	// dirs: bit 0 rows, bit 1 columns (fdwt2h1_* / fdwt2v1_* lift one direction only: line passes)
 	// phase-ordered wavelets: the fused sweep plus exact border strips needs room for the strips;
@@ -169,19 +154,18 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 	// (option il_exact_borders = 0: no strips -- the borders keep the sweep's rows-then-columns rounding, a few ulp off
 	// the reference's phase order there, far inside the 1e-5 relative tolerance; like "fma" an opt-in, never the default)
 	const bool strips = fused && il_is_phased(w) && w != kCdf97SFma && !scale_single && g.il_exact_borders;
-	const bool lazy = lazy_strips && strips && !inverse;
-	// any other path reads its whole input as it is: pending strips first
-	if (!lazy && side_join())
-		return 1;
 	if (fused) {
 		hipError_t e;
+		IlStripArgs sa;
+		if (strips)
+			sa = il_strip_args(w, inverse, in, even_rows, out, lx, ly, ll, ll_pitch);
 		if (!inverse) {
 			FwdLevelArgs a;
 			a.in = in.p; a.in_pitch = in.sx / 4; a.in_bstride = 0;
 			a.out_ll = ll; a.ll_pitch = ll_pitch; a.ll_bstride = 0;
 			a.out_h = out.p; a.h_pitch = out.sx / 4; a.h_bstride = 0;
 			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1; a.il_ll = ll != nullptr ? (g.il_temporal ? 2 : 1) : 0;
-			e = launch_fwd_level(w, a, g.tune, g.stream);
+			e = launch_fwd_level(w, a, g.tune, g.stream, strips ? &sa : nullptr);
 		} else {
 			InvLevelArgs a;
 			// the even rows may live in a buffer of their own (packed), see interleaved2d
@@ -189,18 +173,10 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 			a.in_h = in.p + in.sx; a.h_pitch = in.sx / 4 * 2; a.h_bstride = 0;
 			a.out = out.p; a.out_pitch = out.sx / 4; a.out_bstride = 0;
 			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1;
-			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream);
+			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream, strips ? &sa : nullptr);
 		}
 		if (e != hipSuccess)
 			return fail("interleaved sweep launch failed: %s", hipGetErrorString(e));
-		// the reference's phase order, where it rounds differently from rows-then-columns
-		if (lazy) {
-			if (side_fork()) // the side stream waits for this sweep (and still holds the previous level's strips)
-				return 1;
-			return il_exact_strips(w, inverse, in, even_rows, out, lx, ly, ll, ll_pitch, g.side);
-		}
-		if (strips)
-			return il_exact_strips(w, inverse, in, even_rows, out, lx, ly, inverse ? nullptr : ll, ll_pitch, g.stream);
 		return 0;
 	}
 	// generic.  The phase-ordered entries reproduce the reference's order exactly when the
@@ -240,26 +216,8 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 	return 0;
 }
 
-static int interleaved2d_body(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
-	int *jp, int decompose_one, int dirs);
-
-// (a failure half way through the forward chain must not leave the side stream forked: under a HIP-graph
-// capture an unjoined fork invalidates the capture)
 static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
 	int *jp, int decompose_one, int dirs = 3)
-{
-	const int rc = interleaved2d_body(w, inverse, scale_single, src, dst, sox, soy, six, siy, jp, decompose_one, dirs);
-	if (rc && g.side_pending) {
-		char keep[sizeof(g_err)];
-		memcpy(keep, g_err, sizeof(keep)); // the first error is the one to report
-		side_join();
-		memcpy(g_err, keep, sizeof(keep));
-	}
-	return rc;
-}
-
-static int interleaved2d_body(Wavelet w, bool inverse, bool scale_single, Img src, Img dst, int sox, int soy, int six, int siy,
-	int *jp, int decompose_one, int dirs)
 {
 	const int j_limit = ceil_log2(decompose_one ? (sox > soy ? sox : soy) : (sox < soy ? sox : soy));
 	int J = *jp;
@@ -267,8 +225,6 @@ static int interleaved2d_body(Wavelet w, bool inverse, bool scale_single, Img sr
 		J = j_limit;
 	if (!inverse)
 		*jp = J;
-	if (side_join())
-		return 1;
 	const bool alias = src.p == dst.p;
 	// out of place the even rows a forward sweep writes are read again by the compose pass: temporal stores
 	// leave them in the Infinity Cache (8192^2 J=5: 305-309 -> 296-298 us; in place, through the staging image,
@@ -333,52 +289,21 @@ static int interleaved2d_body(Wavelet w, bool inverse, bool scale_single, Img sr
 	};
 
 	if (!inverse) {
-		// Lazy strips (il_level): the exact border strips chain along the side stream beside the
-		// sweeps.  Out of place the compose pass does not wait for the whole chain either: it runs once
-		// level 0's strips are in (from then on the image's own samples are final) and is REPEATED, after
-		// the join, over the part of the image the deeper levels' strips can still have changed: level j's
-		// kept rows 0..7 / last 8 columns sit at image rows < 8 * 2^j and columns >= W - 8 * 2^j.
-		const bool lazy = J > 1 && g.il_lazy_strips;
-		const int reach = J > 1 && J <= 20 ? 8 << (J - 1) : 0x7fffffff;
-		bool early = lazy && !alias && reach < six && reach < siy;
 		for (int j = 0; j < J; j++) {
 			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
 			const Img out = j == 0 ? (alias ? stage : dst) : dense(L[j].b, L[j]);
 			float *ll = j + 1 < J ? L[j + 1].a : nullptr;
-			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0, nullptr, dirs, lazy))
+			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0, nullptr, dirs))
 				return 1;
-			if (j == 0 && early) {
-				if (g.side_pending)
-					HIP_TRY(hipEventRecord(g.side_c, g.side)); // level 0's strips
-				else
-					early = false; // level 0 took another path
-			}
 		}
 		if (J == 1)
-			return side_join() || (alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0);
-		hipError_t e;
-		if (early) {
-			HIP_TRY(hipStreamWaitEvent(g.stream, g.side_c, 0));
-			e = launch_il_compose((const float *)dst.p, dst.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream);
-			if (e != hipSuccess)
-				return fail("interleaved compose failed: %s", hipGetErrorString(e));
-			if (side_join())
-				return 1;
-			e = launch_il_compose((const float *)dst.p, dst.sx / 4, (float *)dst.p, dst.sx / 4, six, reach, pyramid(true, J), g.stream);
-			if (e == hipSuccess)
-				e = launch_il_compose((const float *)dst.p, dst.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream, false, (six - reach) & ~7);
-			if (e != hipSuccess)
-				return fail("interleaved compose (border) failed: %s", hipGetErrorString(e));
-			return 0;
-		}
-		if (side_join()) // the strips of every level are in
-			return 1;
+			return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
 		// the even rows receive the samples of the levels >= 1 in ONE pass (in place that pass
 		// also brings them back from the staging image; the odd rows are final after level 0)
 		if (alias && copy_odd_rows(dst, stage))
 			return 1;
 		const Img base = alias ? stage : dst;
-		e = launch_il_compose((const float *)base.p, base.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream);
+		hipError_t e = launch_il_compose((const float *)base.p, base.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream);
 		if (e != hipSuccess)
 			return fail("interleaved compose failed: %s", hipGetErrorString(e));
 		return 0;
@@ -437,8 +362,6 @@ static int inplace_int2d(bool inverse, Img src, Img dst, int sox, int soy, int s
 		J = j_limit;
 	if (!inverse)
 		*jp = J;
-	if (side_join())
-		return 1;
 	if (src.p != dst.p && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))
 		return 1;
 	for (int step = 0; step < J; step++) {

@@ -162,10 +162,11 @@ static __device__ __forceinline__ unsigned lds_offset(const void *p)
 // Workgroup -> tile mapping shared by both sweeps.  Each XCD has its own L2 and
 // workgroups are dealt round-robin over the 8 XCDs, so with `swz` consecutive
 // tiles are handed to the same XCD (neighbouring tiles share halo lines).
-static __device__ __forceinline__ int tile_block_id(int swz)
+static __device__ __forceinline__ int tile_block_id(int swz, int first = 0)
 {
-	int b = blockIdx.x;
-	const int nb = gridDim.x;
+	// (`first`: leading workgroups of the launch that do not take tiles)
+	int b = blockIdx.x - first;
+	const int nb = gridDim.x - first;
 	if (swz && (nb & 7) == 0)
 		b = (b & 7) * (nb >> 3) + (b >> 3);
 	return b;

@@ -90,227 +90,6 @@ hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, 
 	return hipErrorInvalidValue;
 }
 
-// ---- interleaved layout: exact border strips of the fused path, one launch per level ----
-// The fused sweep finishes rows before columns; the reference's phase order rounds differently in
-// the top 8 rows and the last 5 columns of a level only (dwt_backend_il.hip, il_exact_strips).  A
-// workgroup takes a tile of such a strip plus a 12-sample margin from the level's INPUT into LDS
-// -- 24 samples across the strip (from the image border), 128 along it --, runs the six phase
-// passes in the reference's order (rows' prolog, columns' prolog, rows' core, columns' core,
-// rows' epilog, columns' epilog) and writes the part no artificial tile edge can have reached
-// (4 samples per pass along the strip, 12 in all; 16 across it) over the sweep's result and over
-// the dense low-pass copy the next level reads.  A pass is the reference's line kernel restricted
-// to the phase: x[i] += c * (x[i-1] + x[i+1]) over the index range the phase owns, step after
-// step, TRUE line indices, mirrored neighbours at the image border.  Each thread holds a piece of
-// a line in registers -- a whole 24-sample line across the strip, or 8 samples plus 4 either side
-// along it -- so a pass costs one barrier (ping-pong LDS images).  LDS image: [across][along]; the
-// right strip is held transposed, so both strips run the same code.
-template <class W, bool INV, int NE>
-static __device__ __forceinline__ void il_phase_piece(typename W::T (&v)[NE], int i0, int N, int o, int e, const IlPhase &ph)
-{
-	// v[j] <-> true index i0 + j, i0 EVEN (the parity of j is the parity of the index); the tile
-	// holds [o, e).  Branch-free: every candidate update is computed and kept or dropped by a
-	// select.  An update needs both neighbours inside the tile and inside the piece -- except at
-	// the true ends of the line, where the missing neighbour is the mirror image of the other.
-	using T = typename W::T;
-	constexpr int K = W::K;
-	if (INV) {
-#pragma unroll
-		for (int j = 0; j < NE; j++) {
-			const int i = i0 + j;
-			const T sc = W::inv_scale(j & 1, v[j]);
-			v[j] = (i >= ph.sc_lo && i <= ph.sc_hi) ? sc : v[j];
-		}
-	}
-	const int lo_t = o == 0 ? 0 : o + 1, hi_t = e == N ? N - 1 : e - 2; // both neighbours in the tile
-#pragma unroll
-	for (int st = 0; st < K; st++) {
-		constexpr int dummy = 0;
-		(void)dummy;
-		const int par = INV ? (st & 1) : !(st & 1);
-		const int lo = max(ph.lo[st], lo_t), hi = min(ph.hi[st], hi_t);
-#pragma unroll
-		for (int j = 0; j < NE; j++) {
-			if ((j & 1) != par)
-				continue; // compile time
-			const int i = i0 + j;
-			bool ok = i >= lo && i <= hi;
-			T l, r;
-			if (j == 0) {
-				l = v[1];
-				ok = ok && i == 0;
-			} else {
-				l = (i == 0) ? v[j + 1 < NE ? j + 1 : j] : v[j - 1];
-			}
-			if (j == NE - 1) {
-				r = v[NE - 2];
-				ok = ok && i == N - 1;
-			} else {
-				r = (i == N - 1) ? v[j > 0 ? j - 1 : j] : v[j + 1];
-			}
-			const T nv = INV ? W::inv_step(st, v[j], l, r) : W::fwd_step(st, v[j], l, r);
-			v[j] = ok ? nv : v[j];
-		}
-	}
-	if (!INV) {
-#pragma unroll
-		for (int j = 0; j < NE; j++) {
-			const int i = i0 + j;
-			const T sc = W::fwd_scale(j & 1, v[j]);
-			v[j] = (i >= ph.sc_lo && i <= ph.sc_hi) ? sc : v[j];
-		}
-	}
-}
-
-template <class W, bool INV>
-__global__ __launch_bounds__(512) void k_il_strip(IlStripArgs a)
-{
-	using T = typename W::T;
-	// kept across the strip: 8 rows from the top / the last 8 columns.  The reference's order differs from
-	// the sweep's in the last 5 (6 with the parity) columns only; 8 makes the kept region closed under
-	// "what a forward level computes from the uncorrected low-pass samples of the level above" (the
-	// lazy strips of il_level); the band's artificial edge, 23-24 samples from the border, reaches 4.
-	constexpr int kKeep = 104, kMargin = 12, kBand = 24, kKeepTop = 8, kKeepRight = 8, kLong = kKeep + 2 * kMargin;
-	constexpr int kOwn = 8, kHalo = 4, kPiece = kOwn + 2 * kHalo;
-	// the lazy strips (dwt_backend_il.hip) rely on this: a forward output depends on inputs at most K away, so what the
-	// next level computes from not-yet-corrected low-pass samples (rows 0..K-1, the last K columns) stays inside ITS kept
-	// region of 2 K rows / columns and is recomputed by its own strips (a race-check tool will flag that read)
-	static_assert(kKeepTop >= 2 * W::K && kKeepRight >= 2 * W::K, "kept region must close over the lifting reach");
-	__shared__ T buf[2][kBand * kLong];
-	// blocks [0, n_top): tiles of the top strip; the rest: tiles of the right strip
-	const bool top = (int)blockIdx.x < a.n_top;
-	const int tile = top ? blockIdx.x : blockIdx.x - a.n_top;
-	// "long" axis: along the strip (x for the top strip, y for the right one); "short": across it
-	const int n_long = top ? a.lx : a.ly, n_short = top ? a.ly : a.lx;
-	const int l0 = tile * kKeep;
-	const int ol = max(0, l0 - kMargin) & ~1, el = min(n_long, l0 + kKeep + kMargin); // tile range, long axis
-	// the band starts on an even index (23 or 24 samples for the right strip): piece parity = index parity
-	const int os = top ? 0 : max(0, n_short - (kBand - 1)) & ~1, es = top ? min(n_short, kBand) : n_short;
-	const int nl = el - ol, ns = es - os;
-	auto load = [&](int y, int x) -> T {
-		return (a.in_even && !(y & 1)) ? a.in_even[(long)(y >> 1) * a.even_pitch + x] : a.in[(long)y * a.in_pitch + x];
-	};
-	// tile -> LDS: all of a thread's loads in flight together (kBand * kLong = 6 x 512 elements)
-	{
-		constexpr int kPer = kBand * kLong / 512;
-		T tmp[kPer];
-		int where[kPer];
-#pragma unroll
-		for (int k = 0; k < kPer; k++) {
-			const int idx = threadIdx.x + 512 * k;
-			// top strip: consecutive lanes along x; right strip: kBand consecutive lanes share an image row
-			const int sl = top ? idx / kLong : idx % kBand, ll_ = top ? idx % kLong : idx / kBand;
-			const bool ok = sl < ns && ll_ < nl;
-			where[k] = ok ? sl * kLong + ll_ : -1;
-			const int sh = os + sl, lo = ol + ll_;
-			tmp[k] = ok ? (top ? load(sh, lo) : load(lo, sh)) : T(0);
-		}
-#pragma unroll
-		for (int k = 0; k < kPer; k++)
-			if (where[k] >= 0)
-				buf[0][where[k]] = tmp[k];
-	}
-	__syncthreads();
-	int cur = 0;
-#pragma unroll 1
-	for (int pass = 0; pass < 6; pass++) {
-		const bool rows = !(pass & 1);
-		const bool along_long = top ? rows : !rows;
-		const IlPhase ph = rows ? a.rph[pass >> 1] : a.cph[pass >> 1];
-		const int N = rows ? a.lx : a.ly;
-		{
-			// a phase that owns no index inside the tile leaves it as it is: no pass, no barrier
-			const int o = along_long ? ol : os, e = along_long ? el : es;
-			bool touches = ph.sc_lo <= ph.sc_hi && ph.sc_hi >= o && ph.sc_lo < e;
-#pragma unroll
-			for (int st = 0; st < W::K; st++)
-				touches = touches || (ph.lo[st] <= ph.hi[st] && ph.hi[st] >= o && ph.lo[st] < e);
-			if (!touches)
-				continue;
-		}
-		const T *src = buf[cur];
-		T *dst = buf[cur ^ 1];
-		if (along_long) {
-			// a thread: 8 samples of one line + 4 either side; pieces of a line on consecutive lanes
-			const int npieces = (nl + kOwn - 1) / kOwn; // <= 16
-			for (int it = threadIdx.x; it < ns * 16; it += blockDim.x) {
-				const int line = it >> 4, pc = it & 15;
-				if (pc >= npieces)
-					continue;
-				const int i0 = ol + pc * kOwn - kHalo; // true index of v[0]
-				T v[kPiece];
-#pragma unroll
-				for (int j = 0; j < kPiece; j++) {
-					const int i = i0 + j;
-					v[j] = (i >= ol && i < el) ? src[line * kLong + (i - ol)] : T(0);
-				}
-				il_phase_piece<W, INV, kPiece>(v, i0, N, ol, el, ph);
-#pragma unroll
-				for (int j = kHalo; j < kHalo + kOwn; j++) {
-					const int i = i0 + j;
-					if (i < el)
-						dst[line * kLong + (i - ol)] = v[j];
-				}
-			}
-		} else {
-			// a thread: one whole line across the strip (24 samples, stride kLong)
-			for (int line = threadIdx.x; line < nl; line += blockDim.x) {
-				T v[kBand];
-#pragma unroll
-				for (int j = 0; j < kBand; j++)
-					v[j] = j < ns ? src[j * kLong + line] : T(0);
-				il_phase_piece<W, INV, kBand>(v, os, N, os, es, ph);
-#pragma unroll
-				for (int j = 0; j < kBand; j++)
-					if (j < ns)
-						dst[j * kLong + line] = v[j];
-			}
-		}
-		__syncthreads();
-		cur ^= 1;
-	}
-	// kept part: along the strip [l0, l0 + kKeep), across it the 8 rows from the top / the last 6 columns
-	const int kl0 = l0, kl1 = min(n_long, l0 + kKeep);
-	const int ks0 = top ? 0 : max(0, n_short - kKeepRight), ks1 = top ? min(n_short, kKeepTop) : n_short;
-	const int kw = ks1 - ks0, kn = kl1 - kl0;
-#pragma unroll
-	for (int k = 0; k < 2; k++) { // at most 8 x 104 kept samples
-		const int idx = threadIdx.x + 512 * k;
-		const int sl = top ? idx / kKeep : idx % kKeepTop, ll_ = top ? idx % kKeep : idx / kKeepTop;
-		if (sl < kw && ll_ < kn) {
-			const int sh = ks0 + sl, lo = kl0 + ll_;
-			const int y = top ? sh : lo, x = top ? lo : sh;
-			const T v = buf[cur][(sh - os) * kLong + (lo - ol)];
-			a.out[(long)y * a.out_pitch + x] = v;
-			if (a.ll && !((x | y) & 1))
-				a.ll[(long)(y >> 1) * a.ll_pitch + (x >> 1)] = v;
-		}
-	}
-}
-
-hipError_t launch_il_strip(Wavelet w, bool inverse, IlStripArgs a, hipStream_t s)
-{
-	if (a.lx < 32 || a.ly < 32)
-		return hipErrorInvalidValue;
-	a.n_top = (a.lx + 103) / 104;
-	const int n = a.n_top + (a.ly + 103) / 104;
-	switch (w) {
-	case kCdf97S:
-		if (inverse)
-			k_il_strip<Cdf97S, true><<<n, 512, 0, s>>>(a);
-		else
-			k_il_strip<Cdf97S, false><<<n, 512, 0, s>>>(a);
-		break;
-	case kCdf53SNew:
-		if (inverse)
-			return hipErrorInvalidValue;
-		k_il_strip<Cdf53SNew, false><<<n, 512, 0, s>>>(a);
-		break;
-	default:
-		return hipErrorInvalidValue;
-	}
-	return hipGetLastError();
-}
-
 // ---- interleaved layout: all levels' lattices in one pass over the even rows ----
 // A lattice-1 point (p, q) (image column 2p, row 2q) belongs to level
 // j = 1 + min(ctz(p), ctz(q)) capped at J-1; its sample sits at (p >> (j-1), q >> (j-1))

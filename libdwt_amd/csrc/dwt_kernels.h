@@ -58,9 +58,13 @@ struct InvLevelArgs {
 	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
 };
 
-hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
+// `strip` (interleaved layout, float 9/7 both ways and fdwt2_cdf53 forward, one image of 64 samples or more either
+// way): the launch also computes the level's border strips in the reference's phase order and its tiles leave those
+// samples alone (dwt_il_strip.h)
+struct IlStripArgs;
+hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip = nullptr);
 
-hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s);
+hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip = nullptr);
 // the same two sweeps for the double-precision wavelets (dwt_sweep2d_d.hip); pitches in 8-byte ELEMENTS
 hipError_t launch_fwd_level_d(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s);
 hipError_t launch_inv_level_d(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s);
@@ -181,10 +185,8 @@ struct IlStripArgs {
 	float *ll;
 	long ll_pitch;
 	int lx, ly;
-	int n_top; // set by the launcher: workgroups of the top strip (the rest take the right strip)
 	IlPhase rph[3], cph[3];
 };
-hipError_t launch_il_strip(Wavelet w, bool inverse, IlStripArgs a, hipStream_t s);
 
 // Interleaved (in-place lifting) layout, multi-level: the dense per-level images of the
 // levels 1..J-1 (level j has ceil(W/2^j) x ceil(H/2^j) samples and lives on the stride-2^j

@@ -29,6 +29,7 @@
 // this file is compiled with -ffp-contract=off, so float results are bit-identical
 // to libdwt's CPU path; int results are exact.
 #include "dwt_device.h"
+#include "dwt_il_strip.h"
 
 namespace dwt {
 
@@ -127,14 +128,18 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 struct SweepGeom {
 	int tile_pairs, ntx, swz;
 	int wave_horiz; // 1: the waves of a workgroup take horizontally adjacent tiles
+	int first = 0;  // k_*_sweep_x: the leading workgroups of the launch that take border strips, not tiles
 };
 
 // ---- forward -------------------------------------------------------------------
 // IL: write the result INTERLEAVED in place of the Mallat de-interleave (row 2k = L
 // row, row 2k+1 = H row, columns interleaved alike) to `out_h`: the layout of the
 // 3-D path (src/volume-dwt.c:677-725), where a batch is the slices of a volume.
-template <class W, int CPT, int RING, int NT, bool IL = false>
-__global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
+// X (interleaved layout, phase-ordered wavelets): the tiles leave out the samples whose rounding depends on the
+// reference's phase order -- rows 0..7 and the last 8 columns of the level -- for the strip workgroups of the
+// same launch (dwt_il_strip.h).
+template <class W, int CPT, int RING, int NT, bool IL, bool X>
+static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, const SweepGeom &g)
 {
 	using T = typename W::T;
 	constexpr int K = W::K;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
 	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int bid = tile_block_id(g.swz);
+	const int bid = tile_block_id(g.swz, X ? g.first : 0);
 	int tx, ty;
 	if (g.wave_horiz) {
 		const int ntxb = (g.ntx + nwv - 1) / nwv;
@@ -346,11 +351,13 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 		}
 
 		if constexpr (IL) {
-			if (it >= K) {
+			if (it >= K && (!X || A + it - K >= kIlKeepTop / 2)) {
 				const int k = A + it - K;
 				const unsigned cb = (unsigned)(c0 + lane * CPT) * 4; // byte offset in an interleaved row
 				const T *r0 = out_h + (long)(2 * k) * a.h_pitch;
-				const row_rsrc_t d0 = row_rsrc(r0, (unsigned)a.W * 4);
+				// (X: the rows end 8 columns early -- the buffer drops what lies beyond)
+				const unsigned row_bytes = (unsigned)(X ? a.W - kIlKeepRight : a.W) * 4;
+				const row_rsrc_t d0 = row_rsrc(r0, row_bytes);
 				// multi-level: the compose pass reads this (even) row again soon -- temporal, so that it can stay in the
 				// Infinity Cache; the odd rows are final: non-temporal
 #pragma unroll
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 						store16_row<kNtStore>(d0, cb + e * 4, v4);
 				}
 				if (2 * k + 1 < a.H) {
-					const row_rsrc_t d1 = row_rsrc(r0 + a.h_pitch, (unsigned)a.W * 4);
+					const row_rsrc_t d1 = row_rsrc(r0 + a.h_pitch, row_bytes);
 #pragma unroll
 					for (int e = 0; e < CPT; e += 4)
 						store16_row<kNtStore>(d1, cb + e * 4, u4{to_bits(hi[e]), to_bits(hi[e + 1]), to_bits(hi[e + 2]), to_bits(hi[e + 3])});
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 				// multi-level: the next level's input (even row, even column) also goes
 				// out densely, so that no level has to gather a strided lattice
 				if (a.il_ll) {
-					const row_rsrc_t dl = row_rsrc(out_ll + (long)k * a.ll_pitch, (unsigned)Wd * 4);
+					const row_rsrc_t dl = row_rsrc(out_ll + (long)k * a.ll_pitch, (unsigned)(X ? (a.W - kIlKeepRight + 1) >> 1 : Wd) * 4);
 #pragma unroll
 					for (int e = 0; e < CPT; e += 4)
 						store8_row<false>(dl, cb / 2 + e * 2, u2{to_bits(lo[e]), to_bits(lo[e + 2])});
@@ -405,13 +412,30 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	}
 }
 
+template <class W, int CPT, int RING, int NT, bool IL = false>
+__global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
+{
+	fwd_sweep_tile<W, CPT, RING, NT, IL, false>(a, g);
+}
+
+// one level of a phase-ordered interleaved transform, exact: workgroups [0, g.first) compute the border strips
+template <class W, int CPT, int RING, int NT>
+__global__ __launch_bounds__(256) void k_fwd_sweep_x(FwdLevelArgs a, SweepGeom g, IlStripArgs strip)
+{
+	if ((int)blockIdx.x < g.first) {
+		il_strip_wave<W, false>(strip, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+		return;
+	}
+	fwd_sweep_tile<W, CPT, RING, NT, true, true>(a, g);
+}
+
 // ---- inverse -------------------------------------------------------------------
 // Source rows are Mallat rows: "L row p" = [LL | HL] and "H row p" = [LH | HH].
 // LDS row slot (floats): [L main M | H main M | L halo 8 | H halo 8], M = TW/2;
 // a halo block is [4 columns left of the tile | 4 columns right of the tile].
 // IL: the input is INTERLEAVED (3-D path layout) at `in_h` instead of Mallat subbands.
-template <class W, int CPT, int RING, int NT, bool IL = false>
-__global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
+template <class W, int CPT, int RING, int NT, bool IL, bool X>
+static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, const SweepGeom &g)
 {
 	using T = typename W::T;
 	constexpr int K = W::K;
@@ -440,7 +464,7 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
 	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int bid = tile_block_id(g.swz);
+	const int bid = tile_block_id(g.swz, X ? g.first : 0);
 	int tx, ty;
 	if (g.wave_horiz) {
 		const int ntxb = (g.ntx + nwv - 1) / nwv;
@@ -714,8 +738,9 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 		// output rows and their validity inside this tile
 		const int pe = (K == 4) ? p - 1 : p;     // pair index of even_row
 		const int po = (K == 4) ? p - 2 : p - 1; // pair index of odd_row
-		const bool ve = pe >= A && pe < B;
-		const bool vo = po >= A && po < B && (2 * po + 1 < a.H);
+		const bool ve = pe >= A && pe < B && (!X || pe >= kIlKeepTop / 2);
+		const bool vo = po >= A && po < B && (2 * po + 1 < a.H) && (!X || po >= kIlKeepTop / 2);
+		const unsigned row_bytes = (unsigned)(X ? a.W - kIlKeepRight : a.W) * 4;
 
 		T orow[G][CG], erow[G][CG];
 #pragma unroll
@@ -745,14 +770,30 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 			for (int e = 0; e < CG; e += 4) {
 				const unsigned cb = (unsigned)(c0 + 64 * CG * gi + lane * CG + e) * 4;
 				if (vo)
-					store16_row<kNtStore>(row_rsrc(out + (long)(2 * po + 1) * a.out_pitch, (unsigned)a.W * 4), cb,
+					store16_row<kNtStore>(row_rsrc(out + (long)(2 * po + 1) * a.out_pitch, row_bytes), cb,
 						u4{to_bits(orow[gi][e]), to_bits(orow[gi][e + 1]), to_bits(orow[gi][e + 2]), to_bits(orow[gi][e + 3])});
 				if (ve)
-					store16_row<kNtStore>(row_rsrc(out + (long)(2 * pe) * a.out_pitch, (unsigned)a.W * 4), cb,
+					store16_row<kNtStore>(row_rsrc(out + (long)(2 * pe) * a.out_pitch, row_bytes), cb,
 						u4{to_bits(erow[gi][e]), to_bits(erow[gi][e + 1]), to_bits(erow[gi][e + 2]), to_bits(erow[gi][e + 3])});
 			}
 		}
 	}
+}
+
+template <class W, int CPT, int RING, int NT, bool IL = false>
+__global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
+{
+	inv_sweep_tile<W, CPT, RING, NT, IL, false>(a, g);
+}
+
+template <class W, int CPT, int RING, int NT>
+__global__ __launch_bounds__(256) void k_inv_sweep_x(InvLevelArgs a, SweepGeom g, IlStripArgs strip)
+{
+	if ((int)blockIdx.x < g.first) {
+		il_strip_wave<W, true>(strip, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+		return;
+	}
+	inv_sweep_tile<W, CPT, RING, NT, true, true>(a, g);
 }
 
 // ---- launch wrappers -------------------------------------------------------------
@@ -831,8 +872,20 @@ static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid,
 	}
 }
 
+template <class W, int RING>
+static hipError_t fwd_launch_x(const FwdLevelArgs &a, SweepGeom g, dim3 grid, int waves, const IlStripArgs &strip, hipStream_t s)
+{
+	const size_t lds = (size_t)waves * RING * (64 * 4 + 8) * 4;
+	if (hipError_t e = allow_lds((const void *)k_fwd_sweep_x<W, 4, RING, 3>, lds))
+		return e;
+	g.first = il_strip_blocks(a.W, a.H, waves);
+	grid.x += g.first;
+	k_fwd_sweep_x<W, 4, RING, 3><<<grid, 64 * waves, lds, s>>>(a, g, strip);
+	return hipGetLastError();
+}
+
 template <class W>
-static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s)
+static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip = nullptr)
 {
 	if (a.W < 2 || a.H < 2 || a.batch < 1)
 		return hipErrorInvalidValue;
@@ -863,6 +916,16 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	if (a.interleaved) {
 		// 3-D path: float 9/7 only; always 4 columns per lane so that each row leaves the
 		// wave as ONE contiguous 16 B/lane store (two strided stores per row cost 40 %)
+		if constexpr (std::is_same<W, Cdf97S>::value || std::is_same<W, Cdf53SNew>::value) {
+			// exact border strips in the same launch (one image, levels of 64 samples or more either way)
+			if (strip) {
+				if (a.batch != 1 || a.W < 64 || a.H < 64)
+					return hipErrorInvalidValue;
+				return tt.ring == 16 ? fwd_launch_x<W, 16>(a, g, grid, waves, *strip, s) : fwd_launch_x<W, 8>(a, g, grid, waves, *strip, s);
+			}
+		}
+		if (strip)
+			return hipErrorInvalidValue;
 		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
 			if (tt.ring == 16)
 				return fwd_launch<W, 4, 16, 3, true>(a, g, grid, waves, s);
@@ -871,6 +934,8 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 			return hipErrorInvalidValue;
 		}
 	}
+	if (strip)
+		return hipErrorInvalidValue;
 	// Cache policy bit 2 keeps the LL band's stores temporal so that the next level finds it in the
 	// 256 MiB Infinity Cache.  The LL bands of a large batch do not fit (64 images of 8192^2: 4.3 GB):
 	// temporal stores then only displace other lines -- non-temporal like the detail bands (64 images,
@@ -902,8 +967,20 @@ static hipError_t inv_pick(const InvLevelArgs &a, const SweepGeom &g, dim3 grid,
 	return inv_launch<W, CPT, 8, 1, false>(a, g, grid, waves, s);
 }
 
+template <class W, int CPT>
+static hipError_t inv_launch_x(const InvLevelArgs &a, SweepGeom g, dim3 grid, int waves, const IlStripArgs &strip, hipStream_t s)
+{
+	const size_t lds = (size_t)waves * 8 * (64 * CPT + 16) * 4;
+	if (hipError_t e = allow_lds((const void *)k_inv_sweep_x<W, CPT, 8, 0>, lds))
+		return e;
+	g.first = il_strip_blocks(a.W, a.H, waves);
+	grid.x += g.first;
+	k_inv_sweep_x<W, CPT, 8, 0><<<grid, 64 * waves, lds, s>>>(a, g, strip);
+	return hipGetLastError();
+}
+
 template <class W>
-static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipStream_t s)
+static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip = nullptr)
 {
 	if (a.W < 2 || a.H < 2 || a.batch < 1)
 		return hipErrorInvalidValue;
@@ -926,33 +1003,48 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
+		if constexpr (std::is_same<W, Cdf97S>::value) {
+			if (strip) {
+				if (a.batch != 1 || a.W < 64 || a.H < 64)
+					return hipErrorInvalidValue;
+				return cpt == 8 ? inv_launch_x<W, 8>(a, g, grid, waves, *strip, s) : inv_launch_x<W, 4>(a, g, grid, waves, *strip, s);
+			}
+		}
+		if (strip)
+			return hipErrorInvalidValue;
 		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
 			return cpt == 8 ? inv_launch<W, 8, 8, 0, true>(a, g, grid, waves, s) : inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
 		} else {
 			return hipErrorInvalidValue;
 		}
 	}
+	if (strip)
+		return hipErrorInvalidValue;
 	return cpt == 8 ? inv_pick<W, 8>(a, g, grid, waves, ring, s) : inv_pick<W, 4>(a, g, grid, waves, ring, s);
 }
 
-hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s)
+hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip)
 {
+	if (strip && w != kCdf97S && w != kCdf53SNew)
+		return hipErrorInvalidValue;
 	switch (w) {
-	case kCdf97S: return fwd_level_t<Cdf97S>(a, t, s);
+	case kCdf97S: return fwd_level_t<Cdf97S>(a, t, s, strip);
 	case kCdf53I: return fwd_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return fwd_level_t<Cdf53S>(a, t, s);
 	case kCdf97I: return fwd_level_t<Cdf97I>(a, t, s);
 	case kCdf97SFma: return fwd_level_t<Cdf97SFma>(a, t, s);
-	case kCdf53SNew: return a.interleaved ? fwd_level_t<Cdf53SNew>(a, t, s) : hipErrorInvalidValue;
+	case kCdf53SNew: return a.interleaved ? fwd_level_t<Cdf53SNew>(a, t, s, strip) : hipErrorInvalidValue;
 	default: break; // the double-precision drivers run on the line-pass kernels
 	}
 	return hipErrorInvalidValue;
 }
 
-hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s)
+hipError_t launch_inv_level(Wavelet w, const InvLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip)
 {
+	if (strip && w != kCdf97S)
+		return hipErrorInvalidValue;
 	switch (w) {
-	case kCdf97S: return inv_level_t<Cdf97S>(a, t, s);
+	case kCdf97S: return inv_level_t<Cdf97S>(a, t, s, strip);
 	case kCdf53I: return inv_level_t<Cdf53I>(a, t, s);
 	case kCdf53S: return inv_level_t<Cdf53S>(a, t, s);
 	case kCdf97I: return inv_level_t<Cdf97I>(a, t, s);

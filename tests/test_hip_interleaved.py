@@ -386,33 +386,37 @@ def test_one_direction_entries(dwt, oracle, shape, which):
 
 @pytest.mark.parametrize("shape,levels", [((2048, 2048), 5), ((1500, 1000), 3), ((3001, 4097), 5), ((4096, 1024), 4), ((640, 2000), 2),
                                           ((8192, 8192), 5)], ids=lambda v: str(v))
-def test_lazy_border_strips_do_not_change_the_bits(dwt, oracle, shape, levels):
-    """Forward 9/7, device resident, out of place: by default the exact border strips of level j run
-    on a side stream beside level j+1's sweep (which may read low-pass samples not corrected yet: what it
-    computes from them is recomputed by the next level's strips) and the compose pass runs before the
-    chain has ended, repeated over the image border afterwards.  Same bits as the in-line order
-    (il_lazy_strips = 0) on images large enough for the early compose, and the oracle's bits where the
-    oracle is quick enough."""
+def test_border_strips_in_the_sweeps_launch(dwt, oracle, shape, levels):
+    """9/7, device resident, out of place, both directions: the samples whose rounding depends on the reference's
+    phase order (rows 0..7, the last 8 columns of every level) are computed by extra workgroups of each level's own
+    sweep launch while its tiles leave them alone.  Same bits as the reference's order pass by pass over the whole
+    image (accel 1), and as the oracle where the oracle is quick enough."""
     h, w = shape
     rng = np.random.default_rng(h * 3 + w + levels)
     img = rng.random((h, w), dtype=np.float32)
     src = dwt.DeviceImage(h, w).upload(img)
     outs = []
-    for lazy in (1, 0, 1):
+    for accel in (0, 1):
         dst = dwt.DeviceImage(h, w).upload(np.full((h, w), -9.0, np.float32))
-        dwt.set_option("il_lazy_strips", lazy)
+        back = dwt.DeviceImage(h, w).upload(np.full((h, w), -7.0, np.float32))
+        dwt.dwt_util_set_accel(accel)
         try:
             j = dwt.transform2d_interleaved("cdf97_s", 0, 0, src.ptr, dst.ptr, w * 4, 4, w, h, None, None, levels)
+            dwt.transform2d_interleaved("cdf97_s", 1, 0, dst.ptr, back.ptr, w * 4, 4, w, h, None, None, levels)
         finally:
-            dwt.set_option("il_lazy_strips", 1)
+            dwt.dwt_util_set_accel(0)
         assert j == levels
-        outs.append(dst.download(np.float32))
+        outs.append((dst.download(np.float32), back.download(np.float32)))
         dst.free()
-    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+        back.free()
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])), "forward"
+    assert np.array_equal(bits(outs[0][1]), bits(outs[1][1])), "inverse"
     if h * w <= 3001 * 4097:
         want = img.copy()
         oracle.fwd("cdf97_2f_inplace_s", want, levels)
-        assert np.array_equal(bits(outs[0]), bits(want))
+        assert np.array_equal(bits(outs[0][0]), bits(want))
+        oracle.inv("cdf97_2i_inplace_s", want, levels)
+        assert np.array_equal(bits(outs[0][1]), bits(want))
     src.free()
 
 

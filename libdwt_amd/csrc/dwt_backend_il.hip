@@ -116,16 +116,17 @@ static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int
 // strips are computed from the level's input in the reference's order by extra workgroups of the
 // sweep's own launch (dwt_il_strip.h), whose tiles leave those samples alone: every level leaves
 // its launch exact, the dense low-pass copy the next level reads included.
-//   in_even: rows 0, 2, 4, ... of the level input when they live packed in a buffer of their own
-static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, const Img *in_even, Img out, int lx, int ly, float *ll, long ll_pitch)
+//   in_step / ll2: see il_level
+static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, int in_step, const float *ll2, long ll2_pitch, Img out, int lx, int ly,
+	float *ll, long ll_pitch)
 {
 	const int K = w == kCdf53SNew ? 2 : 4;
 	IlStripArgs a;
-	// with packed even rows, `in` holds the image's odd rows at their place (row y at y * pitch)
 	a.in = (const float *)in.p;
 	a.in_pitch = in.sx / 4;
-	a.in_even = in_even ? (const float *)in_even->p : nullptr;
-	a.even_pitch = in_even ? in_even->sx / 4 : 0;
+	a.in_step = in_step;
+	a.ll_in = ll2;
+	a.ll_in_pitch = ll2_pitch;
 	a.out = (float *)out.p;
 	a.out_pitch = out.sx / 4;
 	a.ll = inverse ? nullptr : ll;
@@ -140,17 +141,25 @@ static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, const Img *in_
 }
 
 // one level on dense images with a common pitch: rows completely, then columns
+// whether a level takes the fused sweep.  Phase-ordered wavelets: the sweep plus exact border strips needs room for
+// the strips; smaller levels take the exact phase passes for the whole level
+static bool il_fusable(Wavelet w, bool scale_single, int lx, int ly, int dirs)
+{
+	const bool phased_small = il_is_phased(w) && w != kCdf97SFma && !scale_single && (lx < 64 || ly < 64);
+	return dirs == 3 && !g.force_generic && !phased_small && lx >= 2 && ly >= 2;
+}
+
+// inverse, fused sweep only: the level may be read where it lives -- `in` = the rows of its lattice in a larger image
+// (in.sx = that lattice's row pitch), `in_step` elements between neighbouring samples of a row -- with the samples at
+// (even row, even column) taken from the dense low-pass band `ll2` (the level below's result) instead
 static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
-	const Img *even_rows = nullptr, int dirs = 3)
+	int dirs = 3, int in_step = 1, const float *ll2 = nullptr, long ll2_pitch = 0)
 {
 	// dirs: bit 0 rows, bit 1 columns (fdwt2h1_* / fdwt2v1_* lift one direction only: line passes)
-	// phase-ordered wavelets: the fused sweep plus exact border strips needs room for the strips;
-	// smaller levels take the exact phase passes for the whole level (below)
 	const bool phased_small = il_is_phased(w) && w != kCdf97SFma && !scale_single && (lx < 64 || ly < 64);
-	const bool fused = dirs == 3 && !g.force_generic && !(phased_small && !even_rows) && lx >= 2 && ly >= 2 &&
-		(((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
-	if (even_rows && !fused)
-		return fail("internal: split rows need the fused sweep");
+	const bool fused = il_fusable(w, scale_single, lx, ly, dirs) && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
+	if ((in_step != 1 || ll2) && !(fused && inverse))
+		return fail("internal: only the fused inverse sweep reads a lattice");
 	// (option il_exact_borders = 0: no strips -- the borders keep the sweep's rows-then-columns rounding, a few ulp off
 	// the reference's phase order there, far inside the 1e-5 relative tolerance; like "fma" an opt-in, never the default)
 	const bool strips = fused && il_is_phased(w) && w != kCdf97SFma && !scale_single && g.il_exact_borders;
@@ -158,7 +167,7 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 		hipError_t e;
 		IlStripArgs sa;
 		if (strips)
-			sa = il_strip_args(w, inverse, in, even_rows, out, lx, ly, ll, ll_pitch);
+			sa = il_strip_args(w, inverse, in, in_step, ll2, ll2_pitch, out, lx, ly, ll, ll_pitch);
 		if (!inverse) {
 			FwdLevelArgs a;
 			a.in = in.p; a.in_pitch = in.sx / 4; a.in_bstride = 0;
@@ -168,11 +177,11 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 			e = launch_fwd_level(w, a, g.tune, g.stream, strips ? &sa : nullptr);
 		} else {
 			InvLevelArgs a;
-			// the even rows may live in a buffer of their own (packed), see interleaved2d
-			a.in_ll = even_rows ? even_rows->p : in.p; a.ll_pitch = even_rows ? even_rows->sx / 4 : in.sx / 4 * 2; a.ll_bstride = 0;
+			a.in_ll = in.p; a.ll_pitch = in.sx / 4 * 2; a.ll_bstride = 0;
 			a.in_h = in.p + in.sx; a.h_pitch = in.sx / 4 * 2; a.h_bstride = 0;
 			a.out = out.p; a.out_pitch = out.sx / 4; a.out_bstride = 0;
 			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1;
+			a.in_step = in_step; a.in_ll2 = ll2; a.ll2_pitch = ll2_pitch;
 			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream, strips ? &sa : nullptr);
 		}
 		if (e != hipSuccess)
@@ -293,7 +302,7 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
 			const Img out = j == 0 ? (alias ? stage : dst) : dense(L[j].b, L[j]);
 			float *ll = j + 1 < J ? L[j + 1].a : nullptr;
-			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0, nullptr, dirs))
+			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0, dirs))
 				return 1;
 		}
 		if (J == 1)
@@ -308,8 +317,11 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			return fail("interleaved compose failed: %s", hipGetErrorString(e));
 		return 0;
 	}
-	// inverse: the coefficients are read from the source image (never modified before the last
-	// sweep has read it, so out of place needs no copy)
+	// inverse: the coefficients are read from the source image, never modified before the last sweep has read it.
+	// A level that takes the fused sweep reads its lattice where it lives in the image, the samples at (even row, even
+	// column) from the dense result of the level below: no gather of the lattices, no copies between the levels, no
+	// compose pass (round 4; 8192^2 J=5: 309 -> 2xx us).  Other levels (tiny ones of the phase-ordered wavelets, the
+	// generic path) get their input gathered into a dense image first.
 	const Img cin = src;
 	if (J == 1) {
 		if (!alias)
@@ -318,29 +330,32 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			return 1;
 		return copy_rect(dst, 0, 0, stage, 0, 0, six, siy);
 	}
-	hipError_t e = launch_il_decompose((const float *)cin.p, cin.sx / 4, six, siy, pyramid(false, J), g.stream);
-	if (e != hipSuccess)
-		return fail("interleaved decompose failed: %s", hipGetErrorString(e));
+	const bool aligned = ((uintptr_t)cin.p | (uintptr_t)dst.p) % 4 == 0;
+	hipError_t e;
 	for (int j = J - 1; j >= 1; j--) {
+		const float *ll2 = j + 1 < J ? L[j + 1].b : nullptr;
+		const long ll2_pitch = j + 1 < J ? L[j + 1].pitch : 0;
+		if (aligned && il_fusable(w, scale_single, L[j].lx, L[j].ly, 3)) {
+			if (il_level(w, true, scale_single, Img{cin.p, cin.sx << j, 4}, dense(L[j].b, L[j]), L[j].lx, L[j].ly, nullptr, 0, 3, 1 << j, ll2, ll2_pitch))
+				return 1;
+			continue;
+		}
+		e = launch_lattice_copy((const float *)cin.p, 1L << j, (cin.sx / 4) << j, 0, L[j].a, 1, L[j].pitch, 0, L[j].lx, L[j].ly, 1, g.stream);
+		if (e != hipSuccess)
+			return fail("lattice gather failed: %s", hipGetErrorString(e));
+		// the reconstructed low-pass band of the level below is the even-even lattice of this one
+		if (ll2 && scatter(ll2, ll2_pitch, (char *)L[j].a, L[j].pitch * 4, 2, L[j + 1]))
+			return 1;
 		if (il_level(w, true, scale_single, dense(L[j].a, L[j]), dense(L[j].b, L[j]), L[j].lx, L[j].ly, nullptr, 0))
 			return 1;
-		// the reconstructed low-pass band is the even-even lattice of the level above
-		if (j >= 2 && scatter(L[j].b, L[j].pitch, (char *)L[j - 1].a, L[j - 1].pitch * 4, 2, L[j]))
+	}
+	// level 0.  In place the sweep must not write what other tiles still read: it writes the staging image
+	if (aligned && il_fusable(w, scale_single, L[0].lx, L[0].ly, 3)) {
+		if (il_level(w, true, scale_single, cin, alias ? stage : dst, L[0].lx, L[0].ly, nullptr, 0, 3, 1, L[1].b, L[1].pitch))
 			return 1;
+		return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
 	}
-	// level 0.  Out of place (fused sweep): odd rows straight from the coefficient image, even
-	// rows from a packed copy that carries the reconstructed LL band (one compose pass).  In
-	// place the sweep must not read what it overwrites: its whole input is built in the staging
-	// image (odd rows copied, even rows composed) and the sweep writes the caller's image.
-	const bool phased_small = il_is_phased(w) && w != kCdf97SFma && !scale_single && (L[0].lx < 64 || L[0].ly < 64);
-	const bool split = !alias && !g.force_generic && !phased_small && L[0].lx >= 2 && L[0].ly >= 2;
-	if (split) {
-		const Img even{stage.p, stage.sx, 4}; // (siy+1)/2 packed rows
-		e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)even.p, even.sx / 4, six, siy, pyramid(true, 2), g.stream, true);
-		if (e != hipSuccess)
-			return fail("interleaved compose failed: %s", hipGetErrorString(e));
-		return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0, &even);
-	}
+	// generic path: the whole input is built in the staging image (odd rows copied, even rows composed)
 	if (copy_odd_rows(stage, cin))
 		return 1;
 	e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)stage.p, stage.sx / 4, six, siy, pyramid(true, 2), g.stream);

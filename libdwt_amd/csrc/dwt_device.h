@@ -48,6 +48,12 @@ static __device__ __forceinline__ void dma16_row(row_rsrc_t r, unsigned byte_off
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16, byte_off, 0, 0, AUX);
 }
 
+template <int AUX = 0>
+static __device__ __forceinline__ void dma4_row(row_rsrc_t r, unsigned byte_off, void *l)
+{
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 4, byte_off, 0, 0, AUX);
+}
+
 template <bool NT>
 static __device__ __forceinline__ u4 load16_row(row_rsrc_t r, unsigned byte_off)
 {

@@ -158,7 +158,7 @@ static __device__ __forceinline__ void il_strip_wave(const IlStripArgs &a, int t
 		for (int j = 0; j < kBand; j++) {
 			const int y = top ? yl + j : yl, x = top ? xl : xl + j;
 			const bool ok = here && j < ns;
-			const T *p = (a.in_even && !(y & 1)) ? a.in_even + (long)(y >> 1) * a.even_pitch + x : a.in + (long)y * a.in_pitch + x;
+			const T *p = (a.ll_in && !((x | y) & 1)) ? a.ll_in + (long)(y >> 1) * a.ll_in_pitch + (x >> 1) : a.in + (long)y * a.in_pitch + (long)x * a.in_step;
 			v[j] = ok ? *p : T(0);
 		}
 	}

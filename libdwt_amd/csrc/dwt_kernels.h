@@ -56,6 +56,10 @@ struct InvLevelArgs {
 	long out_pitch, out_bstride;
 	int W, H, batch;
 	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
+	// interleaved only -- a level read straight from the lattice it lives on in a larger image:
+	int in_step = 1;              // elements between neighbouring samples of a source row (2^j on the lattice of level j)
+	const void *in_ll2 = nullptr; // dense low-pass band (ceil(W/2) x ceil(H/2), the level below's result): replaces the
+	long ll2_pitch = 0;           // samples at (even row, even column) of the source
 };
 
 // `strip` (interleaved layout, float 9/7 both ways and fdwt2_cdf53 forward, one image of 64 samples or more either
@@ -178,8 +182,9 @@ hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, 
 struct IlStripArgs {
 	const float *in;
 	long in_pitch;
-	const float *in_even;
-	long even_pitch;
+	int in_step;         // elements between neighbouring samples of an input row (a level on its lattice in a larger image)
+	const float *ll_in;  // or null: dense low-pass band that replaces the input samples at (even row, even column)
+	long ll_in_pitch;
 	float *out;
 	long out_pitch;
 	float *ll;

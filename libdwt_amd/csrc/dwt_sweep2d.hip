@@ -434,9 +434,13 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_x(FwdLevelArgs a, SweepGeom g
 // LDS row slot (floats): [L main M | H main M | L halo 8 | H halo 8], M = TW/2;
 // a halo block is [4 columns left of the tile | 4 columns right of the tile].
 // IL: the input is INTERLEAVED (3-D path layout) at `in_h` instead of Mallat subbands.
-template <class W, int CPT, int RING, int NT, bool IL, bool X>
+// SP (interleaved input, CPT 4): the even rows are SPLIT -- their even columns (the low-pass band) come from the dense
+// image `in_ll2`, their odd columns from the source row -- and take the Mallat rows' LDS layout and register gather;
+// with `in_step` > 1 the source rows are rows of a lattice in a larger image.
+template <class W, int CPT, int RING, int NT, bool IL, bool X, bool SP = false>
 static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, const SweepGeom &g)
 {
+	static_assert(!SP || (IL && CPT == 4), "split even rows: interleaved input, 4 columns per lane");
 	using T = typename W::T;
 	constexpr int K = W::K;
 	constexpr int kRing = RING;
@@ -458,7 +462,8 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	constexpr int NARR = CG + 2 * K - 1;         // interleaved samples c-K+1 .. c+CG+K-1 of a group
 	constexpr int HC = CG / 2;                   // subband columns per lane and group
 	constexpr int kDmaMain = IL ? CPT / 4 : (CPT == 8 ? 2 : 1);
-	constexpr int kDmaPerIter = 2 * (kDmaMain + 1);
+	// (the fewest an iteration issues: SP even row: L segment, two strided H loads, halo)
+	constexpr int kDmaPerIter = SP ? 4 + kDmaMain + 1 : 2 * (kDmaMain + 1);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
 	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
@@ -512,6 +517,8 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	if constexpr (IL) {
 		halo_colI = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
 	}
+	const int step = IL ? a.in_step : 1;
+	const unsigned src_row_bytes = ((unsigned)(a.W - 1) * step + 1) * 4; // a source row up to its last sample
 	auto issue = [&](int it) {
 		const int p = p0 + it;
 		if constexpr (IL) {
@@ -520,18 +527,42 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				const int r = reflect(2 * p + rr, a.H);
 				char *lrow = ring + (size_t)((2 * it + rr) & (kRing - 1)) * RS * 4;
 				// even rows come from in_ll, odd rows from in_h (reflection keeps the parity): the
-				// two may be different buffers (multi-level inverse: composed even rows)
+				// two may be different buffers
 				const T *grow = (r & 1) ? in_h + (long)(r >> 1) * a.h_pitch : in_ll + (long)(r >> 1) * a.ll_pitch;
-				{
+				if (SP && rr == 0) {
+					// even row, split: LDS row as for Mallat rows, [L main M | H main M | L halo 8 | H halo 8]
+					const T *gl = (const T *)a.in_ll2 + (long)(r >> 1) * a.ll2_pitch;
+					const row_rsrc_t rl = row_rsrc(gl, (unsigned)nL * 4), rh = row_rsrc(grow, src_row_bytes);
+					if (lane < 32)
+						dma16_row<kLdAux>(rl, (unsigned)(cl0 + lane * 4) * 4, lrow);
+#pragma unroll
+					for (int i = 0; i < 2; i++)
+						dma4_row<kLdAux>(rh, (unsigned)(2 * (cl0 + 64 * i + lane) + 1) * step * 4, lrow + M * 4 + i * 256);
+					if (edge_tile) {
+						if (lane < 2 && nL + lane < cl0 + M)
+							dma4<kLdAux>(gl + edge_col, lrow + (nL - cl0) * 4);
+						if (lane >= 2 && lane < 4 && nH + (lane & 1) < cl0 + M)
+							dma4<kLdAux>(grow + (long)(2 * edge_col + 1) * step, lrow + M * 4 + (nH - cl0) * 4 - 8);
+					}
+					if (lane < 16)
+						dma4<kLdAux>(halo_is_h ? grow + (long)(2 * halo_col + 1) * step : gl + halo_col, lrow + 2 * M * 4);
+					continue;
+				}
+				if (step == 1) {
 					const row_rsrc_t rs = row_rsrc(grow, (unsigned)a.W * 4);
 #pragma unroll
 					for (int i = 0; i < CPT / 4; i++)
 						dma16_row<kLdAux>(rs, (unsigned)(c0 + i * 256 + lane * 4) * 4, lrow + i * 1024);
-					if (lane < min(4, c0 + TW - a.W))
-						dma4<kLdAux>(grow + reflect(a.W + min(lane, 3), a.W), lrow + (a.W - c0) * 4);
+				} else {
+					const row_rsrc_t rs = row_rsrc(grow, src_row_bytes);
+#pragma unroll
+					for (int i = 0; i < CPT; i++)
+						dma4_row<kLdAux>(rs, (unsigned)(c0 + 64 * i + lane) * step * 4, lrow + i * 256);
 				}
+				if (lane < min(4, c0 + TW - a.W))
+					dma4<kLdAux>(grow + (long)reflect(a.W + min(lane, 3), a.W) * step, lrow + (a.W - c0) * 4);
 				if (lane < 8)
-					dma4<kLdAux>(grow + halo_colI, lrow + TW * 4);
+					dma4<kLdAux>(grow + (long)halo_colI * step, lrow + TW * 4);
 			}
 			return;
 		}
@@ -620,7 +651,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
 			const unsigned base = ring_off + (unsigned)((2 * it + rr) & (kRing - 1)) * RS * 4;
-			if constexpr (IL) {
+			if (IL && !(SP && rr == 0)) { // (compile time once the loop is unrolled)
 				// LDS row: [main TW | left halo 4 | right halo 4] of interleaved samples
 				const unsigned own = base + lane * CPT * 4;
 				const unsigned la = lane == 0 ? base + TW * 4 : own - 16;
@@ -786,14 +817,21 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 	inv_sweep_tile<W, CPT, RING, NT, IL, false>(a, g);
 }
 
-template <class W, int CPT, int RING, int NT>
+// interleaved input, 4 columns per lane; SP: split even rows (InvLevelArgs::in_ll2)
+template <class W, int RING, int NT, bool SP>
+__global__ __launch_bounds__(256) void k_inv_sweep_il(InvLevelArgs a, SweepGeom g)
+{
+	inv_sweep_tile<W, 4, RING, NT, true, false, SP>(a, g);
+}
+
+template <class W, int RING, int NT, bool SP>
 __global__ __launch_bounds__(256) void k_inv_sweep_x(InvLevelArgs a, SweepGeom g, IlStripArgs strip)
 {
 	if ((int)blockIdx.x < g.first) {
 		il_strip_wave<W, true>(strip, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 		return;
 	}
-	inv_sweep_tile<W, CPT, RING, NT, true, true>(a, g);
+	inv_sweep_tile<W, 4, RING, NT, true, true, SP>(a, g);
 }
 
 // ---- launch wrappers -------------------------------------------------------------
@@ -967,15 +1005,25 @@ static hipError_t inv_pick(const InvLevelArgs &a, const SweepGeom &g, dim3 grid,
 	return inv_launch<W, CPT, 8, 1, false>(a, g, grid, waves, s);
 }
 
-template <class W, int CPT>
+template <class W, bool SP>
 static hipError_t inv_launch_x(const InvLevelArgs &a, SweepGeom g, dim3 grid, int waves, const IlStripArgs &strip, hipStream_t s)
 {
-	const size_t lds = (size_t)waves * 8 * (64 * CPT + 16) * 4;
-	if (hipError_t e = allow_lds((const void *)k_inv_sweep_x<W, CPT, 8, 0>, lds))
+	const size_t lds = (size_t)waves * 8 * (64 * 4 + 16) * 4;
+	if (hipError_t e = allow_lds((const void *)k_inv_sweep_x<W, 8, 0, SP>, lds))
 		return e;
 	g.first = il_strip_blocks(a.W, a.H, waves);
 	grid.x += g.first;
-	k_inv_sweep_x<W, CPT, 8, 0><<<grid, 64 * waves, lds, s>>>(a, g, strip);
+	k_inv_sweep_x<W, 8, 0, SP><<<grid, 64 * waves, lds, s>>>(a, g, strip);
+	return hipGetLastError();
+}
+
+template <class W>
+static hipError_t inv_launch_il_sp(const InvLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, hipStream_t s)
+{
+	const size_t lds = (size_t)waves * 8 * (64 * 4 + 16) * 4;
+	if (hipError_t e = allow_lds((const void *)k_inv_sweep_il<W, 8, 0, true>, lds))
+		return e;
+	k_inv_sweep_il<W, 8, 0, true><<<grid, 64 * waves, lds, s>>>(a, g);
 	return hipGetLastError();
 }
 
@@ -1003,17 +1051,21 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.interleaved) {
+		if (a.in_step < 1 || (a.in_ll2 && (a.ll2_pitch < (a.W + 1) / 2)))
+			return hipErrorInvalidValue;
 		if constexpr (std::is_same<W, Cdf97S>::value) {
 			if (strip) {
 				if (a.batch != 1 || a.W < 64 || a.H < 64)
 					return hipErrorInvalidValue;
-				return cpt == 8 ? inv_launch_x<W, 8>(a, g, grid, waves, *strip, s) : inv_launch_x<W, 4>(a, g, grid, waves, *strip, s);
+				return a.in_ll2 ? inv_launch_x<W, true>(a, g, grid, waves, *strip, s) : inv_launch_x<W, false>(a, g, grid, waves, *strip, s);
 			}
 		}
 		if (strip)
 			return hipErrorInvalidValue;
 		if constexpr (std::is_base_of<Cdf97S, W>::value || std::is_base_of<Cdf53S, W>::value) {
-			return cpt == 8 ? inv_launch<W, 8, 8, 0, true>(a, g, grid, waves, s) : inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
+			if (a.in_ll2)
+				return inv_launch_il_sp<W>(a, g, grid, waves, s);
+			return inv_launch<W, 4, 8, 0, true>(a, g, grid, waves, s);
 		} else {
 			return hipErrorInvalidValue;
 		}

@@ -116,9 +116,9 @@ static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int
 // strips are computed from the level's input in the reference's order by extra workgroups of the
 // sweep's own launch (dwt_il_strip.h), whose tiles leave those samples alone: every level leaves
 // its launch exact, the dense low-pass copy the next level reads included.
-//   in_step / ll2: see il_level
-static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, int in_step, const float *ll2, long ll2_pitch, Img out, int lx, int ly,
-	float *ll, long ll_pitch)
+//   in_step / ll2 / out_step: see il_level
+static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, int in_step, const float *ll2, long ll2_pitch, Img out, int out_step,
+	int lx, int ly, float *ll, long ll_pitch)
 {
 	const int K = w == kCdf53SNew ? 2 : 4;
 	IlStripArgs a;
@@ -129,6 +129,7 @@ static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, int in_step, c
 	a.ll_in_pitch = ll2_pitch;
 	a.out = (float *)out.p;
 	a.out_pitch = out.sx / 4;
+	a.out_step = out_step;
 	a.ll = inverse ? nullptr : ll;
 	a.ll_pitch = ll_pitch;
 	a.lx = lx;
@@ -149,17 +150,19 @@ static bool il_fusable(Wavelet w, bool scale_single, int lx, int ly, int dirs)
 	return dirs == 3 && !g.force_generic && !phased_small && lx >= 2 && ly >= 2;
 }
 
-// inverse, fused sweep only: the level may be read where it lives -- `in` = the rows of its lattice in a larger image
-// (in.sx = that lattice's row pitch), `in_step` elements between neighbouring samples of a row -- with the samples at
-// (even row, even column) taken from the dense low-pass band `ll2` (the level below's result) instead
+// Fused sweep only: a level may be read (inverse) or written (forward) where it lives -- `in` / `out` = the rows of its
+// lattice in a larger image (sx = that lattice's row pitch), `lat_step` elements between neighbouring samples of a row.
+// Inverse: the samples at (even row, even column) come from the dense low-pass band `ll2` (the level below's result)
+// instead; forward: with `ll` (a deeper level follows) those lattice points are left for the deeper levels to fill.
 static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
-	int dirs = 3, int in_step = 1, const float *ll2 = nullptr, long ll2_pitch = 0)
+	int dirs = 3, int lat_step = 1, const float *ll2 = nullptr, long ll2_pitch = 0)
 {
+	const int in_step = inverse ? lat_step : 1, out_step = inverse ? 1 : lat_step;
 	// dirs: bit 0 rows, bit 1 columns (fdwt2h1_* / fdwt2v1_* lift one direction only: line passes)
 	const bool phased_small = il_is_phased(w) && w != kCdf97SFma && !scale_single && (lx < 64 || ly < 64);
 	const bool fused = il_fusable(w, scale_single, lx, ly, dirs) && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
-	if ((in_step != 1 || ll2) && !(fused && inverse))
-		return fail("internal: only the fused inverse sweep reads a lattice");
+	if ((lat_step != 1 || ll2) && !fused)
+		return fail("internal: only the fused sweeps work on a lattice");
 	// (option il_exact_borders = 0: no strips -- the borders keep the sweep's rows-then-columns rounding, a few ulp off
 	// the reference's phase order there, far inside the 1e-5 relative tolerance; like "fma" an opt-in, never the default)
 	const bool strips = fused && il_is_phased(w) && w != kCdf97SFma && !scale_single && g.il_exact_borders;
@@ -167,13 +170,14 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 		hipError_t e;
 		IlStripArgs sa;
 		if (strips)
-			sa = il_strip_args(w, inverse, in, in_step, ll2, ll2_pitch, out, lx, ly, ll, ll_pitch);
+			sa = il_strip_args(w, inverse, in, in_step, ll2, ll2_pitch, out, out_step, lx, ly, ll, ll_pitch);
 		if (!inverse) {
 			FwdLevelArgs a;
 			a.in = in.p; a.in_pitch = in.sx / 4; a.in_bstride = 0;
 			a.out_ll = ll; a.ll_pitch = ll_pitch; a.ll_bstride = 0;
 			a.out_h = out.p; a.h_pitch = out.sx / 4; a.h_bstride = 0;
 			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1; a.il_ll = ll != nullptr ? (g.il_temporal ? 2 : 1) : 0;
+			a.out_step = out_step;
 			e = launch_fwd_level(w, a, g.tune, g.stream, strips ? &sa : nullptr);
 		} else {
 			InvLevelArgs a;
@@ -283,39 +287,28 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 		stage.p = (char *)g.stage_img;
 	}
 
-	auto pyramid = [&](bool results, int levels) {
-		IlPyramid py;
-		py.J = levels;
-		for (int j = 1; j < levels; j++) {
-			py.p[j] = results ? L[j].b : L[j].a;
-			py.pitch[j] = L[j].pitch;
-		}
-		return py;
-	};
-	// rows 1, 3, 5, ... of the transformed region from one image to another
-	auto copy_odd_rows = [&](Img to, Img from) -> int {
-		return copy_rect(Img{to.p + to.sx, to.sx * 2, 4}, 0, 0, Img{from.p + from.sx, from.sx * 2, 4}, 0, 0, six, siy / 2);
-	};
-
 	if (!inverse) {
+		// Every level runs on a dense image (the level above hands its low-pass samples over densely) and writes its
+		// result where it lives: a fused level straight to its lattice in the destination (round 4: no compose pass),
+		// other levels through a dense image and a scatter.  Where a deeper level follows, the lattice points at (even
+		// row, even column) are rewritten by it later in the stream.  In place the whole result is built in the
+		// staging image -- the sweep of level 0 must not write what other tiles still read -- and copied back.
+		const Img res = alias ? stage : dst;
+		const bool aligned = ((uintptr_t)src.p | (uintptr_t)res.p) % 4 == 0;
 		for (int j = 0; j < J; j++) {
 			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
-			const Img out = j == 0 ? (alias ? stage : dst) : dense(L[j].b, L[j]);
 			float *ll = j + 1 < J ? L[j + 1].a : nullptr;
-			if (il_level(w, false, scale_single, in, out, L[j].lx, L[j].ly, ll, j + 1 < J ? L[j + 1].pitch : 0, dirs))
+			const long ll_pitch = j + 1 < J ? L[j + 1].pitch : 0;
+			if (j == 0 || (aligned && il_fusable(w, scale_single, L[j].lx, L[j].ly, dirs))) {
+				if (il_level(w, false, scale_single, in, Img{res.p, res.sx << j, 4}, L[j].lx, L[j].ly, ll, ll_pitch, dirs, 1 << j))
+					return 1;
+				continue;
+			}
+			if (il_level(w, false, scale_single, in, dense(L[j].b, L[j]), L[j].lx, L[j].ly, ll, ll_pitch, dirs) ||
+				scatter(L[j].b, L[j].pitch, res.p, res.sx, 1L << j, L[j]))
 				return 1;
 		}
-		if (J == 1)
-			return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
-		// the even rows receive the samples of the levels >= 1 in ONE pass (in place that pass
-		// also brings them back from the staging image; the odd rows are final after level 0)
-		if (alias && copy_odd_rows(dst, stage))
-			return 1;
-		const Img base = alias ? stage : dst;
-		hipError_t e = launch_il_compose((const float *)base.p, base.sx / 4, (float *)dst.p, dst.sx / 4, six, siy, pyramid(true, J), g.stream);
-		if (e != hipSuccess)
-			return fail("interleaved compose failed: %s", hipGetErrorString(e));
-		return 0;
+		return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
 	}
 	// inverse: the coefficients are read from the source image, never modified before the last sweep has read it.
 	// A level that takes the fused sweep reads its lattice where it lives in the image, the samples at (even row, even
@@ -355,12 +348,10 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			return 1;
 		return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
 	}
-	// generic path: the whole input is built in the staging image (odd rows copied, even rows composed)
-	if (copy_odd_rows(stage, cin))
+	// generic path: the whole input is built in the staging image (the coefficients, the level below's result on their
+	// even-even lattice)
+	if (copy_rect(stage, 0, 0, cin, 0, 0, six, siy) || scatter(L[1].b, L[1].pitch, stage.p, stage.sx, 2, L[1]))
 		return 1;
-	e = launch_il_compose((const float *)cin.p, cin.sx / 4, (float *)stage.p, stage.sx / 4, six, siy, pyramid(true, 2), g.stream);
-	if (e != hipSuccess)
-		return fail("interleaved compose failed: %s", hipGetErrorString(e));
 	return il_level(w, true, scale_single, stage, dst, L[0].lx, L[0].ly, nullptr, 0);
 }
 

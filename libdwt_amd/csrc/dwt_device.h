@@ -72,6 +72,12 @@ static __device__ __forceinline__ void store8_row(row_rsrc_t r, unsigned byte_of
 	__builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, NT ? 2 : 0);
 }
 
+template <bool NT>
+static __device__ __forceinline__ void store4_row(row_rsrc_t r, unsigned byte_off, unsigned v)
+{
+	__builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, NT ? 2 : 0);
+}
+
 template <bool NT, class V>
 static __device__ __forceinline__ void store_vec(V *p, V v)
 {

@@ -192,7 +192,7 @@ static __device__ __forceinline__ void il_strip_wave(const IlStripArgs &a, int t
 		const int sh = os + j;
 		if (sh >= ks0 && sh < ks1) {
 			const int y = top ? sh : il, x = top ? il : sh;
-			a.out[(long)y * a.out_pitch + x] = v[j];
+			a.out[(long)y * a.out_pitch + (long)x * a.out_step] = v[j];
 			if (a.ll && !((x | y) & 1))
 				a.ll[(long)(y >> 1) * a.ll_pitch + (x >> 1)] = v[j];
 		}

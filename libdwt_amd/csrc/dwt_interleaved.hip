@@ -1,5 +1,5 @@
 // dwt_interleaved.hip -- kernels of the interleaved (in-place lifting) layout beyond the sweeps:
-// the exact phase-ordered line kernel, the compose / decompose passes over the level lattices,
+// the exact phase-ordered line kernel (the cross-check path and the levels too small for the sweeps),
 // and the device-side view helpers (conv_show, compare).
 #include "dwt_device.h"
 
@@ -90,125 +90,6 @@ hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, 
 	return hipErrorInvalidValue;
 }
 
-// ---- interleaved layout: all levels' lattices in one pass over the even rows ----
-// A lattice-1 point (p, q) (image column 2p, row 2q) belongs to level
-// j = 1 + min(ctz(p), ctz(q)) capped at J-1; its sample sits at (p >> (j-1), q >> (j-1))
-// of that level's dense image.  One thread owns 8 image columns of one even row.
-static __device__ __forceinline__ int il_level_of(int p, int q, int J)
-{
-	const int t = __builtin_ctz((unsigned)(p | q) | (1u << 30)); // ctz(0) -> 30
-	const int j = 1 + t;
-	return j < J ? j : J - 1;
-}
-
-__global__ __launch_bounds__(256) void k_il_compose(const float *__restrict__ base, long base_pitch, float *__restrict__ out,
-	long out_pitch, int W, int H, IlPyramid py, int vec_ok, int out_dense, int x_begin)
-{
-	// grid.x = even rows (may exceed 65535), grid.y = blocks of 2048 columns from x_begin (a multiple of 8)
-	const int x0 = x_begin + (blockIdx.y * blockDim.x + threadIdx.x) * 8;
-	const int q = blockIdx.x, y = 2 * q;
-	if (x0 >= W || y >= H)
-		return;
-	const float *b = base + (long)y * base_pitch + x0;
-	float *o = out + (long)(out_dense ? q : y) * out_pitch + x0;
-	const int p0 = x0 >> 1;
-	float v[8];
-	const bool vec = vec_ok && x0 + 8 <= W;
-	if (vec) {
-		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
-#pragma unroll
-		for (int e = 0; e < 4; e++) {
-			v[e] = from_bits<float>(t0[e]);
-			v[4 + e] = from_bits<float>(t1[e]);
-		}
-		const u4 l1 = *(const u4 *)(py.p[1] + (long)q * py.pitch[1] + p0);
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			v[2 * i] = from_bits<float>(l1[i]);
-	} else {
-#pragma unroll
-		for (int e = 0; e < 8; e++)
-			if (x0 + e < W)
-				v[e] = (e & 1) ? b[e] : py.p[1][(long)q * py.pitch[1] + p0 + (e >> 1)];
-	}
-	if (py.J > 2 && !(q & 1)) {
-		// p0 is a multiple of 4: the points p0 and p0+2 lie on deeper lattices
-#pragma unroll
-		for (int i = 0; i < 4; i += 2)
-			if (x0 + 2 * i < W) {
-				const int p = p0 + i, j = il_level_of(p, q, py.J);
-				v[2 * i] = py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + (p >> (j - 1))];
-			}
-	}
-	if (vec) {
-		*(u4 *)o = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
-		*(u4 *)(o + 4) = u4{to_bits(v[4]), to_bits(v[5]), to_bits(v[6]), to_bits(v[7])};
-	} else {
-#pragma unroll
-		for (int e = 0; e < 8; e++)
-			if (x0 + e < W)
-				o[e] = v[e];
-	}
-}
-
-__global__ __launch_bounds__(256) void k_il_decompose(const float *__restrict__ img, long pitch, int W, int H, IlPyramid py, int vec_ok)
-{
-	const int x0 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
-	const int q = blockIdx.x, y = 2 * q;
-	if (x0 >= W || y >= H)
-		return;
-	const float *b = img + (long)y * pitch + x0;
-	const int p0 = x0 >> 1;
-	float v[4];
-	const bool vec = vec_ok && x0 + 8 <= W;
-	if (vec) {
-		const u4 t0 = *(const u4 *)b, t1 = *(const u4 *)(b + 4);
-		v[0] = from_bits<float>(t0[0]); v[1] = from_bits<float>(t0[2]);
-		v[2] = from_bits<float>(t1[0]); v[3] = from_bits<float>(t1[2]);
-		*(u4 *)(py.p[1] + (long)q * py.pitch[1] + p0) = u4{to_bits(v[0]), to_bits(v[1]), to_bits(v[2]), to_bits(v[3])};
-	} else {
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			if (x0 + 2 * i < W) {
-				v[i] = b[2 * i];
-				py.p[1][(long)q * py.pitch[1] + p0 + i] = v[i];
-			}
-	}
-	// deeper lattices: level j takes the points whose p and q are multiples of 2^(j-1)
-	for (int j = 2; j < py.J; j++) {
-		const int m = (1 << (j - 1)) - 1;
-		if (q & m)
-			break;
-#pragma unroll
-		for (int i = 0; i < 4; i += 2)
-			if (!((p0 + i) & m) && x0 + 2 * i < W)
-				py.p[j][(long)(q >> (j - 1)) * py.pitch[j] + ((p0 + i) >> (j - 1))] = v[i];
-	}
-}
-
-static int il_vec_ok(const float *a, long ap, const float *b, long bp, const IlPyramid &py)
-{
-	return aligned16(a) && aligned16(b) && ap % 4 == 0 && bp % 4 == 0 && py.J > 1 && aligned16(py.p[1]) && py.pitch[1] % 4 == 0;
-}
-
-hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H, const IlPyramid &py, hipStream_t s,
-	bool out_dense, int x_begin)
-{
-	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || x_begin < 0 || x_begin >= W || (x_begin & 7) || ((W + 7) / 8 + 255) / 256 > 65535)
-		return hipErrorInvalidValue;
-	dim3 grid((H + 1) / 2, ((W - x_begin + 7) / 8 + 255) / 256);
-	k_il_compose<<<grid, 256, 0, s>>>(base, base_pitch, out, out_pitch, W, H, py, il_vec_ok(base, base_pitch, out, out_pitch, py), out_dense, x_begin);
-	return hipGetLastError();
-}
-
-hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s)
-{
-	if (py.J < 2 || py.J > 24 || W < 1 || H < 1 || ((W + 7) / 8 + 255) / 256 > 65535)
-		return hipErrorInvalidValue;
-	dim3 grid((H + 1) / 2, ((W + 7) / 8 + 255) / 256);
-	k_il_decompose<<<grid, 256, 0, s>>>(img, pitch, W, H, py, il_vec_ok(img, pitch, img, pitch, py));
-	return hipGetLastError();
-}
 
 } // namespace dwt
 

@@ -42,6 +42,9 @@ struct FwdLevelArgs {
 	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path / in-place lifting layout)
 	int il_ll = 0;       // interleaved only: also write the LL samples densely to out_ll
 	int temporal = 0;    // 1: every store temporal (the outputs are read again at once: staging of an in-place call)
+	int out_step = 1;    // interleaved only: elements between neighbouring samples of an output row -- 2^j when the level
+	                     // is written straight to the lattice it lives on in a larger image (h_pitch: that lattice's row
+	                     // pitch); with il_ll the samples at (even row, even column) are then left to the deeper levels
 };
 
 // One reconstruction level, inverse, dense frame.  Reads LL from `in_ll` and the
@@ -187,27 +190,13 @@ struct IlStripArgs {
 	long ll_in_pitch;
 	float *out;
 	long out_pitch;
+	int out_step; // elements between neighbouring samples of an output row
 	float *ll;
 	long ll_pitch;
 	int lx, ly;
 	IlPhase rph[3], cph[3];
 };
 
-// Interleaved (in-place lifting) layout, multi-level: the dense per-level images of the
-// levels 1..J-1 (level j has ceil(W/2^j) x ceil(H/2^j) samples and lives on the stride-2^j
-// lattice of the W x H image).  Pitches in ELEMENTS.
-struct IlPyramid {
-	float *p[24];
-	long pitch[24];
-	int J; // levels 1 .. J-1 are valid
-};
-// compose: even rows of `out` = even rows of `base` with every lattice point replaced by
-// the sample of the deepest level (< J) that owns it.  base may equal out.  out_dense: `out`
-// holds only the even rows, packed (row q of `out` = image row 2q).
-hipError_t launch_il_compose(const float *base, long base_pitch, float *out, long out_pitch, int W, int H,
-	const IlPyramid &py, hipStream_t s, bool out_dense = false, int x_begin = 0);
-// decompose: every level's lattice gathered from `img` into its dense image, one pass
-hipError_t launch_il_decompose(const float *img, long pitch, int W, int H, const IlPyramid &py, hipStream_t s);
 
 // Up to three device-to-device rectangle copies in one launch; widths in BYTES (multiples of 4).
 struct CopyRects {

@@ -351,6 +351,32 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 		}
 
 		if constexpr (IL) {
+			if (it >= K && (!X || A + it - K >= kIlKeepTop / 2) && a.out_step > 1) {
+				// the level goes straight to the lattice it lives on in a larger image: a dword per sample.  Where a
+				// deeper level follows, the lattice points at (even row, even column) are its to fill
+				const int k = A + it - K;
+				const unsigned sb = (unsigned)a.out_step * 4;
+				const unsigned cb = (unsigned)(c0 + lane * CPT) * sb;
+				const unsigned row_bytes = (unsigned)((X ? a.W - kIlKeepRight : a.W) - 1) * sb + 4;
+				const T *r0 = out_h + (long)(2 * k) * a.h_pitch;
+				const row_rsrc_t d0 = row_rsrc(r0, row_bytes);
+#pragma unroll
+				for (int e = 0; e < CPT; e++)
+					if ((e & 1) || !a.il_ll)
+						store4_row<false>(d0, cb + e * sb, to_bits(lo[e]));
+				if (2 * k + 1 < a.H) {
+					const row_rsrc_t d1 = row_rsrc(r0 + a.h_pitch, row_bytes);
+#pragma unroll
+					for (int e = 0; e < CPT; e++)
+						store4_row<false>(d1, cb + e * sb, to_bits(hi[e]));
+				}
+				if (a.il_ll) {
+					const row_rsrc_t dl = row_rsrc(out_ll + (long)k * a.ll_pitch, (unsigned)(X ? (a.W - kIlKeepRight + 1) >> 1 : Wd) * 4);
+#pragma unroll
+					for (int e = 0; e < CPT; e += 4)
+						store8_row<false>(dl, (unsigned)(c0 + lane * CPT) * 2 + e * 2, u2{to_bits(lo[e]), to_bits(lo[e + 2])});
+				}
+			} else
 			if (it >= K && (!X || A + it - K >= kIlKeepTop / 2)) {
 				const int k = A + it - K;
 				const unsigned cb = (unsigned)(c0 + lane * CPT) * 4; // byte offset in an interleaved row

@@ -48,7 +48,7 @@ struct Ctx {
 	VolTuning vol;
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
-	int il_temporal = 0; // set per interleaved call: the forward sweeps store their even rows temporal (the compose pass reads them again)
+	int il_temporal = 0; // set per interleaved call: the forward sweep of level 0 stores its even rows temporal (in place: the copy back reads them)
 	int il_exact_borders = 1; // interleaved 9/7: 0 = skip the exact border strips (opt-in: not bit-identical in the top 8 rows / last 5 columns of a level)
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of
 	// scratch, up to `place_tries` allocations of it -- each behind a spacer that moves it into other

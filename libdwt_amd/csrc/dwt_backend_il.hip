@@ -239,10 +239,10 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 	if (!inverse)
 		*jp = J;
 	const bool alias = src.p == dst.p;
-	// out of place the even rows a forward sweep writes are read again by the compose pass: temporal stores
-	// leave them in the Infinity Cache (8192^2 J=5: 305-309 -> 296-298 us; in place, through the staging image,
-	// the same policy measured 1 % slower)
-	g.il_temporal = !alias;
+	// in place the forward result is built in the staging image and copied back at once: temporal stores leave the even
+	// rows in the Infinity Cache for that copy (8192^2 J=5, one process, alternated: 342 -> 335 us); out of place nothing
+	// reads them again: non-temporal (245-247 -> 243 us)
+	g.il_temporal = alias;
 	// everything outside the transformed region keeps the caller's values
 	const bool sparse = six < sox || siy < soy;
 	if (!alias && (J == 0 || sparse) && copy_rect(dst, 0, 0, src, 0, 0, sox, soy))

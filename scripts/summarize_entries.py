@@ -19,7 +19,7 @@ out = [f"# Round {tag[1:].lstrip('0') or '0'} — every entry of the path under 
        "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_entries -- python3 scripts/measure_entries.py", "",
        f"Raw per-kernel table: `profiles/{tag}_entries_kernel_stats.csv`.  Template arguments: "
        "`k_fwd_sweep<wavelet, columns per lane, ring rows, cache policy, interleaved>`, `k_vol_z<inverse, columns per lane, cache policy>`, "
-       "`k_vol_fwd_fused<cache policy>`.", "",
+       "`k_vol_fwd_fused<cache policy>`; interleaved layout with the border strips in the launch: `k_fwd_sweep_x<wavelet, columns per lane, ring rows, cache policy>`, `k_inv_sweep_x<wavelet, ring rows, cache policy, split even rows>`.", "",
        "| kernel | calls | avg µs | min µs | max µs | share |", "|---|---|---|---|---|---|"]
 for r in rows:
     out.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} % |")

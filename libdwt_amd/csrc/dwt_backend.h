@@ -49,6 +49,7 @@ struct Ctx {
 	int force_generic = 0;
 	int fma = 0; // opt-in: contract the float 9/7 lifting steps (not bit-identical to libdwt)
 	int il_temporal = 0; // set per interleaved call: the forward sweep of level 0 stores its even rows temporal (in place: the copy back reads them)
+	int il_inplace_shell = 1; // interleaved in-place calls: level 0 over a snapshot of the tile halos (0: through a staging image, the cross-check)
 	int il_exact_borders = 1; // interleaved 9/7: 0 = skip the exact border strips (opt-in: not bit-identical in the top 8 rows / last 5 columns of a level)
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of
 	// scratch, up to `place_tries` allocations of it -- each behind a spacer that moves it into other

@@ -1074,6 +1074,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.tune.nt_auto = value;
 	else if (!strcmp(name, "il_exact_borders"))
 		g.il_exact_borders = value;
+	else if (!strcmp(name, "il_inplace_shell"))
+		g.il_inplace_shell = value;
 	else if (!strcmp(name, "vol_ip_waves"))
 		g.vol.ip_waves = value;
 	else if (!strcmp(name, "nt"))
@@ -1129,6 +1131,8 @@ int dwt_hip_get_option(const char *name)
 		return g.tune.nt_auto;
 	if (!strcmp(name, "il_exact_borders"))
 		return g.il_exact_borders;
+	if (!strcmp(name, "il_inplace_shell"))
+		return g.il_inplace_shell;
 	if (!strcmp(name, "vol_ip_waves"))
 		return g.vol.ip_waves;
 	if (!strcmp(name, "nt"))

@@ -118,7 +118,7 @@ static int il_level_phased(Wavelet w, bool inverse, Img in, Img out, int lx, int
 // its launch exact, the dense low-pass copy the next level reads included.
 //   in_step / ll2 / out_step: see il_level
 static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, int in_step, const float *ll2, long ll2_pitch, Img out, int out_step,
-	int lx, int ly, float *ll, long ll_pitch)
+	int lx, int ly, float *ll, long ll_pitch, const IlShell *sh)
 {
 	const int K = w == kCdf53SNew ? 2 : 4;
 	IlStripArgs a;
@@ -127,6 +127,11 @@ static IlStripArgs il_strip_args(Wavelet w, bool inverse, Img in, int in_step, c
 	a.in_step = in_step;
 	a.ll_in = ll2;
 	a.ll_in_pitch = ll2_pitch;
+	a.top_in = sh ? sh->top : nullptr;
+	a.top_in_pitch = sh ? sh->top_pitch : 0;
+	a.right_in = sh ? sh->right : nullptr;
+	a.right_in_pitch = sh ? sh->right_pitch : 0;
+	a.right_x0 = sh ? sh->right_x0 : 0;
 	a.out = (float *)out.p;
 	a.out_pitch = out.sx / 4;
 	a.out_step = out_step;
@@ -154,10 +159,13 @@ static bool il_fusable(Wavelet w, bool scale_single, int lx, int ly, int dirs)
 // lattice in a larger image (sx = that lattice's row pitch), `lat_step` elements between neighbouring samples of a row.
 // Inverse: the samples at (even row, even column) come from the dense low-pass band `ll2` (the level below's result)
 // instead; forward: with `ll` (a deeper level follows) those lattice points are left for the deeper levels to fill.
+// in == out (fused sweep, lat_step 1, shapes il_shell_bytes accepts): the level runs IN PLACE over a snapshot of what its
+// tiles read of their neighbours (IlShell), built here in the staging image's memory.
 static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out, int lx, int ly, float *ll, long ll_pitch,
 	int dirs = 3, int lat_step = 1, const float *ll2 = nullptr, long ll2_pitch = 0)
 {
 	const int in_step = inverse ? lat_step : 1, out_step = inverse ? 1 : lat_step;
+	const bool in_place = in.p == out.p;
 	// dirs: bit 0 rows, bit 1 columns (fdwt2h1_* / fdwt2v1_* lift one direction only: line passes)
 	const bool phased_small = il_is_phased(w) && w != kCdf97SFma && !scale_single && (lx < 64 || ly < 64);
 	const bool fused = il_fusable(w, scale_single, lx, ly, dirs) && (((uintptr_t)in.p | (uintptr_t)out.p) % 4 == 0);
@@ -166,11 +174,26 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 	// (option il_exact_borders = 0: no strips -- the borders keep the sweep's rows-then-columns rounding, a few ulp off
 	// the reference's phase order there, far inside the 1e-5 relative tolerance; like "fma" an opt-in, never the default)
 	const bool strips = fused && il_is_phased(w) && w != kCdf97SFma && !scale_single && g.il_exact_borders;
+	if (in_place && !(fused && lat_step == 1))
+		return fail("internal: only the fused sweeps run a level in place");
 	if (fused) {
 		hipError_t e;
+		IlShell sh;
+		SweepTuning tune = g.tune;
+		if (in_place) {
+			tune.tile_pairs = il_sweep_tile_pairs(g.tune, lx, ly, inverse);
+			const size_t need = il_shell_bytes(lx, ly, tune.tile_pairs);
+			if (!need)
+				return fail("internal: this level cannot run in place");
+			if (grow(&g.stage_img, &g.stage_bytes, need))
+				return 1;
+			e = launch_il_shell((const float *)in.p, in.sx / 4, lx, ly, tune.tile_pairs, (float *)g.stage_img, &sh, g.stream);
+			if (e != hipSuccess)
+				return fail("interleaved in-place snapshot failed: %s", hipGetErrorString(e));
+		}
 		IlStripArgs sa;
 		if (strips)
-			sa = il_strip_args(w, inverse, in, in_step, ll2, ll2_pitch, out, out_step, lx, ly, ll, ll_pitch);
+			sa = il_strip_args(w, inverse, in, in_step, ll2, ll2_pitch, out, out_step, lx, ly, ll, ll_pitch, in_place ? &sh : nullptr);
 		if (!inverse) {
 			FwdLevelArgs a;
 			a.in = in.p; a.in_pitch = in.sx / 4; a.in_bstride = 0;
@@ -178,7 +201,9 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 			a.out_h = out.p; a.h_pitch = out.sx / 4; a.h_bstride = 0;
 			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1; a.il_ll = ll != nullptr ? (g.il_temporal ? 2 : 1) : 0;
 			a.out_step = out_step;
-			e = launch_fwd_level(w, a, g.tune, g.stream, strips ? &sa : nullptr);
+			if (in_place)
+				a.sh = sh;
+			e = launch_fwd_level(w, a, tune, g.stream, strips ? &sa : nullptr);
 		} else {
 			InvLevelArgs a;
 			a.in_ll = in.p; a.ll_pitch = in.sx / 4 * 2; a.ll_bstride = 0;
@@ -186,7 +211,9 @@ static int il_level(Wavelet w, bool inverse, bool scale_single, Img in, Img out,
 			a.out = out.p; a.out_pitch = out.sx / 4; a.out_bstride = 0;
 			a.W = lx; a.H = ly; a.batch = 1; a.interleaved = 1;
 			a.in_step = in_step; a.in_ll2 = ll2; a.ll2_pitch = ll2_pitch;
-			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, g.tune, g.stream, strips ? &sa : nullptr);
+			if (in_place)
+				a.sh = sh;
+			e = launch_inv_level(w == kCdf53SNew ? kCdf53S : w, a, tune, g.stream, strips ? &sa : nullptr);
 		}
 		if (e != hipSuccess)
 			return fail("interleaved sweep launch failed: %s", hipGetErrorString(e));
@@ -279,9 +306,14 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 			return fail("lattice scatter failed: %s", hipGetErrorString(e));
 		return 0;
 	};
-	// level 0 works on the caller's image; in place it detours through the staging image
+	// Level 0 works on the caller's image.  In place (round 4) it runs over a snapshot of the tiles' foreign samples
+	// (il_level, IlShell: 8192^2 14 % of the image instead of a detour of the whole image through a staging copy);
+	// shapes the snapshot does not cover, and the generic path, detour through the staging image.
+	const bool ptrs_ok = ((uintptr_t)src.p | (uintptr_t)dst.p) % 4 == 0;
+	const bool ip0 = alias && g.il_inplace_shell && ptrs_ok && il_fusable(w, scale_single, L[0].lx, L[0].ly, dirs) &&
+		il_shell_bytes(L[0].lx, L[0].ly, il_sweep_tile_pairs(g.tune, L[0].lx, L[0].ly, inverse)) != 0;
 	Img stage{nullptr, dst.sx, 4};
-	if (alias || inverse) {
+	if ((alias && !ip0) || inverse) {
 		if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * siy))
 			return 1;
 		stage.p = (char *)g.stage_img;
@@ -291,9 +323,10 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 		// Every level runs on a dense image (the level above hands its low-pass samples over densely) and writes its
 		// result where it lives: a fused level straight to its lattice in the destination (round 4: no compose pass),
 		// other levels through a dense image and a scatter.  Where a deeper level follows, the lattice points at (even
-		// row, even column) are rewritten by it later in the stream.  In place the whole result is built in the
-		// staging image -- the sweep of level 0 must not write what other tiles still read -- and copied back.
-		const Img res = alias ? stage : dst;
+		// row, even column) are rewritten by it later in the stream.  In place without the snapshot the whole result is
+		// built in the staging image -- the sweep of level 0 must not write what other tiles still read -- and copied back.
+		const bool detour = alias && !ip0;
+		const Img res = detour ? stage : dst;
 		const bool aligned = ((uintptr_t)src.p | (uintptr_t)res.p) % 4 == 0;
 		for (int j = 0; j < J; j++) {
 			const Img in = j == 0 ? src : dense(L[j].a, L[j]);
@@ -308,7 +341,7 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 				scatter(L[j].b, L[j].pitch, res.p, res.sx, 1L << j, L[j]))
 				return 1;
 		}
-		return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
+		return detour ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
 	}
 	// inverse: the coefficients are read from the source image, never modified before the last sweep has read it.
 	// A level that takes the fused sweep reads its lattice where it lives in the image, the samples at (even row, even
@@ -317,7 +350,7 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 	// generic path) get their input gathered into a dense image first.
 	const Img cin = src;
 	if (J == 1) {
-		if (!alias)
+		if (!alias || ip0)
 			return il_level(w, true, scale_single, cin, dst, L[0].lx, L[0].ly, nullptr, 0);
 		if (il_level(w, true, scale_single, dst, stage, L[0].lx, L[0].ly, nullptr, 0))
 			return 1;
@@ -342,11 +375,13 @@ static int interleaved2d(Wavelet w, bool inverse, bool scale_single, Img src, Im
 		if (il_level(w, true, scale_single, dense(L[j].a, L[j]), dense(L[j].b, L[j]), L[j].lx, L[j].ly, nullptr, 0))
 			return 1;
 	}
-	// level 0.  In place the sweep must not write what other tiles still read: it writes the staging image
+	// level 0.  In place the sweep must not write what other tiles still read: it runs over the snapshot, or writes
+	// the staging image
 	if (aligned && il_fusable(w, scale_single, L[0].lx, L[0].ly, 3)) {
-		if (il_level(w, true, scale_single, cin, alias ? stage : dst, L[0].lx, L[0].ly, nullptr, 0, 3, 1, L[1].b, L[1].pitch))
+		const bool detour = alias && !ip0;
+		if (il_level(w, true, scale_single, cin, detour ? stage : dst, L[0].lx, L[0].ly, nullptr, 0, 3, 1, L[1].b, L[1].pitch))
 			return 1;
-		return alias ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
+		return detour ? copy_rect(dst, 0, 0, stage, 0, 0, six, siy) : 0;
 	}
 	// generic path: the whole input is built in the staging image (the coefficients, the level below's result on their
 	// even-even lattice)

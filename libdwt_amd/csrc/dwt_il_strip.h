@@ -158,7 +158,11 @@ static __device__ __forceinline__ void il_strip_wave(const IlStripArgs &a, int t
 		for (int j = 0; j < kBand; j++) {
 			const int y = top ? yl + j : yl, x = top ? xl : xl + j;
 			const bool ok = here && j < ns;
-			const T *p = (a.ll_in && !((x | y) & 1)) ? a.ll_in + (long)(y >> 1) * a.ll_in_pitch + (x >> 1) : a.in + (long)y * a.in_pitch + (long)x * a.in_step;
+			// (an in-place level: the tiles may have overwritten the input by now -- the strips read their snapshots)
+			const T *p = (a.ll_in && !((x | y) & 1)) ? a.ll_in + (long)(y >> 1) * a.ll_in_pitch + (x >> 1)
+				: (top && a.top_in) ? a.top_in + (long)y * a.top_in_pitch + x
+				: (!top && a.right_in) ? a.right_in + (long)y * a.right_in_pitch + (x - a.right_x0)
+				: a.in + (long)y * a.in_pitch + (long)x * a.in_step;
 			v[j] = ok ? *p : T(0);
 		}
 	}

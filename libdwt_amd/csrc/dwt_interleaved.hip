@@ -91,6 +91,106 @@ hipError_t launch_il_phase(Wavelet w, bool inverse, const void *src, void *dst, 
 }
 
 
+// ---- interleaved layout, in-place level: the snapshot of the tiles' foreign samples (IlShell, dwt_kernels.h) ----
+// One thread per 16-byte piece; four parts in one launch: the rows around the tile-row boundaries, rows 0..13, the
+// columns around the tile-column boundaries, the last columns.  Rows as buffers: any 4-byte aligned image.
+struct IlShellGeom {
+	int W, H, tile_pairs, ntx, npr; // npr: pieces of a whole row
+	long n_rows, n_top, n_cols, n_right;
+};
+
+__global__ __launch_bounds__(256) void k_il_shell(const float *__restrict__ img, long pitch, IlShell sh, IlShellGeom g)
+{
+	long i = (long)blockIdx.x * 256 + threadIdx.x;
+	const unsigned wb = (unsigned)g.W * 4;
+	int y, col;
+	float *drow;
+	unsigned doff, dbytes;
+	if (i < g.n_rows) {
+		const int slot = (int)(i / g.npr), k = slot / 9 + 1;
+		y = 2 * k * g.tile_pairs - 5 + slot % 9;
+		col = (int)(i % g.npr) * 4;
+		drow = (float *)sh.rows + (long)slot * sh.rows_pitch;
+		doff = (unsigned)col * 4;
+		dbytes = (unsigned)sh.rows_pitch * 4;
+	} else if ((i -= g.n_rows) < g.n_top) {
+		y = (int)(i / g.npr);
+		col = (int)(i % g.npr) * 4;
+		drow = (float *)sh.top + (long)y * sh.top_pitch;
+		doff = (unsigned)col * 4;
+		dbytes = (unsigned)sh.top_pitch * 4;
+	} else if ((i -= g.n_top) < g.n_cols) {
+		const int npc = 2 * (g.ntx - 1), k = (int)(i % npc);
+		y = (int)(i / npc);
+		col = 256 * (k / 2 + 1) - 4 + 4 * (k & 1);
+		drow = (float *)sh.cols + (long)y * sh.cols_pitch;
+		doff = (unsigned)k * 16;
+		dbytes = (unsigned)sh.cols_pitch * 4;
+	} else if ((i -= g.n_cols) < g.n_right) {
+		const int k = (int)(i % (kIlShellRight / 4));
+		y = (int)(i / (kIlShellRight / 4));
+		col = sh.right_x0 + 4 * k;
+		drow = (float *)sh.right + (long)y * sh.right_pitch;
+		doff = (unsigned)k * 16;
+		dbytes = (unsigned)sh.right_pitch * 4;
+	} else {
+		return;
+	}
+	if (y >= g.H)
+		return;
+	// (a piece that straddles the row's end: zero fill -- its missing columns are never read, reflection brings
+	// them from a tile's own side)
+	const u4 v = load16_row<true>(row_rsrc(img + (long)y * pitch, wb), (unsigned)col * 4);
+	store16_row<false>(row_rsrc(drow, dbytes), doff, v);
+}
+
+static bool il_shell_shape(int W, int H, int tile_pairs, IlShellGeom *g, size_t off[5])
+{
+	if (W < 64 || H < 64 || tile_pairs < 8 || (W % 256 != 0 && W % 256 < 8))
+		return false;
+	const int Hd = (H + 1) / 2, nty = (Hd + tile_pairs - 1) / tile_pairs, ntx = (W + 255) / 256;
+	const long rp = (W + 3) / 4 * 4;
+	g->W = W; g->H = H; g->tile_pairs = tile_pairs; g->ntx = ntx; g->npr = (W + 3) / 4;
+	g->n_rows = (long)9 * (nty - 1) * g->npr;
+	g->n_top = (long)14 * g->npr;
+	g->n_cols = (long)H * 2 * (ntx - 1);
+	g->n_right = (long)H * (kIlShellRight / 4);
+	off[0] = 0;                                                  // rows
+	off[1] = off[0] + (size_t)9 * (nty - 1) * rp * 4;           // top
+	off[2] = off[1] + (size_t)14 * rp * 4;                       // cols
+	off[3] = off[2] + (size_t)H * 8 * (ntx - 1) * 4;             // right
+	off[4] = off[3] + (size_t)H * kIlShellRight * 4;             // end
+	return true;
+}
+
+size_t il_shell_bytes(int W, int H, int tile_pairs)
+{
+	IlShellGeom g;
+	size_t off[5];
+	return il_shell_shape(W, H, tile_pairs, &g, off) ? off[4] : 0;
+}
+
+hipError_t launch_il_shell(const float *img, long pitch, int W, int H, int tile_pairs, float *scratch, IlShell *sh, hipStream_t s)
+{
+	IlShellGeom g;
+	size_t off[5];
+	if (!il_shell_shape(W, H, tile_pairs, &g, off) || !aligned16(scratch))
+		return hipErrorInvalidValue;
+	const long rp = (W + 3) / 4 * 4;
+	char *b = (char *)scratch;
+	sh->rows = (const float *)(b + off[0]); sh->rows_pitch = rp;
+	sh->top = (const float *)(b + off[1]); sh->top_pitch = rp;
+	sh->cols = (const float *)(b + off[2]); sh->cols_pitch = 8L * (g.ntx - 1);
+	sh->right = (const float *)(b + off[3]); sh->right_pitch = kIlShellRight;
+	sh->right_x0 = (W - 16) & ~3;
+	sh->tile_pairs = tile_pairs;
+	const long n = g.n_rows + g.n_top + g.n_cols + g.n_right;
+	if ((n + 255) / 256 > 0x7fffffffL)
+		return hipErrorInvalidValue;
+	k_il_shell<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(img, pitch, *sh, g);
+	return hipGetLastError();
+}
+
 } // namespace dwt
 
 // ---------------------------------------------------------------------------------

@@ -26,6 +26,30 @@ struct SweepTuning {
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
 };
 
+// In-place level of the interleaved layout (input image == output image): a snapshot of what a tile reads of its
+// NEIGHBOURS' samples, taken before the level's launch (launch_il_shell).  A tile's own samples are still unwritten
+// when it reads them (its stores trail its loads); everything else it reads comes from here.  Tiles of 256 columns x
+// `tile_pairs` row pairs.
+struct IlShell {
+	const float *rows = nullptr;  // 9 rows around every boundary between tile rows: boundary k (rows 2 k tile_pairs - 5 .. + 3)
+	long rows_pitch = 0;          //   at slot 9 (k - 1) + i; whole rows
+	const float *cols = nullptr;  // per image row the 8 columns around every boundary between tile columns: boundary b
+	long cols_pitch = 0;          //   (columns 256 (b + 1) - 4 .. + 3) at 8 b
+	const float *top = nullptr;   // rows 0 .. 13, whole (input of the top border strip)
+	long top_pitch = 0;
+	const float *right = nullptr; // columns right_x0 .. W - 1 of every row (input of the right border strip)
+	long right_pitch = 0;
+	int right_x0 = 0;
+	int tile_pairs = 0;
+};
+constexpr int kIlShellRight = 20; // floats per row of IlShell::right
+// bytes of scratch a shell of a W x H level takes; 0 = this shape cannot run in place (narrow last tile column, short tiles)
+size_t il_shell_bytes(int W, int H, int tile_pairs);
+// fills the shell from the image (pitch in elements) into `scratch` (il_shell_bytes) and returns its description
+hipError_t launch_il_shell(const float *img, long pitch, int W, int H, int tile_pairs, float *scratch, IlShell *sh, hipStream_t s);
+// the tile height launch_fwd_level / launch_inv_level give an interleaved single-image level under these settings
+int il_sweep_tile_pairs(const SweepTuning &t, int W, int H, bool inverse);
+
 // One decomposition level, forward, dense frame (size_o == size_i, W,H >= 2).
 // Reads the W x H region at `in`; writes LL (ceil(W/2) x ceil(H/2)) to `out_ll` and
 // the three detail subbands at their Mallat offsets relative to `out_h`:
@@ -42,6 +66,7 @@ struct FwdLevelArgs {
 	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path / in-place lifting layout)
 	int il_ll = 0;       // interleaved only: also write the LL samples densely to out_ll
 	int temporal = 0;    // 1: every store temporal (the outputs are read again at once: staging of an in-place call)
+	IlShell sh;          // interleaved only, in place (in == out_h, out_step 1): the neighbours' samples come from this snapshot
 	int out_step = 1;    // interleaved only: elements between neighbouring samples of an output row -- 2^j when the level
 	                     // is written straight to the lattice it lives on in a larger image (h_pitch: that lattice's row
 	                     // pitch); with il_ll the samples at (even row, even column) are then left to the deeper levels
@@ -60,6 +85,7 @@ struct InvLevelArgs {
 	int W, H, batch;
 	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
 	// interleaved only -- a level read straight from the lattice it lives on in a larger image:
+	IlShell sh;                   // in place (in_ll == out, in_step 1): the neighbours' samples come from this snapshot
 	int in_step = 1;              // elements between neighbouring samples of a source row (2^j on the lattice of level j)
 	const void *in_ll2 = nullptr; // dense low-pass band (ceil(W/2) x ceil(H/2), the level below's result): replaces the
 	long ll2_pitch = 0;           // samples at (even row, even column) of the source
@@ -188,6 +214,11 @@ struct IlStripArgs {
 	int in_step;         // elements between neighbouring samples of an input row (a level on its lattice in a larger image)
 	const float *ll_in;  // or null: dense low-pass band that replaces the input samples at (even row, even column)
 	long ll_in_pitch;
+	const float *top_in;   // or null (in-place level): rows 0 .. 13 of the input, IlShell::top
+	long top_in_pitch;
+	const float *right_in; // or null (in-place level): columns right_x0 .. of every input row, IlShell::right
+	long right_in_pitch;
+	int right_x0;
 	float *out;
 	long out_pitch;
 	int out_step; // elements between neighbouring samples of an output row

@@ -201,6 +201,14 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 
 	int islot = 0, rslot = 0; // ring slots of the next rows to fill / to consume
 	const bool tall = a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
+	// In place (interleaved layout, a.sh): this tile's own rows and columns come from the image -- its stores trail its
+	// loads --, everything else from the snapshot: a neighbour's row as a whole from the row shell, a neighbour's
+	// column of an own row from the column shell (offset in that shell's row, or -1: an own column)
+	[[maybe_unused]] const bool shl = IL && a.sh.rows != nullptr;
+	[[maybe_unused]] int halo_sh = -1;
+	if (IL && shl)
+		halo_sh = (halo_col >= c0 - 4 && halo_col < c0) ? 8 * (tx - 1) + (halo_col - (c0 - 4))
+			: (halo_col >= c0 + TW && halo_col < c0 + TW + 4) ? 8 * tx + 4 + (halo_col - (c0 + TW)) : -1;
 	auto issue = [&](int it) {
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
@@ -208,6 +216,27 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 			const int r = tall ? reflect1(ri, a.H) : reflect(ri, a.H);
 			char *lrow = ring + (size_t)(islot + rr) * RS * 4;
 			const T *grow = in + (long)r * a.in_pitch;
+			[[maybe_unused]] const T *hsrc = grow + halo_col; // lanes 0..7: the halo column
+			// (in place) an own row read from the image: its last 8 columns -- the border strip waves of the launch may
+			// have written theirs already -- come from the snapshot `rgt + column`
+			[[maybe_unused]] const T *rgt = nullptr;
+			if (IL && shl) {
+				if (r < 2 * A)
+					grow = (const T *)a.sh.rows + (long)(9 * (ty - 1) + r - (2 * A - 5)) * a.sh.rows_pitch, hsrc = grow + halo_col;
+				else if (r >= 2 * B)
+					grow = (const T *)a.sh.rows + (long)(9 * ty + r - (2 * B - 5)) * a.sh.rows_pitch, hsrc = grow + halo_col;
+				else if (r < kIlKeepTop) // the strips' rows: the snapshot of rows 0..13
+					grow = (const T *)a.sh.top + (long)r * a.sh.top_pitch, hsrc = grow + halo_col;
+				else {
+					rgt = (const T *)a.sh.right + (long)r * a.sh.right_pitch - a.sh.right_x0;
+					if (halo_sh >= 0)
+						hsrc = (const T *)a.sh.cols + (long)r * a.sh.cols_pitch + halo_sh;
+					else if (halo_col >= a.W - kIlKeepRight)
+						hsrc = rgt + halo_col;
+				}
+			}
+			[[maybe_unused]] const T *esrc = (IL && rgt) ? rgt + edge_col : grow + edge_col; // lanes < n_edge: a reflected column
+			const bool fix_right = IL && rgt && c0 + TW > a.W - kIlKeepRight; // this tile holds the last 8 columns
 			const row_rsrc_t rs = row_rsrc(grow, (unsigned)a.W * 4);
 			// The 8 rows around a tile's upper edge are read twice: by this tile now, in its warm-up, and by the
 			// tile above at the end of its march.  The first read is TEMPORAL whatever the policy, so that the
@@ -217,19 +246,23 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 #pragma unroll
 				for (int i = 0; i < CPT / 4; i++)
 					dma16_row<0>(rs, (unsigned)(c0 + i * 256 + lane * 4) * 4, lrow + i * 1024);
+				if (fix_right && lane < kIlKeepRight) // (lands after the row's own DMA: loads return in order)
+					dma4<0>(rgt + (a.W - kIlKeepRight + lane), lrow + (a.W - kIlKeepRight - c0) * 4);
 				if (lane < n_edge)
-					dma4<0>(grow + edge_col, lrow + (a.W - c0) * 4);
+					dma4<0>(esrc, lrow + (a.W - c0) * 4);
 				if (lane < 8)
-					dma4<0>(grow + halo_col, lrow + TW * 4);
+					dma4<0>(IL ? hsrc : grow + halo_col, lrow + TW * 4);
 			} else {
 #pragma unroll
 				for (int i = 0; i < CPT / 4; i++)
 					dma16_row<kLdAux>(rs, (unsigned)(c0 + i * 256 + lane * 4) * 4, lrow + i * 1024);
+				if (fix_right && lane < kIlKeepRight)
+					dma4<0>(rgt + (a.W - kIlKeepRight + lane), lrow + (a.W - kIlKeepRight - c0) * 4);
 				if (lane < n_edge)
-					dma4<kLdAux>(grow + edge_col, lrow + (a.W - c0) * 4);
+					dma4<kLdAux>(esrc, lrow + (a.W - c0) * 4);
 				// (the halo columns are the x-neighbour tiles' own lines, read by them at about the same time: temporal)
 				if (lane < 8)
-					dma4<0>(grow + halo_col, lrow + TW * 4);
+					dma4<0>(IL ? hsrc : grow + halo_col, lrow + TW * 4);
 			}
 		}
 		islot = islot + 2 >= kRing ? 0 : islot + 2;
@@ -545,6 +578,17 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	}
 	const int step = IL ? a.in_step : 1;
 	const unsigned src_row_bytes = ((unsigned)(a.W - 1) * step + 1) * 4; // a source row up to its last sample
+	// in place (a.sh, see the forward sweep): offsets of the lane's halo column in the column shell's row, or -1
+	[[maybe_unused]] const bool shl = IL && a.sh.rows != nullptr;
+	[[maybe_unused]] int halo_shI = -1, halo_shH = -1;
+	if (IL && shl) {
+		// (columns further out are fetched by the split rows' halo lanes but feed no output: wherever they come from)
+		auto in_shell = [&](int col) {
+			return (col >= c0 - 4 && col < c0) ? 8 * (tx - 1) + (col - (c0 - 4)) : (col >= c0 + TW && col < c0 + TW + 4) ? 8 * tx + 4 + (col - (c0 + TW)) : -1;
+		};
+		halo_shI = in_shell(halo_colI);
+		halo_shH = in_shell(2 * halo_col + 1); // (split even rows: the high-pass half's halo, an odd image column)
+	}
 	auto issue = [&](int it) {
 		const int p = p0 + it;
 		if constexpr (IL) {
@@ -555,6 +599,23 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				// even rows come from in_ll, odd rows from in_h (reflection keeps the parity): the
 				// two may be different buffers
 				const T *grow = (r & 1) ? in_h + (long)(r >> 1) * a.h_pitch : in_ll + (long)(r >> 1) * a.ll_pitch;
+				// own row of an in-place level read from the image: its foreign columns come from `crow`, its last 8
+				// columns (the border strip waves may have written theirs already) from `rgt + column`
+				[[maybe_unused]] const T *crow = nullptr, *rgt = nullptr;
+				if (shl) {
+					if (r < 2 * A)
+						grow = (const T *)a.sh.rows + (long)(9 * (ty - 1) + r - (2 * A - 5)) * a.sh.rows_pitch;
+					else if (r >= 2 * B)
+						grow = (const T *)a.sh.rows + (long)(9 * ty + r - (2 * B - 5)) * a.sh.rows_pitch;
+					else if (r < kIlKeepTop) // the strips' rows: the snapshot of rows 0..13
+						grow = (const T *)a.sh.top + (long)r * a.sh.top_pitch;
+					else {
+						crow = (const T *)a.sh.cols + (long)r * a.sh.cols_pitch;
+						rgt = (const T *)a.sh.right + (long)r * a.sh.right_pitch - a.sh.right_x0;
+					}
+				}
+				const int wr = a.W - kIlKeepRight; // first of the last 8 columns
+				const bool fix_right = rgt && c0 + TW > wr;
 				if (SP && rr == 0) {
 					// even row, split: LDS row as for Mallat rows, [L main M | H main M | L halo 8 | H halo 8]
 					const T *gl = (const T *)a.in_ll2 + (long)(r >> 1) * a.ll2_pitch;
@@ -564,14 +625,23 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 #pragma unroll
 					for (int i = 0; i < 2; i++)
 						dma4_row<kLdAux>(rh, (unsigned)(2 * (cl0 + 64 * i + lane) + 1) * step * 4, lrow + M * 4 + i * 256);
+					if (fix_right) {
+						// the odd columns among the last 8, from the snapshot (lands after the strided loads above)
+						const int fo = wr | 1;
+						if (lane < 4 && fo + 2 * lane < a.W)
+							dma4<kLdAux>(rgt + fo + 2 * lane, lrow + M * 4 + ((fo - c0) >> 1) * 4);
+					}
 					if (edge_tile) {
 						if (lane < 2 && nL + lane < cl0 + M)
 							dma4<kLdAux>(gl + edge_col, lrow + (nL - cl0) * 4);
 						if (lane >= 2 && lane < 4 && nH + (lane & 1) < cl0 + M)
-							dma4<kLdAux>(grow + (long)(2 * edge_col + 1) * step, lrow + M * 4 + (nH - cl0) * 4 - 8);
+							dma4<kLdAux>((rgt ? rgt : grow) + (long)(2 * edge_col + 1) * step, lrow + M * 4 + (nH - cl0) * 4 - 8);
 					}
-					if (lane < 16)
-						dma4<kLdAux>(halo_is_h ? grow + (long)(2 * halo_col + 1) * step : gl + halo_col, lrow + 2 * M * 4);
+					if (lane < 16) {
+						const int hcol = 2 * halo_col + 1;
+						dma4<kLdAux>(!halo_is_h ? gl + halo_col : (crow && halo_shH >= 0) ? crow + halo_shH : (rgt && hcol >= wr) ? rgt + hcol : grow + (long)hcol * step,
+							lrow + 2 * M * 4);
+					}
 					continue;
 				}
 				if (step == 1) {
@@ -585,10 +655,12 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 					for (int i = 0; i < CPT; i++)
 						dma4_row<kLdAux>(rs, (unsigned)(c0 + 64 * i + lane) * step * 4, lrow + i * 256);
 				}
+				if (fix_right && lane < kIlKeepRight)
+					dma4<kLdAux>(rgt + (wr + lane), lrow + (wr - c0) * 4);
 				if (lane < min(4, c0 + TW - a.W))
-					dma4<kLdAux>(grow + (long)reflect(a.W + min(lane, 3), a.W) * step, lrow + (a.W - c0) * 4);
+					dma4<kLdAux>((rgt ? rgt : grow) + (long)reflect(a.W + min(lane, 3), a.W) * step, lrow + (a.W - c0) * 4);
 				if (lane < 8)
-					dma4<kLdAux>(grow + (long)halo_colI * step, lrow + TW * 4);
+					dma4<kLdAux>((crow && halo_shI >= 0) ? crow + halo_shI : (rgt && halo_colI >= wr) ? rgt + halo_colI : grow + (long)halo_colI * step, lrow + TW * 4);
 			}
 			return;
 		}
@@ -977,6 +1049,8 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
+	if (a.sh.rows && (!a.interleaved || a.batch != 1 || a.out_step != 1 || g.tile_pairs != a.sh.tile_pairs))
+		return hipErrorInvalidValue; // the snapshot of an in-place level was taken for other tiles
 	if (a.interleaved) {
 		// 3-D path: float 9/7 only; always 4 columns per lane so that each row leaves the
 		// wave as ONE contiguous 16 B/lane store (two strided stores per row cost 40 %)
@@ -1076,6 +1150,8 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 		grid = dim3(((g.ntx + waves - 1) / waves) * nty, a.batch);
 	else
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
+	if (a.sh.rows && (!a.interleaved || a.batch != 1 || a.in_step != 1 || g.tile_pairs != a.sh.tile_pairs))
+		return hipErrorInvalidValue; // the snapshot of an in-place level was taken for other tiles
 	if (a.interleaved) {
 		if (a.in_step < 1 || (a.in_ll2 && (a.ll2_pitch < (a.W + 1) / 2)))
 			return hipErrorInvalidValue;
@@ -1099,6 +1175,11 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	if (strip)
 		return hipErrorInvalidValue;
 	return cpt == 8 ? inv_pick<W, 8>(a, g, grid, waves, ring, s) : inv_pick<W, 4>(a, g, grid, waves, ring, s);
+}
+
+int il_sweep_tile_pairs(const SweepTuning &t, int W, int H, bool inverse)
+{
+	return pick_tile_pairs(t, W, H, 4, 1, inverse);
 }
 
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip)

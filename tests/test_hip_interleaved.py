@@ -420,6 +420,41 @@ def test_border_strips_in_the_sweeps_launch(dwt, oracle, shape, levels):
     src.free()
 
 
+@pytest.mark.parametrize("shape,levels", [((8192, 8192), 5), ((4096, 4096), 1), ((3000, 5000), 3), ((6000, 2056), 2), ((2500, 2311), 4), ((4100, 2568), 2)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("kind", ["cdf97", "cdf53"])
+def test_in_place_level_over_the_halo_snapshot(dwt, kind, shape, levels):
+    """In-place calls on images of more than 4 M samples: level 0 runs IN PLACE over a snapshot of what its tiles read
+    of their neighbours (and of what the border strip waves of the same launch write) instead of through a staging
+    copy of the image.  Same bits as the out-of-place call and as the staging path (il_inplace_shell = 0), forward
+    and inverse, several times over (a missed dependency would show up as a race)."""
+    h, w = shape
+    rng = np.random.default_rng(h + 7 * w + levels)
+    img = rng.random((h, w), dtype=np.float32)
+    src = dwt.DeviceImage(h, w).upload(img)
+    ref_f = dwt.DeviceImage(h, w).upload(np.zeros((h, w), np.float32))
+    ref_i = dwt.DeviceImage(h, w).upload(np.zeros((h, w), np.float32))
+    name = kind + "_s"
+    dwt.transform2d_interleaved(name, 0, 0, src.ptr, ref_f.ptr, w * 4, 4, w, h, None, None, levels)
+    dwt.transform2d_interleaved(name, 1, 0, ref_f.ptr, ref_i.ptr, w * 4, 4, w, h, None, None, levels)
+    want_f, want_i = ref_f.download(np.float32), ref_i.download(np.float32)
+    work = dwt.DeviceImage(h, w)
+    for shell in (1, 1, 0, 1):
+        dwt.set_option("il_inplace_shell", shell)
+        try:
+            work.upload(img)
+            dwt.transform2d_interleaved(name, 0, 0, work.ptr, work.ptr, w * 4, 4, w, h, None, None, levels)
+            got_f = work.download(np.float32)
+            dwt.transform2d_interleaved(name, 1, 0, work.ptr, work.ptr, w * 4, 4, w, h, None, None, levels)
+            got_i = work.download(np.float32)
+        finally:
+            dwt.set_option("il_inplace_shell", 1)
+        assert np.array_equal(bits(got_f), bits(want_f)), ("forward", shell)
+        assert np.array_equal(bits(got_i), bits(want_i)), ("inverse", shell)
+    for d in (src, ref_f, ref_i, work):
+        d.free()
+
+
 @pytest.mark.parametrize("shape,levels", [((1500, 1000), 3), ((2048, 2048), 5), ((640, 2000), 2)], ids=lambda v: str(v))
 def test_fast_borders_option_within_tolerance(dwt, oracle, shape, levels):
     """Option il_exact_borders = 0 (opt-in, like "fma"): the interleaved 9/7 without the exact border strips --

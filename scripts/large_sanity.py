@@ -26,8 +26,9 @@ for (h, w, J, wav, dt) in [(32768, 32768, 5, "cdf97_s", torch.float32), (64, 1 <
     print(f"{h}x{w} {wav} J={j}/{j2}: fused == line passes: {same}; round-trip max err {err:.3e}", flush=True)
     del a, f, g, r
 
-# interleaved layout: extreme shapes, fused sweeps vs the generic path.  5/3: both finish rows
-# first -> same bits; 9/7: the generic path follows the reference's phase order -> <= 1e-5
+# interleaved layout: extreme shapes, the fused sweeps (levels on their lattices, border strips in the launches) vs the
+# generic path (the reference's phase order pass by pass), bit for bit both ways; in place (level 0 over the halo
+# snapshot) vs out of place
 for (h, w, J) in [(16384, 16384, 6), (64, 1 << 20, 3), (1 << 20, 64, 3), (3001, 70001, -1)]:
     a = torch.rand((h, w), device="cuda")
     f = torch.empty_like(a); g = torch.empty_like(a)
@@ -37,15 +38,23 @@ for (h, w, J) in [(16384, 16384, 6), (64, 1 << 20, 3), (1 << 20, 64, 3), (3001, 
         dwt.set_option("generic", 1)
         dwt.transform2d_interleaved(wav, 0, 0, a, g, w * 4, 4, w, h, None, None, J)
         dwt.set_option("generic", 0)
-        if wav == "cdf53_s":
-            ok = ok and torch.equal(f, g)
-        else:
-            ok = ok and (f - g).abs().max().item() <= 1e-5 * g.abs().max().item()
-    dwt.transform2d_interleaved("cdf97_s", 1, 0, f, f, w * 4, 4, w, h, None, None, j)
+        ok = ok and torch.equal(f, g)
+        g.copy_(a)
+        dwt.transform2d_interleaved(wav, 0, 0, g, g, w * 4, 4, w, h, None, None, J)
+        ok = ok and torch.equal(f, g)
+    # (f, g: the 9/7 coefficients) inverse: out of place, generic, in place
+    r0 = torch.empty_like(a)
+    dwt.transform2d_interleaved("cdf97_s", 1, 0, f, r0, w * 4, 4, w, h, None, None, j)
+    dwt.set_option("generic", 1)
+    r1 = torch.empty_like(a)
+    dwt.transform2d_interleaved("cdf97_s", 1, 0, f, r1, w * 4, 4, w, h, None, None, j)
+    dwt.set_option("generic", 0)
+    dwt.transform2d_interleaved("cdf97_s", 1, 0, g, g, w * 4, 4, w, h, None, None, j)
     torch.cuda.synchronize()
-    err = (f - a).abs().max().item()
-    print(f"{h}x{w} interleaved cdf53_s/cdf97_s J={j}: fused == line passes: {ok}; round-trip max err {err:.3e}", flush=True)
-    del a, f, g
+    ok_i = torch.equal(r0, r1) and torch.equal(r0, g)
+    err = (r0 - a).abs().max().item()
+    print(f"{h}x{w} interleaved cdf53_s/cdf97_s J={j}: forward fused == line passes == in place: {ok}; inverse alike: {ok_i}; round-trip max err {err:.3e}", flush=True)
+    del a, f, g, r0, r1
 # 3-D out of place: the fused one-pass level vs the two-pass path, bit for bit
 for (nz, ny, nx, lv) in [(1024, 1024, 1024, 3), (301, 1000, 1111, 2), (2050, 64, 4096, 1)]:
     a = torch.rand((nz, ny, nx), device="cuda")

@@ -1318,8 +1318,16 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	if (upload(src, A.p))
 		return 1;
 	// B receives the result.  It starts as a copy of what the destination holds so
-	// that every element the reference leaves untouched keeps its value.
-	if (s2) {
+	// that every element the reference leaves untouched keeps its value -- unless the call
+	// writes every element of the frame anyway (a dense frame, at least one level: no second
+	// trip over PCIe for the out-of-place entries)
+	const int so_min = sox < soy ? sox : soy, so_max = sox > soy ? sox : soy;
+	const int j_lim = ceil_log2(decompose_one ? so_max : so_min);
+	const int j_eff = (*j < 0 || *j > j_lim) ? j_lim : *j;
+	const bool writes_all = ge.dense() && j_eff >= 1;
+	if (s2 && writes_all) {
+		// (nothing to preserve)
+	} else if (s2) {
 		if (upload(dst, B.p))
 			return 1;
 	} else {

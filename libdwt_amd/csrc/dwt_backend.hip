@@ -990,6 +990,17 @@ void dwt_hip_finish(void)
 			hipEventDestroy(e);
 		e = nullptr;
 	}
+	for (auto &row : g.pipe_ev)
+		for (hipEvent_t &e : row) {
+			if (e)
+				hipEventDestroy(e);
+			e = nullptr;
+		}
+	if (g.up)
+		hipStreamDestroy(g.up);
+	if (g.down)
+		hipStreamDestroy(g.down);
+	g.up = g.down = nullptr;
 	if (g.pin)
 		hipHostFree(g.pin);
 	g.pin = nullptr;
@@ -1076,6 +1087,8 @@ int dwt_hip_set_option(const char *name, int value)
 		g.il_exact_borders = value;
 	else if (!strcmp(name, "il_inplace_shell"))
 		g.il_inplace_shell = value;
+	else if (!strcmp(name, "host_pipeline"))
+		g.host_pipeline = value;
 	else if (!strcmp(name, "vol_ip_waves"))
 		g.vol.ip_waves = value;
 	else if (!strcmp(name, "nt"))
@@ -1133,6 +1146,8 @@ int dwt_hip_get_option(const char *name)
 		return g.il_exact_borders;
 	if (!strcmp(name, "il_inplace_shell"))
 		return g.il_inplace_shell;
+	if (!strcmp(name, "host_pipeline"))
+		return g.host_pipeline;
 	if (!strcmp(name, "vol_ip_waves"))
 		return g.vol.ip_waves;
 	if (!strcmp(name, "nt"))
@@ -1277,6 +1292,238 @@ int dwt_hip_prof_read(double *ms, int *launches)
 	return 0;
 }
 
+// ---- host-pointer forward call on a large image: level 0 band by band under the transfers ----
+// A host-pointer call is bound by PCIe: 8192^2 floats take 4.7 ms each way against 0.15 ms of kernels.  The two
+// directions are independent links, so the call is cut into bands of 512 row pairs: while band g+1 is still on its
+// way up, band g's tiles of level 0 run (FwdLevelArgs::pair_lo / pair_hi) and their detail rows -- three quarters of
+// the result -- travel down.  The caller's image is pinned in place for the call (hipHostRegister, 0.6 ms for
+// 256 MiB the first time): every copy is an asynchronous DMA from / to it, no repacking on the CPU.  In place the
+// rows Hd + [A, B) that band [A, B)'s LH / HH rows will overwrite are uploaded together with the band itself, so
+// that no output lands on input that has not been read.  The deeper levels run on the complete low-pass band at the
+// end and its quadrant follows.  Returns 0 done, 1 error, -1 not applicable (the caller takes the plain path).
+static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int stride_x, int W, int H, int *jp, int decompose_one)
+{
+	constexpr int kBand = 512; // row pairs per band: a multiple of every tile height
+	const Geom ge{W, H, W, H};
+	const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, Hh = H / 2;
+	const int n_bands = (Hd + kBand - 1) / kBand;
+	if (!g.host_pipeline || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
+		stride_x % 4 || stride_x < W * 4)
+		return -1;
+	const int j_lim = ceil_log2(decompose_one ? (W > H ? W : H) : (W < H ? W : H));
+	const int J = (*jp < 0 || *jp > j_lim) ? j_lim : *jp;
+	if (J < 1)
+		return -1;
+	const long pitch = align_up((long)W * 4, 256);
+	const size_t span = (size_t)(H - 1) * stride_x + (size_t)W * 4;
+	// pin the caller's image(s) where they are
+	const bool two = src != dst;
+	if (hipHostRegister((void *)src, span, hipHostRegisterDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		return -1;
+	}
+	if (two && hipHostRegister(dst, span, hipHostRegisterDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		hipHostUnregister((void *)src);
+		return -1;
+	}
+	auto body = [&]() -> int {
+		if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * H) || grow(&g.host_b, &g.host_b_bytes, (size_t)pitch * H))
+			return 1;
+		// level 1 follows level 0 band by band too (its details are three quarters of the low-pass quadrant): scratch
+		// for both low-pass bands
+		const int Wd1 = (Wd + 1) / 2, Hd1 = (Hd + 1) / 2, Hh1 = Hd / 2;
+		const long llp = align_up((long)Wd, 64), llp1 = align_up((long)Wd1, 64);
+		const bool lvl1 = J > 1 && Wd >= 2 && Hd >= 2;
+		if (J > 1 && grow(&g.stage_img, &g.stage_bytes, ((size_t)llp * Hd + (size_t)llp1 * Hd1) * 4))
+			return 1;
+		float *const ll0 = (float *)g.stage_img, *const ll1 = ll0 + (size_t)llp * Hd;
+		int done1 = 0; // level 1: row pairs computed so far
+		if (!g.up) {
+			HIP_TRY(hipStreamCreateWithFlags(&g.up, hipStreamNonBlocking));
+			HIP_TRY(hipStreamCreateWithFlags(&g.down, hipStreamNonBlocking));
+		}
+		for (auto &row : g.pipe_ev)
+			for (int k = 0; k < 16; k++)
+				if (!row[k])
+					HIP_TRY(hipEventCreateWithFlags(&row[k], hipEventDisableTiming));
+		char *A = (char *)g.host_a, *B = (char *)g.host_b;
+		// everything queued on the caller's stream so far comes first
+		HIP_TRY(hipEventRecord(g.pipe_ev[0][15], g.stream));
+		HIP_TRY(hipStreamWaitEvent(g.up, g.pipe_ev[0][15], 0));
+		HIP_TRY(hipStreamWaitEvent(g.down, g.pipe_ev[0][15], 0));
+		// One copy per band and direction.  (Measured: cutting them into pieces of 2-16 MiB, or plain instead of 2-D
+		// copies where the rows lie back to back, made the call slower or erratic -- 7.8-10.8 ms against 7.5.  The two
+		// directions overlap only in part on this platform: 256 MiB each way at once from pinned memory take 9.4 ms as two
+		// copies, 5.9 ms as 32 + 32; scripts/probes/r04_duplex_probe.py.)
+		auto up_rows = [&](int r0, int r1) -> int {
+			if (r1 > r0)
+				HIP_TRY(hipMemcpy2DAsync(A + (long)r0 * pitch, pitch, (const char *)src + (long)r0 * stride_x, stride_x, (size_t)W * 4, r1 - r0,
+					hipMemcpyHostToDevice, g.up));
+			return 0;
+		};
+		auto down_rect = [&](int r0, int r1, int c0, int c1) -> int {
+			if (r1 > r0 && c1 > c0)
+				HIP_TRY(hipMemcpy2DAsync((char *)dst + (long)r0 * stride_x + (long)c0 * 4, stride_x, B + (long)r0 * pitch + (long)c0 * 4, pitch,
+					(size_t)(c1 - c0) * 4, r1 - r0, hipMemcpyDeviceToHost, g.down));
+			return 0;
+		};
+		// (DWT_HIP_PIPE_VERBOSE: when each stream finishes, from the call's start)
+		static const bool verbose = getenv("DWT_HIP_PIPE_VERBOSE") != nullptr;
+		hipEvent_t tv[4] = {};
+		if (verbose) {
+			for (auto &e : tv)
+				hipEventCreate(&e);
+			hipEventRecord(tv[0], g.up);
+		}
+		int top_end = 0, bot_end = Hd; // rows [0, top_end) and [Hd, bot_end) are on their way up
+		// In place a result may only come down onto rows that have gone up: rectangles wait here until they may
+		// (level 1's LH / HH rows lie ahead of the upload front for a few bands)
+		struct Pending { int r0, r1, c0, c1; };
+		Pending pend[64];
+		int n_pend = 0;
+		auto flush = [&](bool all) -> int {
+			int keep = 0;
+			for (int i = 0; i < n_pend; i++) {
+				const Pending q = pend[i];
+				const bool up = all || q.r1 <= top_end || (q.r0 >= Hd && q.r1 <= bot_end) || (top_end >= Hd && q.r1 <= (top_end > bot_end ? top_end : bot_end));
+				if (!up)
+					pend[keep++] = q;
+				else if (down_rect(q.r0, q.r1, q.c0, q.c1))
+					return 1;
+			}
+			n_pend = keep;
+			return 0;
+		};
+		auto later = [&](int r0, int r1, int c0, int c1) {
+			if (r1 > r0 && c1 > c0 && n_pend < 64)
+				pend[n_pend++] = Pending{r0, r1, c0, c1};
+		};
+		for (int b = 0; b < n_bands; b++) {
+			const int P0 = b * kBand, P1 = (b + 1) * kBand < Hd ? (b + 1) * kBand : Hd;
+			// the band's input rows (its tiles read up to row 2 P1 + 2) ...
+			int want = P1 == Hd ? H : (2 * P1 + 3 < H ? 2 * P1 + 3 : H);
+			if (top_end >= Hd && top_end < bot_end)
+				top_end = bot_end; // (those went up as some band's bottom rows)
+			if (want > top_end) {
+				// rows [Hd, bot_end) inside the range are up already
+				if (top_end < Hd && want > Hd) {
+					if (up_rows(top_end, Hd) || up_rows(bot_end > Hd ? bot_end : Hd, want > bot_end ? want : bot_end))
+						return 1;
+					bot_end = want > bot_end ? want : bot_end;
+				} else if (up_rows(top_end, want)) {
+					return 1;
+				}
+				top_end = want;
+				if (top_end >= Hd && top_end > bot_end)
+					bot_end = top_end;
+			}
+			// ... and the rows its LH / HH rows will land on
+			const int b1 = Hd + P1 < H ? Hd + P1 : H;
+			if (b1 > bot_end && b1 > top_end) {
+				const int from = bot_end > top_end ? bot_end : top_end;
+				if (up_rows(from > Hd ? from : Hd, b1))
+					return 1;
+				bot_end = b1;
+			}
+			HIP_TRY(hipEventRecord(g.pipe_ev[0][b], g.up));
+			HIP_TRY(hipStreamWaitEvent(g.stream, g.pipe_ev[0][b], 0));
+			FwdLevelArgs a;
+			a.in = A; a.in_pitch = pitch / 4; a.in_bstride = 0;
+			a.out_h = B; a.h_pitch = pitch / 4; a.h_bstride = 0;
+			if (J > 1) {
+				a.out_ll = ll0; a.ll_pitch = llp; a.ll_bstride = 0;
+			} else {
+				a.out_ll = B; a.ll_pitch = pitch / 4; a.ll_bstride = 0;
+			}
+			a.W = W; a.H = H; a.batch = 1;
+			a.pair_lo = P0; a.pair_hi = P1 == Hd ? Hd + kBand : P1;
+			hipError_t e = launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
+			if (e != hipSuccess)
+				return fail("forward level 0 (band %d) launch failed: %s", b, hipGetErrorString(e));
+			// level 1 on the rows of the low-pass band that are complete now (its tiles read up to row 2 hi + 2)
+			int lo1 = done1, hi1 = done1;
+			if (lvl1) {
+				hi1 = P1 == Hd ? Hd1 : ((P1 - 3) / 2) / 64 * 64;
+				if (hi1 > lo1) {
+					FwdLevelArgs a1;
+					a1.in = ll0; a1.in_pitch = llp; a1.in_bstride = 0;
+					a1.out_h = B; a1.h_pitch = pitch / 4; a1.h_bstride = 0;
+					if (J > 2) {
+						a1.out_ll = ll1; a1.ll_pitch = llp1; a1.ll_bstride = 0;
+					} else {
+						a1.out_ll = B; a1.ll_pitch = pitch / 4; a1.ll_bstride = 0;
+					}
+					a1.W = Wd; a1.H = Hd; a1.batch = 1;
+					a1.pair_lo = lo1; a1.pair_hi = hi1 == Hd1 ? Hd1 + kBand : hi1;
+					e = launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a1, g.tune, g.stream);
+					if (e != hipSuccess)
+						return fail("forward level 1 (band %d) launch failed: %s", b, hipGetErrorString(e));
+					done1 = hi1;
+				} else {
+					hi1 = lo1;
+				}
+			}
+			HIP_TRY(hipEventRecord(g.pipe_ev[1][b], g.stream));
+			HIP_TRY(hipStreamWaitEvent(g.down, g.pipe_ev[1][b], 0));
+			// the band's detail rows: HL beside the low-pass quadrant, LH | HH below it; level 1's alike inside the quadrant
+			later(P0, P1, Wd, W);
+			later(Hd + P0, Hd + (P1 < Hh ? P1 : Hh), 0, W);
+			if (hi1 > lo1) {
+				later(lo1, hi1 < Hd1 ? hi1 : Hd1, Wd1, Wd);
+				later(Hd1 + lo1, Hd1 + (hi1 < Hh1 ? hi1 : Hh1), 0, Wd);
+			}
+			// (the download stream has just been made to wait for this band's uploads and kernels)
+			if (flush(false))
+				return 1;
+		}
+		if (verbose) {
+			hipEventRecord(tv[1], g.up);
+			hipEventRecord(tv[2], g.down);
+		}
+		// the deeper levels on the complete low-pass band of the last banded level, then that band's quadrant
+		int qw = Wd, qh = Hd;
+		if (lvl1) {
+			qw = Wd1; qh = Hd1;
+			if (J > 2) {
+				int j2 = J - 2;
+				const Geom gl{Wd1, Hd1, Wd1, Hd1};
+				if (forward2d(w, Img{(char *)ll1, llp1 * 4, 4}, Img{B, pitch, 4}, gl, &j2, decompose_one, 0, 1, 0, 0))
+					return 1;
+			}
+		}
+		HIP_TRY(hipEventRecord(g.pipe_ev[2][0], g.stream));
+		HIP_TRY(hipStreamWaitEvent(g.down, g.pipe_ev[2][0], 0));
+		if (flush(true) || down_rect(0, qh, 0, qw))
+			return 1;
+		if (verbose)
+			hipEventRecord(tv[3], g.down);
+		HIP_TRY(hipStreamSynchronize(g.down));
+		HIP_TRY(hipStreamSynchronize(g.up));
+		if (verbose) {
+			float up = 0, dd = 0, all = 0;
+			hipEventElapsedTime(&up, tv[0], tv[1]);
+			hipEventElapsedTime(&dd, tv[0], tv[2]);
+			hipEventElapsedTime(&all, tv[0], tv[3]);
+			fprintf(stderr, "host pipeline: uploads done at %.2f ms, detail downloads at %.2f ms, all at %.2f ms\n", up, dd, all);
+			for (auto &e : tv)
+				hipEventDestroy(e);
+		}
+		*jp = J;
+		return 0;
+	};
+	const int rc = body();
+	if (rc) {
+		hipStreamSynchronize(g.up);
+		hipStreamSynchronize(g.down);
+		hipStreamSynchronize(g.stream);
+	}
+	hipHostUnregister((void *)src);
+	if (two)
+		hipHostUnregister(dst);
+	return rc;
+}
+
 int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, int stride_x, int stride_y,
 	int sox, int soy, int six, int siy, int *j, int decompose_one, int zero_padding)
 {
@@ -1307,6 +1554,11 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	}
 
 	// ---- host pointers: stage the whole outer frame through HBM ----
+	if (!inverse && ge.dense() && stride_y == es && es == 4) {
+		const int rc = host_forward_pipelined(w, src, dst, stride_x, sox, soy, j, decompose_one);
+		if (rc >= 0)
+			return rc;
+	}
 	const long pitch = align_up((long)sox * es, 256);
 	const size_t bytes = (size_t)pitch * soy;
 	if (grow(&g.host_a, &g.host_a_bytes, bytes) || grow(&g.host_b, &g.host_b_bytes, bytes))

@@ -66,6 +66,8 @@ struct FwdLevelArgs {
 	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path / in-place lifting layout)
 	int il_ll = 0;       // interleaved only: also write the LL samples densely to out_ll
 	int temporal = 0;    // 1: every store temporal (the outputs are read again at once: staging of an in-place call)
+	int pair_lo = 0, pair_hi = 0; // pair_hi > 0: only the tiles that start at a row pair in [pair_lo, pair_hi) -- multiples of 64 --
+	                              // run (a level computed band by band while its input is still arriving over PCIe)
 	IlShell sh;          // interleaved only, in place (in == out_h, out_step 1): the neighbours' samples come from this snapshot
 	int out_step = 1;    // interleaved only: elements between neighbouring samples of an output row -- 2^j when the level
 	                     // is written straight to the lattice it lives on in a larger image (h_pitch: that lattice's row

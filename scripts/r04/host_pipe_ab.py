@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Host-pointer forward call, 8192^2 float 9/7, 5 levels: pipelined under the transfers against upload / transform / download."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import libdwt_amd as dwt
+dwt.dwt_util_init()
+n, J = 8192, 5
+rng = np.random.default_rng(1)
+img = rng.random((n, n), dtype=np.float32)
+ref = None
+for rnd in range(3):
+    for pipe in (0, 1):
+        dwt.set_option("host_pipeline", pipe)
+        a = img.copy(); b = np.empty_like(a)
+        ts = []
+        for rep in range(4):
+            a[:] = img
+            t0 = time.perf_counter(); dwt.dwt_cdf97_2f_s(a, n * 4, 4, n, n, n, n, J); t1 = time.perf_counter()
+            ts.append(t1 - t0)
+        t2 = []
+        for rep in range(4):
+            t0 = time.perf_counter(); dwt.dwt_cdf97_2f_s2(img, b, n * 4, 4, n, n, n, n, J); t1 = time.perf_counter()
+            t2.append(t1 - t0)
+        if ref is None:
+            ref = b.copy()
+        ok = np.array_equal(a, ref) and np.array_equal(b, ref)
+        print(f"host_pipeline={pipe}: results as the plain path's: {ok}; in place {min(ts)*1e3:.2f} ms (median {sorted(ts)[len(ts)//2]*1e3:.2f}), out of place {min(t2)*1e3:.2f} ms; same result: {np.array_equal(a, b)}", flush=True)

@@ -1085,3 +1085,36 @@ def test_randomised_soak():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress.py"), "20", "7"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, (out.stdout[-2000:], out.stderr[-1000:])
+
+
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
+@pytest.mark.parametrize("shape,levels", [((4096, 8192), 5), ((8192, 8192), 5), ((5001, 4097), 3), ((8192, 2100), 1), ((2049, 8200), -1), ((16390, 1100), 2)],
+                         ids=lambda v: str(v))
+def test_host_pointer_call_pipelined_under_the_transfers(dwt, wname, shape, levels):
+    """Host-pointer forward calls on images of 64 MiB and more run level 0 band by band while the image is still crossing
+    PCIe (the caller's memory pinned in place, uploads, kernels and downloads on three streams).  Same bits as the plain
+    upload / transform / download path (host_pipeline = 0), in place and out of place, odd sizes and padded rows."""
+    h, w = shape
+    ff, fi, dt = NAMES[wname]
+    rng = np.random.default_rng(h + w)
+    pitch = w + 24  # elements: rows with padding the call must neither read as image nor touch
+    base = np.full((h, pitch), 7, dtype=dt)
+    img = rng.integers(-30000, 30000, size=(h, w)).astype(dt) if dt == np.int32 else rng.random((h, w), dtype=np.float32)
+    base[:, :w] = img
+    outs = []
+    for pipe in (0, 1, 1):
+        dwt.set_option("host_pipeline", pipe)
+        try:
+            a = base.copy()
+            j1 = getattr(dwt, "dwt_" + ff)(a, pitch * 4, 4, w, h, w, h, levels)  # in place
+            src = base.copy()
+            b = np.full((h, pitch), 9, dtype=dt)
+            j2 = dwt._fwd(dwt.WAVELET_ID[wname], src, b, pitch * 4, 4, w, h, w, h, levels, 0, 0, "forward, out of place")
+        finally:
+            dwt.set_option("host_pipeline", 1)
+        assert j1 == j2 and np.array_equal(src, base)
+        assert np.all(a[:, w:] == 7) and np.all(b[:, w:] == 9)
+        assert np.array_equal(bits(a[:, :w]), bits(b[:, :w]))
+        outs.append((j1, a[:, :w].copy()))
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert np.array_equal(bits(outs[0][1]), bits(outs[1][1])) and np.array_equal(bits(outs[0][1]), bits(outs[2][1]))

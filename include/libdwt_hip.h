@@ -101,7 +101,7 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * non-temporal too, 15 = 7 with the neighbour taps by wavefront shifts instead of LDS reads), "nt_auto"
  * (1 = policy 3 by itself when a launch's LL bands exceed 1 GiB), "fma" (1 = contracted lifting steps:
  * NOT the reference's rounding, within 1e-5), "fused_d" (0 = double precision through the exact line passes),
- * "host_pipeline" (1 = forward host-pointer calls on images of 64 MiB and more run band by band under their own
+ * "host_pipeline" (1 = host-pointer calls on images of 64 MiB and more run band by band under their own
  * PCIe transfers, the caller's memory pinned in place for the call; 0 = upload, transform, download),
  * "il_inplace_shell" (1 = in-place calls of the interleaved entries run level 0 in place over a snapshot of the tile
  * halos; 0 = through a staging copy of the image, the cross-check),

@@ -1524,6 +1524,121 @@ static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int str
 	return rc;
 }
 
+// The inverse likewise: the low-pass quadrant goes up first and the levels >= 1 run on it while the detail bands
+// follow; band [P0, P1) of level 0 needs the HL rows up to P1 + 2 and the LH | HH rows up to Hd + P1 + 2, and its
+// result -- rows [2 P0, 2 P1) of the image -- comes down at once.  In place that result overwrites coefficient rows:
+// every row below 2 P1 goes up before it (a band's uploads run ahead of its own needs by that much).
+static int host_inverse_pipelined(Wavelet w, const void *src, void *dst, int stride_x, int W, int H, int j_max, int decompose_one)
+{
+	constexpr int kBand = 512;
+	const Geom ge{W, H, W, H};
+	const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, Hh = H / 2;
+	const int n_bands = (Hd + kBand - 1) / kBand;
+	if (!g.host_pipeline || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
+		stride_x % 4 || stride_x < W * 4)
+		return -1;
+	int J = ceil_log2(decompose_one ? (W > H ? W : H) : (W < H ? W : H));
+	if (j_max >= 0 && j_max < J)
+		J = j_max;
+	if (J < 1)
+		return -1;
+	const long pitch = align_up((long)W * 4, 256);
+	const size_t span = (size_t)(H - 1) * stride_x + (size_t)W * 4;
+	const bool two = src != dst;
+	if (hipHostRegister((void *)src, span, hipHostRegisterDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		return -1;
+	}
+	if (two && hipHostRegister(dst, span, hipHostRegisterDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		hipHostUnregister((void *)src);
+		return -1;
+	}
+	auto body = [&]() -> int {
+		if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * H) || grow(&g.host_b, &g.host_b_bytes, (size_t)pitch * H))
+			return 1;
+		const long llp = align_up((long)Wd, 64);
+		if (J > 1 && grow(&g.stage_img, &g.stage_bytes, (size_t)llp * Hd * 4))
+			return 1;
+		if (!g.up) {
+			HIP_TRY(hipStreamCreateWithFlags(&g.up, hipStreamNonBlocking));
+			HIP_TRY(hipStreamCreateWithFlags(&g.down, hipStreamNonBlocking));
+		}
+		for (auto &row : g.pipe_ev)
+			for (int k = 0; k < 16; k++)
+				if (!row[k])
+					HIP_TRY(hipEventCreateWithFlags(&row[k], hipEventDisableTiming));
+		char *A = (char *)g.host_a, *B = (char *)g.host_b;
+		HIP_TRY(hipEventRecord(g.pipe_ev[0][15], g.stream));
+		HIP_TRY(hipStreamWaitEvent(g.up, g.pipe_ev[0][15], 0));
+		HIP_TRY(hipStreamWaitEvent(g.down, g.pipe_ev[0][15], 0));
+		auto up_rect = [&](int r0, int r1, int c0, int c1) -> int {
+			if (r1 > r0 && c1 > c0)
+				HIP_TRY(hipMemcpy2DAsync(A + (long)r0 * pitch + (long)c0 * 4, pitch, (const char *)src + (long)r0 * stride_x + (long)c0 * 4, stride_x,
+					(size_t)(c1 - c0) * 4, r1 - r0, hipMemcpyHostToDevice, g.up));
+			return 0;
+		};
+		// the low-pass quadrant first; the levels >= 1 rebuild the level-0 low-pass band from it
+		if (up_rect(0, Hd, 0, Wd))
+			return 1;
+		HIP_TRY(hipEventRecord(g.pipe_ev[2][1], g.up));
+		HIP_TRY(hipStreamWaitEvent(g.stream, g.pipe_ev[2][1], 0));
+		const void *ll = A;
+		long ll_pitch = pitch / 4;
+		if (J > 1) {
+			const Geom gl{Wd, Hd, Wd, Hd};
+			if (inverse2d(w, Img{A, pitch, 4}, Img{(char *)g.stage_img, llp * 4, 4}, gl, J - 1, decompose_one, 0, 1, 0, 0))
+				return 1;
+			ll = g.stage_img;
+			ll_pitch = llp;
+		}
+		int top_done = 0, bot_done = Hd; // HL rows [0, top_done) and image rows [Hd, bot_done) are on their way up
+		for (int b = 0; b < n_bands; b++) {
+			const int P0 = b * kBand, P1 = (b + 1) * kBand < Hd ? (b + 1) * kBand : Hd;
+			const bool last = P1 == Hd;
+			// what the band reads, and (in place) every row its result will overwrite
+			int top_need = last ? Hd : (2 * P1 < Hd ? 2 * P1 : Hd);
+			if (!last && top_need < P1 + 2)
+				top_need = P1 + 2 < Hd ? P1 + 2 : Hd;
+			int bot_need = last ? H : Hd + (P1 + 2 < Hh ? P1 + 2 : Hh);
+			if (!last && 2 * P1 > bot_need)
+				bot_need = 2 * P1 < H ? 2 * P1 : H;
+			if (up_rect(top_done, top_need, Wd, W) || up_rect(bot_done, bot_need, 0, W))
+				return 1;
+			top_done = top_need > top_done ? top_need : top_done;
+			bot_done = bot_need > bot_done ? bot_need : bot_done;
+			HIP_TRY(hipEventRecord(g.pipe_ev[0][b], g.up));
+			HIP_TRY(hipStreamWaitEvent(g.stream, g.pipe_ev[0][b], 0));
+			InvLevelArgs a;
+			a.W = W; a.H = H; a.batch = 1;
+			a.in_h = A; a.h_pitch = pitch / 4; a.h_bstride = 0;
+			a.in_ll = ll; a.ll_pitch = ll_pitch; a.ll_bstride = 0;
+			a.out = B; a.out_pitch = pitch / 4; a.out_bstride = 0;
+			a.pair_lo = P0; a.pair_hi = last ? Hd + kBand : P1;
+			hipError_t e = launch_inv_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, g.tune, g.stream);
+			if (e != hipSuccess)
+				return fail("inverse level 1 (band %d) launch failed: %s", b, hipGetErrorString(e));
+			HIP_TRY(hipEventRecord(g.pipe_ev[1][b], g.stream));
+			HIP_TRY(hipStreamWaitEvent(g.down, g.pipe_ev[1][b], 0));
+			const int r0 = 2 * P0, r1 = last ? H : 2 * P1;
+			HIP_TRY(hipMemcpy2DAsync((char *)dst + (long)r0 * stride_x, stride_x, B + (long)r0 * pitch, pitch, (size_t)W * 4, r1 - r0, hipMemcpyDeviceToHost, g.down));
+		}
+		HIP_TRY(hipStreamSynchronize(g.down));
+		HIP_TRY(hipStreamSynchronize(g.up));
+		return 0;
+	};
+	const int rc = body();
+	if (rc) {
+		hipStreamSynchronize(g.up);
+		hipStreamSynchronize(g.down);
+		hipStreamSynchronize(g.stream);
+	}
+	hipHostUnregister((void *)src);
+	if (two)
+		hipHostUnregister(dst);
+	return rc;
+}
+
 int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, int stride_x, int stride_y,
 	int sox, int soy, int six, int siy, int *j, int decompose_one, int zero_padding)
 {
@@ -1554,8 +1669,9 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	}
 
 	// ---- host pointers: stage the whole outer frame through HBM ----
-	if (!inverse && ge.dense() && stride_y == es && es == 4) {
-		const int rc = host_forward_pipelined(w, src, dst, stride_x, sox, soy, j, decompose_one);
+	if (ge.dense() && stride_y == es && es == 4) {
+		const int rc = inverse ? host_inverse_pipelined(w, src, dst, stride_x, sox, soy, *j, decompose_one)
+		                       : host_forward_pipelined(w, src, dst, stride_x, sox, soy, j, decompose_one);
 		if (rc >= 0)
 			return rc;
 	}

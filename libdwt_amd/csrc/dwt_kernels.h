@@ -86,6 +86,7 @@ struct InvLevelArgs {
 	long out_pitch, out_bstride;
 	int W, H, batch;
 	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
+	int pair_lo = 0, pair_hi = 0; // pair_hi > 0: only the tiles that start at a row pair in [pair_lo, pair_hi) run (see FwdLevelArgs)
 	// interleaved only -- a level read straight from the lattice it lives on in a larger image:
 	IlShell sh;                   // in place (in_ll == out, in_step 1): the neighbours' samples come from this snapshot
 	int in_step = 1;              // elements between neighbouring samples of a source row (2^j on the lattice of level j)

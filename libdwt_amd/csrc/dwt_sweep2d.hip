@@ -545,6 +545,8 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	const int A = ty * g.tile_pairs;
 	if (A >= Hd || tx >= g.ntx)
 		return;
+	if (a.pair_hi > 0 && (A < a.pair_lo || A >= a.pair_hi))
+		return; // this launch computes a band of the level only
 	const int B = min(A + g.tile_pairs, Hd);
 	const int c0 = tx * TW;
 	const int cl0 = c0 >> 1;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host-pointer forward call, 8192^2 float 9/7, 5 levels: pipelined under the transfers against upload / transform / download."""
+"""Host-pointer calls, 8192^2 float 9/7, 5 levels, forward and inverse: pipelined under the transfers against upload / transform / download."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -26,4 +26,9 @@ for rnd in range(3):
         if ref is None:
             ref = b.copy()
         ok = np.array_equal(a, ref) and np.array_equal(b, ref)
-        print(f"host_pipeline={pipe}: results as the plain path's: {ok}; in place {min(ts)*1e3:.2f} ms (median {sorted(ts)[len(ts)//2]*1e3:.2f}), out of place {min(t2)*1e3:.2f} ms; same result: {np.array_equal(a, b)}", flush=True)
+        ti = []
+        for rep in range(4):
+            a[:] = ref
+            t0 = time.perf_counter(); dwt.dwt_cdf97_2i_s(a, n * 4, 4, n, n, n, n, J); t1 = time.perf_counter()
+            ti.append(t1 - t0)
+        print(f"host_pipeline={pipe}: inverse in place {min(ti)*1e3:.2f} ms, round trip error {np.abs(a - img).max():.2e}; forward results as the plain path's: {ok}; in place {min(ts)*1e3:.2f} ms (median {sorted(ts)[len(ts)//2]*1e3:.2f}), out of place {min(t2)*1e3:.2f} ms", flush=True)

@@ -1091,9 +1091,10 @@ def test_randomised_soak():
 @pytest.mark.parametrize("shape,levels", [((4096, 8192), 5), ((8192, 8192), 5), ((5001, 4097), 3), ((8192, 2100), 1), ((2049, 8200), -1), ((16390, 1100), 2)],
                          ids=lambda v: str(v))
 def test_host_pointer_call_pipelined_under_the_transfers(dwt, wname, shape, levels):
-    """Host-pointer forward calls on images of 64 MiB and more run level 0 band by band while the image is still crossing
-    PCIe (the caller's memory pinned in place, uploads, kernels and downloads on three streams).  Same bits as the plain
-    upload / transform / download path (host_pipeline = 0), in place and out of place, odd sizes and padded rows."""
+    """Host-pointer calls on images of 64 MiB and more run level 0 (forward: and level 1) band by band while the image is
+    still crossing PCIe (the caller's memory pinned in place, uploads, kernels and downloads on three streams).  Same bits
+    as the plain upload / transform / download path (host_pipeline = 0), forward and inverse, in place and out of place,
+    odd sizes and padded rows; the round trip closes."""
     h, w = shape
     ff, fi, dt = NAMES[wname]
     rng = np.random.default_rng(h + w)
@@ -1115,6 +1116,21 @@ def test_host_pointer_call_pipelined_under_the_transfers(dwt, wname, shape, leve
         assert j1 == j2 and np.array_equal(src, base)
         assert np.all(a[:, w:] == 7) and np.all(b[:, w:] == 9)
         assert np.array_equal(bits(a[:, :w]), bits(b[:, :w]))
-        outs.append((j1, a[:, :w].copy()))
+        fwd = a[:, :w].copy()
+        # and back: in place on `a`, out of place from `b` into `c`
+        dwt.set_option("host_pipeline", pipe)
+        try:
+            getattr(dwt, "dwt_" + fi)(a, pitch * 4, 4, w, h, w, h, j1)
+            keep = b.copy()
+            c = np.full((h, pitch), 5, dtype=dt)
+            dwt._inv(dwt.WAVELET_ID[wname], b, c, pitch * 4, 4, w, h, w, h, j1, 0, 0, "inverse, out of place")
+        finally:
+            dwt.set_option("host_pipeline", 1)
+        assert np.array_equal(b, keep) and np.all(a[:, w:] == 7) and np.all(c[:, w:] == 5)
+        assert np.array_equal(bits(a[:, :w]), bits(c[:, :w]))
+        outs.append((j1, fwd, a[:, :w].copy()))
     assert outs[0][0] == outs[1][0] == outs[2][0]
-    assert np.array_equal(bits(outs[0][1]), bits(outs[1][1])) and np.array_equal(bits(outs[0][1]), bits(outs[2][1]))
+    for k in (1, 2):
+        assert np.array_equal(bits(outs[0][k]), bits(outs[1][k])) and np.array_equal(bits(outs[0][k]), bits(outs[2][k]))
+    rec = outs[0][2]
+    assert np.array_equal(rec, img) if dt == np.int32 else np.abs(rec - img).max() < 1e-4

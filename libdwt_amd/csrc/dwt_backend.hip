@@ -1292,6 +1292,34 @@ int dwt_hip_prof_read(double *ms, int *launches)
 	return 0;
 }
 
+// Pins a caller's host range for the duration of a call, unless it is pinned memory already (hipHostMalloc, or
+// registered by the caller): ok() says whether asynchronous copies may address it.
+struct HostPin {
+	void *p = nullptr;
+	bool ours = false, good = false;
+	HostPin(const void *ptr, size_t bytes)
+	{
+		hipPointerAttribute_t at;
+		if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeHost) {
+			good = true; // the caller's own pinned memory
+			return;
+		}
+		(void)hipGetLastError();
+		if (hipHostRegister((void *)ptr, bytes, hipHostRegisterDefault) == hipSuccess) {
+			p = (void *)ptr;
+			ours = good = true;
+		} else {
+			(void)hipGetLastError();
+		}
+	}
+	~HostPin()
+	{
+		if (ours)
+			hipHostUnregister(p);
+	}
+	bool ok() const { return good; }
+};
+
 // ---- host-pointer forward call on a large image: level 0 band by band under the transfers ----
 // A host-pointer call is bound by PCIe: 8192^2 floats take 4.7 ms each way against 0.15 ms of kernels.  The two
 // directions are independent links, so the call is cut into bands of 512 row pairs: while band g+1 is still on its
@@ -1318,15 +1346,12 @@ static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int str
 	const size_t span = (size_t)(H - 1) * stride_x + (size_t)W * 4;
 	// pin the caller's image(s) where they are
 	const bool two = src != dst;
-	if (hipHostRegister((void *)src, span, hipHostRegisterDefault) != hipSuccess) {
-		(void)hipGetLastError();
+	HostPin pin_src(src, span);
+	if (!pin_src.ok())
 		return -1;
-	}
-	if (two && hipHostRegister(dst, span, hipHostRegisterDefault) != hipSuccess) {
-		(void)hipGetLastError();
-		hipHostUnregister((void *)src);
+	HostPin pin_dst(two ? dst : src, two ? span : 0);
+	if (two && !pin_dst.ok())
 		return -1;
-	}
 	auto body = [&]() -> int {
 		if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * H) || grow(&g.host_b, &g.host_b_bytes, (size_t)pitch * H))
 			return 1;
@@ -1518,9 +1543,6 @@ static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int str
 		hipStreamSynchronize(g.down);
 		hipStreamSynchronize(g.stream);
 	}
-	hipHostUnregister((void *)src);
-	if (two)
-		hipHostUnregister(dst);
 	return rc;
 }
 
@@ -1545,15 +1567,12 @@ static int host_inverse_pipelined(Wavelet w, const void *src, void *dst, int str
 	const long pitch = align_up((long)W * 4, 256);
 	const size_t span = (size_t)(H - 1) * stride_x + (size_t)W * 4;
 	const bool two = src != dst;
-	if (hipHostRegister((void *)src, span, hipHostRegisterDefault) != hipSuccess) {
-		(void)hipGetLastError();
+	HostPin pin_src(src, span);
+	if (!pin_src.ok())
 		return -1;
-	}
-	if (two && hipHostRegister(dst, span, hipHostRegisterDefault) != hipSuccess) {
-		(void)hipGetLastError();
-		hipHostUnregister((void *)src);
+	HostPin pin_dst(two ? dst : src, two ? span : 0);
+	if (two && !pin_dst.ok())
 		return -1;
-	}
 	auto body = [&]() -> int {
 		if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * H) || grow(&g.host_b, &g.host_b_bytes, (size_t)pitch * H))
 			return 1;
@@ -1633,9 +1652,6 @@ static int host_inverse_pipelined(Wavelet w, const void *src, void *dst, int str
 		hipStreamSynchronize(g.down);
 		hipStreamSynchronize(g.stream);
 	}
-	hipHostUnregister((void *)src);
-	if (two)
-		hipHostUnregister(dst);
 	return rc;
 }
 

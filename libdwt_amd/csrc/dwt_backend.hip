@@ -1335,7 +1335,8 @@ static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int str
 	const Geom ge{W, H, W, H};
 	const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, Hh = H / 2;
 	const int n_bands = (Hd + kBand - 1) / kBand;
-	if (!g.host_pipeline || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
+	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here)
+	if (!g.host_pipeline || decompose_one || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
 		stride_x % 4 || stride_x < W * 4)
 		return -1;
 	const int j_lim = ceil_log2(decompose_one ? (W > H ? W : H) : (W < H ? W : H));
@@ -1556,7 +1557,8 @@ static int host_inverse_pipelined(Wavelet w, const void *src, void *dst, int str
 	const Geom ge{W, H, W, H};
 	const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, Hh = H / 2;
 	const int n_bands = (Hd + kBand - 1) / kBand;
-	if (!g.host_pipeline || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
+	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here)
+	if (!g.host_pipeline || decompose_one || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
 		stride_x % 4 || stride_x < W * 4)
 		return -1;
 	int J = ceil_log2(decompose_one ? (W > H ? W : H) : (W < H ? W : H));

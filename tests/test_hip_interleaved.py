@@ -484,3 +484,41 @@ def test_fast_borders_option_within_tolerance(dwt, oracle, shape, levels):
         dwt.set_option("il_exact_borders", 1)
     src.free()
     dst.free()
+
+
+@pytest.mark.parametrize("opts", [{"waves": 1}, {"waves": 2}, {"ring": 16}, {"tile_pairs": 8}, {"tile_pairs": 16, "waves": 3}, {"tile_pairs": 64, "ring": 16},
+                                  {"xcd_swizzle": 0}], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_interleaved_bits_do_not_depend_on_the_sweep_settings(dwt, opts):
+    """The strip waves share their launch with the tile waves (workgroups of `waves` waves), the in-place snapshot is cut
+    for the tile height in force: whatever the sweep settings, 9/7 interleaved calls -- out of place and in place, forward
+    and inverse -- give the bits of the reference's phase order pass by pass (accel 1)."""
+    h, w, levels = 2200, 2312, 3
+    rng = np.random.default_rng(17)
+    img = rng.random((h, w), dtype=np.float32)
+    src = dwt.DeviceImage(h, w).upload(img)
+    f = dwt.DeviceImage(h, w); r = dwt.DeviceImage(h, w); ip = dwt.DeviceImage(h, w)
+    dwt.dwt_util_set_accel(1)
+    try:
+        dwt.transform2d_interleaved("cdf97_s", 0, 0, src.ptr, f.ptr, w * 4, 4, w, h, None, None, levels)
+        dwt.transform2d_interleaved("cdf97_s", 1, 0, f.ptr, r.ptr, w * 4, 4, w, h, None, None, levels)
+    finally:
+        dwt.dwt_util_set_accel(0)
+    want_f, want_r = f.download(np.float32), r.download(np.float32)
+    try:
+        for k, v in opts.items():
+            dwt.set_option(k, v)
+        dwt.transform2d_interleaved("cdf97_s", 0, 0, src.ptr, f.ptr, w * 4, 4, w, h, None, None, levels)
+        dwt.transform2d_interleaved("cdf97_s", 1, 0, f.ptr, r.ptr, w * 4, 4, w, h, None, None, levels)
+        got_f, got_r = f.download(np.float32), r.download(np.float32)
+        ip.upload(img)
+        dwt.transform2d_interleaved("cdf97_s", 0, 0, ip.ptr, ip.ptr, w * 4, 4, w, h, None, None, levels)
+        got_fi = ip.download(np.float32)
+        dwt.transform2d_interleaved("cdf97_s", 1, 0, ip.ptr, ip.ptr, w * 4, 4, w, h, None, None, levels)
+        got_ri = ip.download(np.float32)
+    finally:
+        for k in opts:
+            dwt.set_option(k, {"waves": 4, "ring": 0, "tile_pairs": 0, "xcd_swizzle": 1}[k])
+    for got, want, what in ((got_f, want_f, "forward"), (got_fi, want_f, "forward in place"), (got_r, want_r, "inverse"), (got_ri, want_r, "inverse in place")):
+        assert np.array_equal(bits(got), bits(want)), what
+    for d in (src, f, r, ip):
+        d.free()

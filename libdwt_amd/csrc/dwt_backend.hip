@@ -1331,9 +1331,13 @@ struct HostPin {
 // end and its quadrant follows.  Returns 0 done, 1 error, -1 not applicable (the caller takes the plain path).
 static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int stride_x, int W, int H, int *jp, int decompose_one)
 {
-	constexpr int kBand = 512; // row pairs per band: a multiple of every tile height
 	const Geom ge{W, H, W, H};
 	const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, Hh = H / 2;
+	// row pairs per band: a multiple of every tile height, at most 16 bands, 256 pairs where that is enough (the first
+	// band's upload and the last band's download overlap with nothing; 8192^2 in bands of 256 / 512 / 1024 pairs: forward
+	// 7.42 / 7.44 / 7.95 ms, inverse 7.17 / 7.31 / 7.79)
+	static const int band_opt = getenv("DWT_HIP_PIPE_BAND") ? atoi(getenv("DWT_HIP_PIPE_BAND")) : 256;
+	const int kBand = std::max(band_opt, ((Hd + 15) / 16 + 63) / 64 * 64);
 	const int n_bands = (Hd + kBand - 1) / kBand;
 	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here)
 	if (!g.host_pipeline || decompose_one || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
@@ -1553,9 +1557,10 @@ static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int str
 // every row below 2 P1 goes up before it (a band's uploads run ahead of its own needs by that much).
 static int host_inverse_pipelined(Wavelet w, const void *src, void *dst, int stride_x, int W, int H, int j_max, int decompose_one)
 {
-	constexpr int kBand = 512;
 	const Geom ge{W, H, W, H};
 	const int Hd = (H + 1) / 2, Wd = (W + 1) / 2, Hh = H / 2;
+	static const int band_opt = getenv("DWT_HIP_PIPE_BAND") ? atoi(getenv("DWT_HIP_PIPE_BAND")) : 256;
+	const int kBand = std::max(band_opt, ((Hd + 15) / 16 + 63) / 64 * 64); // (see host_forward_pipelined)
 	const int n_bands = (Hd + kBand - 1) / kBand;
 	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here)
 	if (!g.host_pipeline || decompose_one || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||

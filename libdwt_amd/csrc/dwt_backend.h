@@ -129,6 +129,7 @@ int zero_rect(Img img, long x, long y, long w, long h);
 // host images <-> dense device images (any byte strides; awkward pitches go through a pinned buffer)
 int host_upload(const void *hp, int stride_x, int stride_y, int es, int w, int h, void *dp, long pitch);
 int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, const void *dp, long pitch);
+int host_volume_xfer(bool to_device, void *dev, size_t d_sy, size_t d_sz, void *host, size_t h_sy, size_t h_sz, int nx, int ny, int nz);
 // one exact out-of-place 1-D pass over the lines of a frame (in == out is staged)
 int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_w, int frame_h, int n_lines, int N, int hoff);
 // placement (dwt_backend.hip / dwt_placement.hip)

@@ -327,15 +327,9 @@ static int vol_xfer(bool to_device, void *dev, size_t d_sy, size_t d_sz, void *h
 {
 	const size_t row = (size_t)nx * 4;
 	const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
-	const bool fast = h_sy % 64 == 0 && h_sz % 16 == 0 && (uintptr_t)host % 16 == 0;
-	if (!fast) {
-		for (int z = 0; z < nz; z++) {
-			char *hp = (char *)host + (size_t)z * h_sz, *dp = (char *)dev + (size_t)z * d_sz;
-			if (to_device ? host_upload(hp, (int)h_sy, 4, 4, nx, ny, dp, (long)d_sy) : host_download(hp, (int)h_sy, 4, 4, nx, ny, dp, (long)d_sy))
-				return 1;
-		}
-		return 0;
-	}
+	const bool fast = h_sy % 4 == 0 && h_sz % 4 == 0 && (uintptr_t)host % 4 == 0; // (see host_pitch_is_fast)
+	if (!fast)
+		return host_volume_xfer(to_device, dev, d_sy, d_sz, host, h_sy, h_sz, nx, ny, nz);
 	void *dst = to_device ? dev : host;
 	const void *src = to_device ? host : dev;
 	const size_t dst_sy = to_device ? d_sy : h_sy, dst_sz = to_device ? d_sz : h_sz, src_sy = to_device ? h_sy : d_sy, src_sz = to_device ? h_sz : d_sz;

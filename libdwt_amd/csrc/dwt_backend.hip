@@ -1402,8 +1402,9 @@ static int host_forward_pipelined(Wavelet w, const void *src, void *dst, int str
 	static const int band_opt = getenv("DWT_HIP_PIPE_BAND") ? atoi(getenv("DWT_HIP_PIPE_BAND")) : 256;
 	const int kBand = std::max(band_opt, ((Hd + 15) / 16 + 63) / 64 * 64);
 	const int n_bands = (Hd + kBand - 1) / kBand;
-	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here)
-	if (!g.host_pipeline || decompose_one || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
+	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here;
+	// a tile height set by hand must divide the band: tiles do not straddle bands)
+	if (!g.host_pipeline || decompose_one || kBand % 64 || (g.tune.tile_pairs > 0 && kBand % g.tune.tile_pairs) || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
 		stride_x % 4 || stride_x < W * 4)
 		return -1;
 	const int j_lim = ceil_log2(decompose_one ? (W > H ? W : H) : (W < H ? W : H));
@@ -1625,8 +1626,9 @@ static int host_inverse_pipelined(Wavelet w, const void *src, void *dst, int str
 	static const int band_opt = getenv("DWT_HIP_PIPE_BAND") ? atoi(getenv("DWT_HIP_PIPE_BAND")) : 256;
 	const int kBand = std::max(band_opt, ((Hd + 15) / 16 + 63) / 64 * 64); // (see host_forward_pipelined)
 	const int n_bands = (Hd + kBand - 1) / kBand;
-	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here)
-	if (!g.host_pipeline || decompose_one || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
+	// (decompose_one: the levels past the shorter side's last run on the generic passes, which borrow the buffers used here;
+	// a tile height set by hand must divide the band: tiles do not straddle bands)
+	if (!g.host_pipeline || decompose_one || kBand % 64 || (g.tune.tile_pairs > 0 && kBand % g.tune.tile_pairs) || elem_size(w) != 4 || !level_fused_ok(ge, 0) || (size_t)W * H * 4 < ((size_t)64 << 20) || n_bands < 2 || n_bands > 16 ||
 		stride_x % 4 || stride_x < W * 4)
 		return -1;
 	int J = ceil_log2(decompose_one ? (W > H ? W : H) : (W < H ? W : H));

@@ -552,7 +552,9 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	// smaller launches prefer more resident waves.
 	SweepTuning tt = t;
 	if (tt.ring != 8 && tt.ring != 16)
-		tt.ring = (g.ntx >= waves && (long)g.ntx * nty * a.batch >= 3072) ? 16 : 8;
+		// (one image in the interleaved layout: from 512 tiles on -- 8192^2 J=5 250-252 -> 247.5-248 us, the Mallat entry
+		// loses 5 us of 148 with that threshold; measured in one process, alternated)
+		tt.ring = (g.ntx >= waves && (long)g.ntx * nty * a.batch >= ((a.interleaved && a.batch == 1) ? 512 : 3072)) ? 16 : 8;
 	// deep ring: the waves of a workgroup take side-by-side tiles (+ 7 %); shallow: stacked tiles
 	g.wave_horiz = tt.ring == 16;
 	dim3 grid;

@@ -23,7 +23,7 @@ out = [f"# Round {tag[1:].lstrip('0') or '0'} — every entry of the path under 
        "| kernel | calls | avg µs | min µs | max µs | share |", "|---|---|---|---|---|---|"]
 for r in rows:
     out.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} % |")
-out += ["", "Wall-clock per entry in the same (profiled) process (the host-pointer call, whose copies run on three streams, is slower under the profiler: `profiles/" + tag + "_entries_wallclock_unprofiled.txt` has the plain run):", "", "```"] + [l.rstrip() for l in open(log) if " us " in l] + ["```", ""]
+out += ["", "Wall-clock per entry in the same (profiled) process (`profiles/" + tag + "_entries_wallclock_unprofiled.txt` has the plain run):", "", "```"] + [l.rstrip() for l in open(log) if " us " in l] + ["```", ""]
 notes = os.path.join(ROOT, "profiles", f"{tag}_entries_notes.md")  # hand-written additions kept across regenerations
 if os.path.exists(notes):
     out += [open(notes).read().rstrip(), ""]

@@ -116,7 +116,10 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * results + scatter passes), "vol_nt", "vol_rows" (8 / 6), "vol_tile_pairs", "vol_swizzle",
  * "vol_ip_waves" (0 = auto / 4 / 8 waves per workgroup of the one-pass levels: tiles of 32 or 64 rows),
  * "vol_inplace_fused" (in-place calls: 1 = one fused pass per level in place over a snapshot of the tile
- * halos, forward and inverse; 0 = two passes per level). */
+ * halos, forward and inverse; 0 = two passes per level).
+ * Environment (diagnostics only, read once): DWT_HIP_PLACE_VERBOSE (the placement search prints its timings),
+ * DWT_HIP_PIPE_VERBOSE (a pipelined host-pointer call prints when its upload / download streams end),
+ * DWT_HIP_PIPE_BAND (row pairs per band of such a call, a multiple of 64; default 256). */
 int dwt_hip_set_option(const char *name, int value);
 int dwt_hip_get_option(const char *name);
 

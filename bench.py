@@ -264,6 +264,29 @@ class Plane:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_json(self, obj, limit=4096):
+        """Every rank's small dict, on every rank, in rank order -- over HOST tensors (gloo in both group
+        layouts), so that the per-rank part of the line never depends on RCCL.  A rank whose text exceeds
+        `limit` bytes contributes {"truncated": true}."""
+        if self.dist is None:
+            return [obj]
+        torch = self.torch
+        raw = json.dumps(obj).encode()
+        if len(raw) > limit:
+            raw = b'{"truncated": true}'
+        mine = torch.zeros(limit, dtype=torch.uint8)
+        mine[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        parts = [torch.zeros(limit, dtype=torch.uint8) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(parts, mine)
+        out = []
+        for t in parts:
+            b = bytes(t.tolist()).rstrip(b"\0")
+            try:
+                out.append(json.loads(b.decode()))
+            except ValueError:
+                out.append({"unreadable": True})
+        return out
+
 
 def open_group(torch, dist, dev, dev_index, shared, pg_timeout):
     """One process per GPU: a default group with gloo for host tensors and RCCL ("nccl" on ROCm)
@@ -368,7 +391,9 @@ def cpu_baseline(size, levels):
     return {"value": top["gsamples_per_s"], "unit": "Gsamples/s", "cores": top["threads"], "kind": kind, "cpu_model": cpu_model(),
             "sample": f"1 image {size}x{size} float, {levels} levels, dwt_cdf97_2f_s in place, best single run per row "
                       f"(dwt_util_perf protocol, M=1); value = best row: {top['threads']} OpenMP threads, pitch "
-                      f"{top['pitch_bytes']} B, accel {top['accel']} / {top['workers']} workers",
+                      f"{top['pitch_bytes']} B, accel {top['accel']} / {top['workers']} workers; threads = min(CPUs this process may "
+                      f"run on = {avail}, 16): one GPU's share of the host (a 1-GPU lease of the 8-GPU node gets 16 of its cores; "
+                      f"BENCH_CPU_THREADS overrides)",
             "rows": rows}
 
 
@@ -542,17 +567,47 @@ def single_image_stats(torch, dwt, src, dst, n, J):
         k = i % nb
         dwt.dwt_cdf97_2i_s(work[k], n * 4, 4, n, n, n, n, J)
 
+    # the interleaved (in-place lifting) layout: dwt_cdf97_2f_inplace_s / dwt_cdf97_2i_inplace_s (src/libdwt.c:12926, 17474),
+    # out of place (device-level entry) and in place (what the libdwt.h entries are); 2 x the image per call
+    def il_fwd(i):
+        k = i % nb
+        dwt.transform2d_interleaved("cdf97_s", 0, 0, src[k], dst[k], n * 4, 4, n, n, n, n, J)
+
+    def il_inv(i):
+        k = i % nb
+        dwt.transform2d_interleaved("cdf97_s", 1, 0, dst[k], src[k], n * 4, 4, n, n, n, n, J)
+
+    def il_fwd_inplace(i):
+        k = i % nb
+        dwt.dwt_cdf97_2f_inplace_s(work[k], n * 4, 4, n, n, n, n, J)
+
+    def il_inv_inplace(i):
+        k = i % nb
+        dwt.dwt_cdf97_2i_inplace_s(work[k], n * 4, 4, n, n, n, n, J)
+
+    # measurement is explicit: tile heights of the one-image shapes, forward and inverse (untimed)
+    dwt.tune("cdf97_s", 0, src[0], dst[0], 0, 1, n * 4, n, n, J)
+    dwt.tune("cdf97_s", 1, dst[0], src[0], 0, 1, n * 4, n, n, J)
     out = {"reps": 100, "warmup": 20, "algorithmic_bytes": alg}
-    for name, fn in (("s2", s2), ("inplace", inplace), ("inv_s2", inv_s2), ("inv_inplace", inv_inplace)):
-        if name == "inplace":
+    legs = [("s2", s2), ("inplace", inplace), ("inv_s2", inv_s2), ("inv_inplace", inv_inplace),
+            ("il_fwd", il_fwd), ("il_inv", il_inv), ("il_fwd_inplace", il_fwd_inplace), ("il_inv_inplace", il_inv_inplace)]
+    for name, fn in legs:
+        if name in ("inplace", "il_fwd_inplace"):
             work.copy_(src)
         if name == "inv_s2":  # coefficients of the whole batch back in dst
             dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
+        if name == "il_inv":  # every image of dst a valid interleaved transform
+            for k in range(nb):
+                il_fwd(k)
         ms = _event_times(torch, fn, 100, 20)
         mn, med = min(ms), statistics.median(ms)
         out[f"{name}_us_min"] = round(mn * 1e3, 1)
         out[f"{name}_us_median"] = round(med * 1e3, 1)
-        out[f"frac_{name}"] = round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # the interleaved entries against what they have to move: the image in and out once (2 x 4 B per sample)
+        ref_bytes = 2 * 4 * n * n if name.startswith("il_") else alg
+        out[f"frac_{name}"] = round(ref_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    out["il_how"] = ("il_*: the interleaved layout's entries (dwt_cdf97_2f_inplace_s / _2i_inplace_s semantics), bit-exact default "
+                     "path; frac_il_* = 2 x image bytes / median / 8 TB/s")
     return out
 
 
@@ -567,6 +622,7 @@ def shard_sweep(torch, dwt, src, dst, n, J, nb):
         k = nb // div
         if k < 1 or nb % div:
             continue
+        dwt.tune("cdf97_s", 0, src[:k], dst[:k], img_bytes, k, n * 4, n, n, J)  # tile heights of this shard size (untimed)
         ms = _event_times(torch, lambda i: dwt.transform2d_batch("cdf97_s", 0, src[:k], dst[:k], img_bytes, k, n * 4, n, n, J), 10, 3)
         med = statistics.median(ms)
         rate[div] = k * n * n / (med * 1e-3) / 1e9
@@ -734,6 +790,7 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
         # plain first allocations with the library's own search off
         dwt.set_option("place_tries", 1)
         plain = make()
+        dwt.tune("cdf97_s", 0, plain[0], plain[1], n * n * 4, nb, n * 4, n, n, J)  # (search off: tile heights only)
         run(plain)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -781,6 +838,14 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
         torch.cuda.synchronize()
         plane.barrier()
         torch.cuda.synchronize()
+    # measurement is explicit (round 5): tile heights of the 2-D workloads' calls, before the warm-up, untimed
+    if w == "config3":
+        dwt.tune("cdf53_i", 0, bufs[0], bufs[1], n * n * 4, nb, n * 4, n, n, J)
+        dwt.tune("cdf53_i", 1, bufs[1], bufs[2], n * n * 4, nb, n * 4, n, n, J)
+    elif w == "config4":
+        dwt.tune("cdf97_s", 0, bufs[0], bufs[1], n * n * 4, nb, n * 4, n, n, J)
+    if dwt.alloc_batch_note() and "by" in placement and placement["by"].startswith("dwt_hip_alloc"):
+        placement["note"] = dwt.alloc_batch_note()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -789,7 +854,10 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     elapsed = plane.max(elapsed)
+    per_rank = plane.gather_json({"rank": rank, "elapsed_ms_per_step": round(my_elapsed / args.steps * 1e3, 4),
+                                  "placement_by": placement.get("by"), "placement_note": placement.get("note")})
     try:
         checks = check(bufs)
     except Exception as e:  # noqa: BLE001
@@ -819,6 +887,8 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
     }
     if cpu is not None:
         line["cpu_baseline"] = cpu
+    if world > 1:
+        line["per_rank"] = per_rank
     return line
 
 
@@ -906,9 +976,19 @@ def run_rank(args):
 
     first = None
     placed = args.placements > 1 and not args.inplace
+    def tune_shard(src, dst):
+        """dwt_hip_tune for the calls run_once makes (measurement is explicit since round 5; untimed, before the warm-up)"""
+        if args.inplace:
+            return
+        t0 = time.perf_counter()
+        for c in sorted({min(chunk, nb), nb % chunk or chunk}):
+            dwt.tune("cdf97_s", 0, src[:c], dst[:c], img_bytes, c, n * 4, n, n, J)
+        return round(time.perf_counter() - t0, 3)
+
     dwt.set_option("place_tries", 1)
     src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
     dst = src.clone() if args.inplace else torch.empty_like(src)
+    tune_first_s = tune_shard(src, dst)  # (search off: tile heights only)
     for _ in range(2):
         run_once(src, dst)
     torch.cuda.synchronize()
@@ -920,7 +1000,8 @@ def run_rank(args):
         dt = (time.perf_counter() - t0) / 5
         first = {"gsamples_per_s_this_rank": round(nb * n * n / dt / 1e9, 2), "ms_per_step": round(dt * 1e3, 4),
                  "level0_GBps": round(level0_rate(lambda: run_once(src, dst), 3), 1),
-                 "how": "plain first allocations of the shard and of the library's scratch, no placement search, 5 steps (untimed for `value`)"}
+                 "how": "plain first allocations of the shard and of the library's scratch, no placement search (dwt_hip_tune with "
+                        "place_tries = 1: tile heights only), 5 steps (untimed for `value`)"}
         # ---- the placed shard: dwt_hip_alloc_batch (destination + scratch chosen by timing), same data ----
         src = dst = None
         dwt.dwt_util_finish()  # drops the plainly placed scratch
@@ -935,6 +1016,10 @@ def run_rank(args):
             torch.rand((nb, n, n), generator=gen, out=src)
             placement = {"by": "dwt_hip_alloc_batch", "seconds_total": round(alloc_s, 2)}
             placement.update(dwt.alloc_batch_report())
+            note = dwt.alloc_batch_note()
+            if note:  # the allocator fell back to plain allocations and says why
+                placement["by"] = "plain allocations (dwt_hip_alloc_batch did not search)"
+                placement["note"] = note
             placement["how"] = ("untimed: an arena of most of the free memory; the destination tried at every 4 GiB step (one level against "
                                 "the source), the LL scratch at every step for the three best destinations (the shard's transform itself); "
                                 "the best arrangement kept, the rest of the arena returned; DESIGN s5")
@@ -942,8 +1027,10 @@ def run_rank(args):
             src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
             dst = torch.empty_like(src)
             placement = {"by": f"plain allocations (dwt_hip_alloc_batch failed: {type(e).__name__}: {e})"}
+        placement["tune_seconds"] = tune_shard(src, dst)
+        placement["tune"] = "dwt_hip_tune on the resident shard before the warm-up (untimed): tile heights; the scratch came placed with the batch"
     else:
-        placement = {"by": "none (--placements 1 or --inplace): plain first allocations"}
+        placement = {"by": "none (--placements 1 or --inplace): plain first allocations", "tune_seconds": tune_first_s}
 
     def step():
         run_once(src, dst)
@@ -969,7 +1056,17 @@ def run_rank(args):
     dwt.prof_enable(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
 
+    my_elapsed = elapsed
     elapsed = plane.max(elapsed)
+    # every rank's own figures into the line (a straggler, or a rank whose allocator fell back, must be visible)
+    per_rank = plane.gather_json({
+        "rank": rank, "device": dev_index, "images": nb, "elapsed_ms_per_step": round(my_elapsed / args.steps * 1e3, 4),
+        "step_ms_min": round(min(step_ms), 4), "step_ms_median": round(statistics.median(step_ms), 4),
+        "level0_GBps": round(2 * 4 * n * n * (1 if args.inplace else min(chunk, nb)) / (k_ms / max(k_launches, 1) * 1e-3) / 1e9, 1) if k_launches else None,
+        "placement_by": placement.get("by"), "placement_note": placement.get("note"),
+        "kept_arrangement_ms": placement.get("kept_arrangement_ms"),
+        "first_placement_gsamples_per_s": first["gsamples_per_s_this_rank"] if first else None,
+    })
 
     samples = total * n * n * args.steps
     value = samples / elapsed / 1e9
@@ -1015,9 +1112,12 @@ def run_rank(args):
         }
         out["placement"] = placement
         if first is not None:
-            # whole-job figure of the first placement: this rank's shard rate x ranks (each rank measured its own; rank 0's is shown)
-            out["value_first_placement"] = round(first["gsamples_per_s_this_rank"] * world, 3)
+            # whole-job figure of the first placement: the slowest rank's shard rate x ranks (every rank measured its own)
+            rates = [r.get("first_placement_gsamples_per_s") for r in per_rank if r.get("first_placement_gsamples_per_s")]
+            out["value_first_placement"] = round((min(rates) if rates else first["gsamples_per_s_this_rank"]) * world, 3)
             out["first_placement"] = first
+        if world > 1:
+            out["per_rank"] = per_rank
         if use_dist:
             out["control_plane"] = control
         if shared:
@@ -1082,7 +1182,8 @@ def launcher_selftest(args):
         time.sleep(3600)
     t = plane.max(1.0 + rank)
     lo, hi = B.shard_range(64, rank, world)
-    out = {"selftest": True, "n_gpus": world, "max_over_ranks": t, "images_rank0": hi - lo} if rank == 0 else None
+    per_rank = plane.gather_json({"rank": rank, "images": hi - lo})
+    out = {"selftest": True, "n_gpus": world, "max_over_ranks": t, "images_rank0": hi - lo, "per_rank": per_rank} if rank == 0 else None
 
     def split():
         if hit and fault == "hang_split":

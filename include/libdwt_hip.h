@@ -74,12 +74,12 @@ void dwt_hip_sync(void);
  * profiles/r04_placement.md).  The reference hands its callers a placement-aware allocator for the same
  * kind of reason -- dwt_util_get_opt_stride / dwt_util_get_stride, src/libdwt.c:20641-20707 -- and so does
  * this library:
- *   - the library's own LL scratch: the first forward call (batch or single image, distinct source and
- *     destination, two levels or more) that needs "place_min_mib" (option, default 1024) MiB or more of it
- *     tries up to "place_tries" (option, default 4; 1 = off) allocations, times the call itself on each
- *     and keeps the fastest.  Once per size; later calls allocate nothing and never
- *     synchronise.  dwt_hip_placement_report returns what the last search measured (ms per candidate,
- *     return value = number of candidates, 0 = no search ran).
+ *   - the library's own LL scratch: dwt_hip_tune (below) on a forward call (batch or single image, distinct
+ *     source and destination, two levels or more) that needs "place_min_mib" (option, default 1024) MiB or more
+ *     of it tries up to "place_tries" (option, default 4; 1 = off) allocations, times the call itself on each
+ *     and keeps the fastest.  dwt_hip_placement_report returns what the last search measured (ms per
+ *     candidate, return value = number of candidates, 0 = no search ran).  A transform call itself never
+ *     searches (unless DWT_HIP_TUNE=1): it allocates what it needs once and afterwards nothing.
  *   - dwt_hip_alloc_batch: source and destination of a resident batch of `n_images` dense size_x x size_y
  *     images (pitch size_x elements, images size_x * size_y elements apart) together with the scratch, placed
  *     by measurement: most of the card's free memory is mapped as one arena, the destination is tried at
@@ -91,6 +91,27 @@ int dwt_hip_alloc_batch(int wavelet, int n_images, int size_x, int size_y, int l
 /* the same for the two dense volumes of an out-of-place 3-D call (dwt_hip_transform3d_op) of `levels` levels */
 int dwt_hip_alloc_volumes(int size_x, int size_y, int size_z, int levels, void **src, void **dst);
 int dwt_hip_placement_report(double *ms, int n);
+/* "" when the last dwt_hip_alloc_batch / _volumes of this thread ran its search, else why it allocated plainly */
+const char *dwt_hip_alloc_batch_note(void);
+/* Buffers of dwt_hip_alloc_batch / _volumes are mapped through the virtual-memory API and made reachable for
+ * every peer device when they are made (hipDeviceEnablePeerAccess does not cover such ranges);
+ * dwt_hip_grant_access does the same for a later / narrower choice and, for plain allocations, enables peer
+ * access from each device named.  0 = every device named can reach the buffer. */
+int dwt_hip_grant_access(void *dev_ptr, const int *devices, int n_devices);
+/* MEASUREMENT IS EXPLICIT (round 5).  A transform call never measures anything: it allocates its scratch plainly,
+ * launches every level once and uses the launcher's tile rule -- unless dwt_hip_tune has run for its shape on
+ * the calling thread's context.  dwt_hip_tune runs the `levels`-level transform on THE CALLER'S OWN BUFFERS
+ * (`dst` receives the transform of `src`, as after a call; src != dst, device pointers, batch_stride may be 0
+ * for one image) a few times: the scratch placement search (forward, two levels or more, "place_min_mib" MiB of
+ * scratch or more: up to "place_tries" allocations behind growing spacers, each timed with the call itself,
+ * the fastest kept) and the tile-height tuner (every level of 64 MiB or more: 64 / 32 / 16 row pairs forward,
+ * 32 / 16 / 8 inverse).  Synchronous, one at a time per device; results are kept by the calling thread's
+ * context per (wavelet, direction, width, height, batch) until dwt_hip_finish.  Same bits with and without.
+ * The reference's analogue is explicit too: dwt_util_get_opt_stride, src/libdwt.c:20641-20707.
+ * Programs that only know libdwt.h: DWT_HIP_TUNE=1 in the environment (option "tune_in_call") lets the first
+ * large call of a shape measure by itself, as rounds 3-4 did. */
+int dwt_hip_tune(int wavelet, int inverse, const void *src, void *dst, size_t batch_stride, int batch,
+	int stride_x, int size_x, int size_y, int levels);
 void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int *dst_at, int *ll_at, double *ms4, double *seconds);
 
 /* Tuning / variant selection (mirrors dwt_util_set_accel, src/libdwt.c:19946).  Every setting gives the
@@ -107,9 +128,12 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * halos; 0 = through a staging copy of the image, the cross-check),
  * "il_exact_borders" (0 = no border strips at all: the top 8 rows / last 5 columns of a level keep the sweep's
  * rows-then-columns rounding -- NOT the reference's bits there, a few ulp, far inside 1e-5; opt-in like "fma"),
- * "tune_tiles" (1 = forward levels of 64 MiB and more measure their tile height -- 64 / 32 / 16 row pairs --
- * once per shape, on the first call that may synchronise; 0 = the launcher's rule), "place_tries" /
- * "place_min_mib" (placement search, below).
+ * "tune_tiles" (1 = levels of 64 MiB and more use the tile height dwt_hip_tune measured for their shape;
+ * 0 = always the launcher's rule), "tune_in_call" (1 = the first large call of a shape measures by itself;
+ * default: DWT_HIP_TUNE), "place_tries" / "place_min_mib" (placement search, below), "place_max_gib" (cap of the
+ * arena dwt_hip_alloc_batch / _volumes map for their search; 0 = free memory - 8 GiB).
+ * Read-only: "stat_launches" / "stat_allocs" (kernel launches / device allocations of this context's 2-D drivers
+ * so far), "tile_cache_size", "place_last_tries", "place_last_best".
  * 3-D: "vol_fused" (1 = one-pass levels where they pay, 2 = wherever they can run, 0 = two passes),
  * "vol_whole" (0 = the general kernel variant as a cross-check), "vol_direct" (levels >= 1 into their lattice
  * of the destination: 2 = rows shared by levels 0 and 1 written once, 1 = sample-wise stores, 0 = dense
@@ -138,13 +162,30 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
 
 /* The same batch sharded over several GPUs of ONE process (images are independent: no
  * collective in the transform).  `src` / `dst` lie in the memory of the calling thread's device, which must
- * be devices[0]; image b belongs to slot b * n_devices / batch.  Slot 0's shard is transformed where it
- * lies; every other slot is a persistent host thread with its own context on devices[k] (a device may be
- * named more than once) that pulls its shard across (hipMemcpyPeerAsync over xGMI), transforms it with
- * dwt_hip_transform2d_batch and pushes the result back -- all slots at the same time.  Synchronous: returns
- * when `dst` is complete.  Bytes of `dst` outside the frames keep their values. */
+ * be devices[0]; image b belongs to slot b * n_slots / batch (n_slots = min(n_devices, batch)), i.e. slot k
+ * owns the images [ceil(k * batch / n_slots), ceil((k + 1) * batch / n_slots)) -- dwt_hip_shard_bounds.
+ * Slot 0's shard is transformed where it lies; every other slot is a persistent host thread with its own
+ * context on devices[k] (a device may be named more than once) that pulls its shard across
+ * (hipMemcpyPeerAsync over xGMI) in up to four pieces, transforms each with dwt_hip_transform2d_batch and
+ * pushes the result back while the next piece arrives -- all slots at the same time.  Synchronous: returns
+ * when `dst` is complete.  Bytes of `dst` outside the frames keep their values.  Root-egress bound: the
+ * whole batch leaves and re-enters one device. */
 int dwt_hip_transform2d_batch_sharded(int wavelet, int inverse, const void *src, void *dst,
 	size_t batch_stride, int batch, int stride_x, int size_x, int size_y, int *j, const int *devices, int n_devices);
+void dwt_hip_shard_bounds(int batch, int n_slots, int slot, int *first, int *count);
+
+/* The batch split for shards that are RESIDENT where they are transformed ("the >= 7x scaling
+ * claim is measured on per-GPU-resident data"): shard k -- counts[k] images at srcs[k] / dsts[k],
+ * `batch_stride` bytes apart -- lies in the memory of devices[k] (allocated there by a thread bound to it with
+ * dwt_hip_set_device; a device may be named more than once; counts[k] == 0 skips a shard).  All shards are
+ * transformed at the same time, each by a persistent host thread with a context of its own on its device (the
+ * calling thread takes the first shard on its own device); nothing crosses xGMI.  Synchronous.  `*j` as in
+ * dwt_hip_transform2d_batch.  dwt_hip_tune_batch_multi runs dwt_hip_tune in every slot instead (once, before
+ * the first transform of shards that stay resident): the slots' contexts keep what it measures. */
+int dwt_hip_transform2d_batch_multi(int wavelet, int inverse, const void *const *srcs, void *const *dsts, const int *counts,
+	const int *devices, int n_shards, size_t batch_stride, int stride_x, int size_x, int size_y, int *j);
+int dwt_hip_tune_batch_multi(int wavelet, int inverse, const void *const *srcs, void *const *dsts, const int *counts,
+	const int *devices, int n_shards, size_t batch_stride, int stride_x, int size_x, int size_y, int levels);
 
 /* 2-D transforms in the INTERLEAVED (in-place lifting) layout: no de-interleave, level j
  * works on the stride-2^j lattice of the image (even lattice index = low-pass).

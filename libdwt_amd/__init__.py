@@ -69,6 +69,18 @@ lib.dwt_hip_set_workspace.argtypes = [_P, C.c_size_t, _P, C.c_size_t]
 lib.dwt_hip_set_workspace.restype = _I
 lib.dwt_hip_transform2d_batch_sharded.argtypes = [_I, _I, _P, _P, C.c_size_t, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I]
 lib.dwt_hip_transform2d_batch_sharded.restype = _I
+_PP = C.POINTER(_P)
+lib.dwt_hip_transform2d_batch_multi.argtypes = [_I, _I, _PP, _PP, C.POINTER(_I), C.POINTER(_I), _I, C.c_size_t, _I, _I, _I, C.POINTER(_I)]
+lib.dwt_hip_transform2d_batch_multi.restype = _I
+lib.dwt_hip_tune_batch_multi.argtypes = [_I, _I, _PP, _PP, C.POINTER(_I), C.POINTER(_I), _I, C.c_size_t, _I, _I, _I, _I]
+lib.dwt_hip_tune_batch_multi.restype = _I
+lib.dwt_hip_shard_bounds.argtypes = [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]
+lib.dwt_hip_shard_bounds.restype = None
+lib.dwt_hip_tune.argtypes = [_I, _I, _P, _P, C.c_size_t, _I, _I, _I, _I, _I]
+lib.dwt_hip_tune.restype = _I
+lib.dwt_hip_grant_access.argtypes = [_P, C.POINTER(_I), _I]
+lib.dwt_hip_grant_access.restype = _I
+lib.dwt_hip_alloc_batch_note.restype = C.c_char_p
 lib.dwt_hip_alloc_batch.argtypes = [_I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_P)]
 lib.dwt_hip_alloc_batch.restype = _I
 lib.dwt_hip_placement_report.argtypes = [C.POINTER(C.c_double), _I]
@@ -425,6 +437,54 @@ def transform2d_batch_sharded(wavelet, inverse, src, dst, batch_stride, batch, s
                                                batch_stride, batch, stride_x, size_x, size_y, C.byref(j), dv, len(devices))
     _check(rc, "dwt_hip_transform2d_batch_sharded")
     return j.value
+
+
+def shard_bounds(batch, n_slots, slot):
+    """dwt_hip_shard_bounds: (first image, number of images) of `slot` when image b belongs to slot b*n_slots//batch."""
+    a, n = _I(), _I()
+    lib.dwt_hip_shard_bounds(batch, n_slots, slot, C.byref(a), C.byref(n))
+    return a.value, n.value
+
+
+def _multi_args(srcs, dsts, counts, devices):
+    n = len(srcs)
+    assert len(dsts) == n and len(counts) == n and len(devices) == n
+    return (_P * n)(*[_addr(p) if p else None for p in srcs]), (_P * n)(*[_addr(p) if p else None for p in dsts]), (_I * n)(*counts), (_I * n)(*devices), n
+
+
+def transform2d_batch_multi(wavelet, inverse, srcs, dsts, counts, devices, batch_stride, stride_x, size_x, size_y, j_max=-1):
+    """dwt_hip_transform2d_batch_multi: shard k (counts[k] images at srcs[k] / dsts[k]) is RESIDENT on devices[k];
+    all shards are transformed at once, nothing crosses xGMI."""
+    j = _I(j_max)
+    s_, d_, c_, v_, n = _multi_args(srcs, dsts, counts, devices)
+    rc = lib.dwt_hip_transform2d_batch_multi(WAVELET_ID.get(wavelet, wavelet), int(inverse), s_, d_, c_, v_, n, batch_stride, stride_x,
+                                             size_x, size_y, C.byref(j))
+    _check(rc, "dwt_hip_transform2d_batch_multi")
+    return j.value
+
+
+def tune_batch_multi(wavelet, inverse, srcs, dsts, counts, devices, batch_stride, stride_x, size_x, size_y, levels=-1):
+    """dwt_hip_tune_batch_multi: dwt_hip_tune in every slot of a resident sharded batch."""
+    s_, d_, c_, v_, n = _multi_args(srcs, dsts, counts, devices)
+    _check(lib.dwt_hip_tune_batch_multi(WAVELET_ID.get(wavelet, wavelet), int(inverse), s_, d_, c_, v_, n, batch_stride, stride_x,
+                                        size_x, size_y, levels), "dwt_hip_tune_batch_multi")
+
+
+def tune(wavelet, inverse, src, dst, batch_stride, batch, stride_x, size_x, size_y, levels=-1):
+    """dwt_hip_tune: the explicit measurement (scratch placement, tile heights) on the caller's own device buffers;
+    `dst` receives the transform of `src`.  The calling thread's context keeps the results."""
+    _check(lib.dwt_hip_tune(WAVELET_ID.get(wavelet, wavelet), int(inverse), _addr(src), _addr(dst), batch_stride, batch, stride_x,
+                            size_x, size_y, levels), "dwt_hip_tune")
+
+
+def grant_access(ptr, devices):
+    dv = (_I * len(devices))(*devices)
+    _check(lib.dwt_hip_grant_access(_addr(ptr), dv, len(devices)), "dwt_hip_grant_access")
+
+
+def alloc_batch_note():
+    """'' when the last alloc_batch / alloc_volumes of this thread ran its search, else why it allocated plainly."""
+    return lib.dwt_hip_alloc_batch_note().decode()
 
 
 def transform3d(inverse, vol, stride_y, stride_z, size_x, size_y, size_z, levels=1):

@@ -16,10 +16,11 @@ import torch.distributed as dist
 
 
 def shard_range(n_items, rank, world):
-    """[lo, hi) of the contiguous block of `n_items` owned by `rank` (block sizes differ
-    by at most one; rank r owns items with b*world//n_items == r for even splits)."""
-    lo = (n_items * rank) // world
-    hi = (n_items * (rank + 1)) // world
+    """[lo, hi) of the contiguous block of `n_items` owned by `rank`: item b belongs to rank
+    b*world//n_items (SURVEY.md s8e), so rank r owns [ceil(r*n/world), ceil((r+1)*n/world));
+    block sizes differ by at most one.  The C entry dwt_hip_shard_bounds gives the same bounds."""
+    lo = (n_items * rank + world - 1) // world
+    hi = (n_items * (rank + 1) + world - 1) // world
     return lo, hi
 
 

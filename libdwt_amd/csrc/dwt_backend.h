@@ -58,11 +58,19 @@ struct Ctx {
 	// placement of the LL scratch (DESIGN s5): on the first forward call that needs `place_min_mib` or more of
 	// scratch, up to `place_tries` allocations of it -- each behind a spacer that moves it into other
 	// physical memory -- are timed with the call's own first two levels and the fastest kept
-	int tune_tiles = 1; // large forward levels: tile height measured once per shape (tuned_tile_pairs)
+	// Measurement never happens inside an ordinary transform call (round 5): dwt_hip_tune runs the tile-height
+	// tuner and the scratch placement search on the caller's buffers, once, and the context remembers the
+	// results; a transform call looks them up, allocates plainly and launches each level once.  DWT_HIP_TUNE=1 in
+	// the environment (option "tune_in_call") restores the implicit behaviour for programs that only know libdwt.h.
+	int tune_tiles = 1; // use / measure tile heights of large levels (tuned_tile_pairs); 0: the launcher's rule
 	std::map<unsigned long long, int> tile_cache;
-	int place_tries = 4;
+	int place_tries = 4;  // candidates of the scratch placement search (< 2: no search)
 	int place_min_mib = 1024;
+	int place_max_gib = 0; // cap of the placement arena of dwt_hip_alloc_batch / _volumes (0: free memory - 8 GiB)
+	int tune_in_call = -1; // -1: read DWT_HIP_TUNE on first use
+	bool tuning = false;        // inside dwt_hip_tune: measurements allowed
 	bool placing = false;       // inside a timed trial: no nested search
+	long stat_launches = 0, stat_allocs = 0; // kernel launches / device allocations made by this context's 2-D drivers (tests)
 	double place_ms[8] = {0};   // what the last search measured, per candidate
 	int place_n = 0, place_best = -1;
 	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
@@ -136,10 +144,19 @@ int generic_pass(Wavelet w, bool inverse, bool rows, Img in, Img out, int frame_
 size_t ll_band_bytes(const Geom &ge, int k, int batch, int es); // bytes of LL scratch band k (0: level-1 band, 1: level-2 band)
 int timed_forward(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db, double *ms); // ms of the 2nd of two calls
 int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db);
+int tune2d(Wavelet w, bool inverse, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db);
 bool stream_is_capturing();
+bool may_measure(); // inside dwt_hip_tune, or DWT_HIP_TUNE=1 / option "tune_in_call"
 int tuned_tile_pairs(Wavelet w, const FwdLevelArgs &a);
 int tuned_tile_pairs(Wavelet w, const InvLevelArgs &a);
 int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompose_one, int zero_padding, int batch, long src_bstride, long dst_bstride);
+int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decompose_one, int zero_padding, int batch, long src_bstride, long dst_bstride);
+bool level_fused_ok(const Geom &ge, int j); // level j runs on the fused sweeps (dense frame, both sides >= 2)
+// host-pointer calls on large images, band by band under their own PCIe transfers (dwt_host_xfer.hip):
+// 0 done, 1 error, -1 not applicable (the caller takes the plain path)
+int host_forward_pipelined(Wavelet w, const void *src, void *dst, int stride_x, int W, int H, int *jp, int decompose_one);
+int host_inverse_pipelined(Wavelet w, const void *src, void *dst, int stride_x, int W, int H, int j_max, int decompose_one);
+int prof_drain();
 void prof_before(int level = 0);
 void prof_after(int level = 0);
 int check_inited();

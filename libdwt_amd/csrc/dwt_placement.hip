@@ -102,6 +102,52 @@ struct VmmBuf {
 static std::map<void *, VmmBuf> g_vmm;
 static std::mutex g_vmm_mu;
 
+// Read-write access for the owning device and (peers = true) for every device that can reach it as a peer, so that
+// a placed buffer can be the source / destination of hipMemcpyPeerAsync (dwt_multi.hip) and of RCCL transfers
+// (bench.py's batch split): hipDeviceEnablePeerAccess does not cover ranges mapped through the virtual-memory API.
+static std::vector<hipMemAccessDesc> access_descs(int owner, const int *devices, int n_devices)
+{
+	std::vector<hipMemAccessDesc> v;
+	hipMemAccessDesc acc = {};
+	acc.location.type = hipMemLocationTypeDevice;
+	acc.location.id = owner;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	v.push_back(acc);
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		n = 0;
+	auto add = [&](int d) {
+		int can = 0;
+		if (d == owner || d < 0 || d >= n)
+			return;
+		for (auto &a : v)
+			if (a.location.id == d)
+				return;
+		if (hipDeviceCanAccessPeer(&can, d, owner) == hipSuccess && can) {
+			acc.location.id = d;
+			v.push_back(acc);
+		}
+	};
+	if (devices)
+		for (int i = 0; i < n_devices; i++)
+			add(devices[i]);
+	else
+		for (int d = 0; d < n; d++)
+			add(d);
+	(void)hipGetLastError();
+	return v;
+}
+
+static bool set_access(void *va, size_t bytes, int owner, bool peers)
+{
+	std::vector<hipMemAccessDesc> v = access_descs(owner, peers ? nullptr : &owner, peers ? 0 : 1);
+	if (hipMemSetAccess(va, bytes, v.data(), v.size()) == hipSuccess)
+		return true;
+	(void)hipGetLastError();
+	// the peers were refused: the owner alone (a peer copy of this buffer is then staged by the runtime or fails loudly)
+	return v.size() > 1 && hipMemSetAccess(va, bytes, v.data(), 1) == hipSuccess;
+}
+
 static int vmm_release(void *va, VmmBuf &b, size_t mapped_pieces)
 {
 	for (size_t i = 0; i < mapped_pieces; i++)
@@ -176,12 +222,8 @@ static void *vmm_alloc(size_t bytes, size_t piece, int slices, size_t ballast)
 		if (ok)
 			mapped++;
 	}
-	if (ok) {
-		hipMemAccessDesc acc = {};
-		acc.location = prop.location;
-		acc.flags = hipMemAccessFlagsProtReadWrite;
-		ok = hipMemSetAccess(va, b.bytes, &acc, 1) == hipSuccess;
-	}
+	if (ok)
+		ok = set_access(va, b.bytes, g.device, true);
 	if (!ok) {
 		fail("mapping %zu bytes from %zu-byte pieces failed: %s", bytes, piece, hipGetErrorString(hipGetLastError()));
 		vmm_release(va, b, mapped);
@@ -265,12 +307,8 @@ static void *spread_alloc(size_t bytes, size_t piece, size_t reserve)
 		if (ok)
 			mapped++;
 	}
-	if (ok) {
-		hipMemAccessDesc acc = {};
-		acc.location = prop.location;
-		acc.flags = hipMemAccessFlagsProtReadWrite;
-		ok = hipMemSetAccess(va, b.bytes, &acc, 1) == hipSuccess;
-	}
+	if (ok)
+		ok = set_access(va, b.bytes, g.device, true);
 	if (!ok) {
 		fail("spread allocation of %zu bytes from %zu-byte pieces failed: %s", bytes, piece, hipGetErrorString(hipGetLastError()));
 		vmm_release(va, b, mapped);
@@ -292,6 +330,8 @@ static bool vmm_free(void *va)
 		b = std::move(it->second);
 		g_vmm.erase(it);
 	}
+	// hipFree waits for the device by itself; unmapping does not: work still queued on the range would fault
+	(void)hipDeviceSynchronize();
 	vmm_release(va, b, b.handles.size());
 	return true;
 }
@@ -312,6 +352,15 @@ struct ArenaStats {
 	double dst_best_ms = 0, dst_worst_ms = 0, ll_best_ms = 0, ll_worst_ms = 0, final_ms = 0, seconds = 0;
 };
 static thread_local ArenaStats g_arena;
+// why the last dwt_hip_alloc_batch / _volumes of this thread did NOT search ("" = it did): dwt_hip_alloc_batch_note
+static thread_local char g_arena_note[256] = "";
+static void arena_note(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_arena_note, sizeof(g_arena_note), fmt, ap);
+	va_end(ap);
+}
 
 static int alloc_batch_plain(size_t total, void **src, void **dst)
 {
@@ -353,17 +402,20 @@ static int arena_place(const ArenaJob &job, void **out)
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	const size_t reserve = (size_t)8 << 30;
 	size_t n_chunks = free_b > reserve ? (free_b - reserve) / C : 0;
-	n_chunks = std::min<size_t>(n_chunks, std::max<size_t>(192, 4 * (nS + nD + nL)));
-	if (n_chunks < 2 * (nS + nD + nL))
+	// as much as the search can use: four times the workload, at least 96 GiB (the classes come in 16 GiB granules,
+	// runs of one class can be 64 GiB long); option "place_max_gib" caps it for cards shared with other tenants
+	n_chunks = std::min<size_t>(n_chunks, std::max<size_t>(96, 4 * (nS + nD + nL)));
+	if (g.place_max_gib > 0)
+		n_chunks = std::min<size_t>(n_chunks, (size_t)g.place_max_gib);
+	if (n_chunks < 2 * (nS + nD + nL)) {
+		arena_note("the card has %zu GiB to spare for the placement arena, a choice needs %zu: plain allocations", n_chunks, 2 * (nS + nD + nL));
 		return -1;
+	}
 	const auto t_start = std::chrono::steady_clock::now();
 	hipMemAllocationProp prop = {};
 	prop.type = hipMemAllocationTypePinned;
 	prop.location.type = hipMemLocationTypeDevice;
 	prop.location.id = g.device;
-	hipMemAccessDesc acc = {};
-	acc.location = prop.location;
-	acc.flags = hipMemAccessFlagsProtReadWrite;
 	std::vector<hipMemGenericAllocationHandle_t> chunk;
 	for (size_t i = 0; i < n_chunks; i++) {
 		hipMemGenericAllocationHandle_t h;
@@ -381,6 +433,7 @@ static int arena_place(const ArenaJob &job, void **out)
 	n_chunks = chunk.size();
 	if (n_chunks < 2 * (nS + nD + nL)) {
 		release_chunks();
+		arena_note("only %zu GiB of physical chunks could be created, a choice needs %zu: plain allocations", n_chunks, 2 * (nS + nD + nL));
 		return -1;
 	}
 	char *arena = nullptr;
@@ -395,7 +448,7 @@ static int arena_place(const ArenaJob &job, void **out)
 		if (ok)
 			mapped++;
 	}
-	ok = ok && hipMemSetAccess(arena, n_chunks * C, &acc, 1) == hipSuccess;
+	ok = ok && set_access(arena, n_chunks * C, g.device, false); // (the search runs on this device alone)
 	auto drop_arena = [&]() {
 		for (size_t i = 0; i < mapped; i++)
 			hipMemUnmap(arena + i * C, C);
@@ -477,6 +530,8 @@ static int arena_place(const ArenaJob &job, void **out)
 	hipStreamSynchronize(g.stream);
 	if (rc || best_ms >= 1e30) {
 		drop_arena();
+		if (!rc)
+			arena_note("no arrangement could be measured in an arena of %zu GiB: plain allocations", n_chunks);
 		return rc ? rc : -1;
 	}
 	// 3. the chosen chunks stay where they are mapped -- the buffers ARE the arrangement that was measured,
@@ -506,6 +561,7 @@ static int arena_place(const ArenaJob &job, void **out)
 			used[keep[k].first + i] = 1;
 		}
 		out[k] = arena + keep[k].first * C;
+		set_access(out[k], b.bytes, g.device, true); // what is kept can be reached by the peers too
 		std::lock_guard<std::mutex> lk(g_vmm_mu);
 		g_vmm[out[k]] = std::move(b);
 	}
@@ -733,12 +789,16 @@ int dwt_hip_alloc_batch(int wavelet, int n_images, int size_x, int size_y, int l
 	const size_t total = (size_t)size_x * es * size_y * n_images;
 	const Geom ge{size_x, size_y, size_x, size_y};
 	g_arena = ArenaStats();
+	g_arena_note[0] = 0;
 	const bool search = g.place_tries >= 2 && total >= ((size_t)g.place_min_mib << 20) && ge.Wo(2) >= 2 && ge.Ho(2) >= 2 && !g.ll_external &&
 		!g.force_generic && es == 4 && !stream_is_capturing();
 	if (search) {
 		const int rc = alloc_batch_arena(w, n_images, size_x, size_y, levels, src_out, dst_out);
 		if (rc >= 0)
 			return rc;
+	} else {
+		arena_note("no placement search for this batch (%zu MiB; \"place_min_mib\" %d, \"place_tries\" %d, 32-bit elements and at least two levels needed): plain allocations",
+			total >> 20, g.place_min_mib, g.place_tries);
 	}
 	return alloc_batch_plain(total, src_out, dst_out);
 }
@@ -754,10 +814,14 @@ int dwt_hip_alloc_volumes(int size_x, int size_y, int size_z, int levels, void *
 		return fail("dwt_hip_alloc_volumes: bad argument");
 	const size_t total = (size_t)size_x * size_y * size_z * 4;
 	g_arena = ArenaStats();
+	g_arena_note[0] = 0;
 	if (g.place_tries >= 2 && total >= ((size_t)g.place_min_mib << 20) && !g.force_generic && !stream_is_capturing()) {
 		const int rc = alloc_volumes_arena(size_x, size_y, size_z, levels, src_out, dst_out);
 		if (rc >= 0)
 			return rc;
+	} else {
+		arena_note("no placement search for these volumes (%zu MiB; \"place_min_mib\" %d, \"place_tries\" %d): plain allocations", total >> 20,
+			g.place_min_mib, g.place_tries);
 	}
 	return alloc_batch_plain(total, src_out, dst_out);
 }
@@ -778,6 +842,74 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
 		ms[4] = g_arena.final_ms;
 	}
 	if (seconds) *seconds = g_arena.seconds;
+}
+
+// "" when the last dwt_hip_alloc_batch / _volumes of this thread ran its search; otherwise why it fell back to plain allocations
+const char *dwt_hip_alloc_batch_note(void) { return g_arena_note; }
+
+// Makes a device buffer reachable from other devices of this process (peer copies, RCCL): buffers of
+// dwt_hip_alloc_batch / _volumes / _malloc_mapped get the access on their mapping (they are granted to every peer when
+// they are made; this entry is for a narrower or later choice), plain allocations through hipDeviceEnablePeerAccess
+// from each of the devices.  0 = every device named can reach the buffer.
+int dwt_hip_grant_access(void *ptr, const int *devices, int n_devices)
+{
+	if (check_inited())
+		return 1;
+	if (!ptr || !devices || n_devices < 1)
+		return fail("dwt_hip_grant_access: bad argument");
+	hipPointerAttribute_t at;
+	if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail("dwt_hip_grant_access: not a device pointer");
+	}
+	const int owner = at.device;
+	size_t bytes = 0;
+	bool mapped = false;
+	{
+		std::lock_guard<std::mutex> lk(g_vmm_mu);
+		auto it = g_vmm.find(ptr);
+		if (it != g_vmm.end()) {
+			mapped = true;
+			bytes = it->second.bytes;
+		}
+	}
+	int bad = 0;
+	if (mapped) {
+		std::vector<hipMemAccessDesc> v = access_descs(owner, devices, n_devices);
+		if (hipMemSetAccess(ptr, bytes, v.data(), v.size()) != hipSuccess)
+			return fail("hipMemSetAccess for %zu device(s) failed: %s", v.size(), hipGetErrorString(hipGetLastError()));
+		for (int i = 0; i < n_devices; i++) {
+			bool have = false;
+			for (auto &a : v)
+				have = have || a.location.id == devices[i];
+			bad += !have;
+		}
+	} else {
+		int cur = 0;
+		HIP_TRY(hipGetDevice(&cur));
+		for (int i = 0; i < n_devices; i++) {
+			const int d = devices[i];
+			if (d == owner)
+				continue;
+			int can = 0;
+			if (hipDeviceCanAccessPeer(&can, d, owner) != hipSuccess || !can) {
+				bad++;
+				continue;
+			}
+			if (hipSetDevice(d) == hipSuccess) {
+				const hipError_t e = hipDeviceEnablePeerAccess(owner, 0);
+				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+					bad++;
+			} else {
+				bad++;
+			}
+			(void)hipGetLastError();
+		}
+		HIP_TRY(hipSetDevice(cur));
+	}
+	if (bad)
+		return fail("%d of the %d device(s) cannot reach device %d's memory as peers", bad, n_devices, owner);
+	return 0;
 }
 
 void dwt_hip_free_mapped(void *p)

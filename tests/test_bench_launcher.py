@@ -36,6 +36,8 @@ def test_gpus_flag_starts_the_ranks():
     assert line["max_over_ranks"] == 2.0  # rank 1 reported 1.0 + 1
     assert line["images_rank0"] == 32      # 64 images, b*N//B
     assert line["batch_split"] == {"round_trip_ok": True}  # scatter + gather over gloo inside the guard
+    # every rank's own figures reach the line (host tensors over gloo), in rank order
+    assert line["per_rank"] == [{"rank": 0, "images": 32}, {"rank": 1, "images": 32}]
 
 
 def test_three_ranks():
@@ -44,6 +46,7 @@ def test_three_ranks():
     assert r.returncode == 0, r.stderr
     line = _json_lines(r.stdout)[-1]
     assert line["n_gpus"] == 3 and line["max_over_ranks"] == 3.0 and line["batch_split"] == {"round_trip_ok": True}
+    assert [r["images"] for r in line["per_rank"]] == [22, 21, 21]  # 64 images, image b -> rank b*3//64
 
 
 def test_gpus_flag_must_match_world_size():

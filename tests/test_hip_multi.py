@@ -1,0 +1,224 @@
+"""GPU tests of the multi-GPU front end behind the C-ABI and of the explicit measurement entry.
+
+The test box has ONE GPU: several slots on device 0 are several host threads with contexts of their own on
+the one card -- the same code path as several cards (device binding, streams, peer copies, workspaces), minus
+the xGMI hop.  Every result is compared with the oracle bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+NAMES = {"cdf97_s": ("cdf97_2f_s", "cdf97_2i_s", np.float32), "cdf53_i": ("cdf53_2f_i", "cdf53_2i_i", np.int32)}
+
+
+@pytest.fixture(scope="module")
+def dwt():
+    import libdwt_amd as d
+
+    d.dwt_util_init()
+    yield d
+    d.dwt_util_finish()
+
+
+def rand(rng, shape, dt):
+    if dt == np.int32:
+        return rng.integers(-32768, 32768, size=shape, dtype=np.int32)
+    return rng.random(shape, dtype=np.float32) * 2 - 1
+
+
+def test_shard_bounds_are_the_partition_of_the_survey(dwt):
+    """image b -> slot b*G//B, as SURVEY.md s8e writes it; the same bounds as libdwt_amd.batch.shard_range."""
+    from libdwt_amd.batch import shard_range
+
+    for B in (1, 5, 7, 64, 256):
+        for G in (1, 2, 3, 8):
+            for k in range(G):
+                a, n = dwt.shard_bounds(B, G, k)
+                assert (a, a + n) == shard_range(B, k, G)
+                assert all((b * G) // B == k for b in range(a, a + n))
+    assert [dwt.shard_bounds(5, 3, k) for k in range(3)] == [(0, 2), (2, 2), (4, 1)]
+
+
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
+def test_placed_batch_through_the_sharded_entry(dwt, oracle, wname):
+    """dwt_hip_alloc_batch (buffers mapped through the virtual-memory API, placed by measurement) handed to
+    dwt_hip_transform2d_batch_sharded with three slots: the slots' peer copies read and write the placed buffers from
+    other contexts (round 4 granted the mapping to the allocating device only and never ran the two together).  Seven
+    images over three slots: 3 + 2 + 2; each slot's shard crosses in pieces.  Forward and inverse == oracle."""
+    ff, fi, dt = NAMES[wname]
+    L = dwt.lib
+    nb, h, w, J = 7, 260, 520, 3
+    rng = np.random.default_rng(5)
+    imgs = rand(rng, (nb, h, w), dt)
+    want = imgs.copy()
+    for k in range(nb):
+        oracle.fwd(ff, want[k], J)
+    rec = want.copy()
+    for k in range(nb):
+        oracle.inv(fi, rec[k], J)
+    try:
+        dwt.set_option("place_min_mib", 0)
+        dwt.set_option("place_tries", 2)
+        dwt.set_option("place_max_gib", 24)
+        dwt.dwt_util_finish()
+        src, dst = dwt.alloc_batch(wname, nb, w, h, J)
+        if wname == "cdf97_s":  # (the search runs for the 32-bit float wavelet; other wavelets say why not)
+            assert dwt.alloc_batch_note() == "" and 8 <= dwt.alloc_batch_report()["arena_GiB"] <= 24, (dwt.alloc_batch_note(), dwt.alloc_batch_report())
+        dwt.grant_access(src, [0])
+        dwt.grant_access(dst, [0])
+        assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+        got = np.empty_like(imgs)
+        for devices in ([0, 0, 0], [0], [0, 0, 0, 0, 0]):
+            assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+            assert dwt.transform2d_batch_sharded(wname, 0, src, dst, h * w * 4, nb, w * 4, w, h, J, devices) == J
+            assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+            assert np.array_equal(bits(got), bits(want)), devices
+        assert dwt.transform2d_batch_sharded(wname, 1, dst, src, h * w * 4, nb, w * 4, w, h, J, [0, 0, 0]) == J
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, src, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(rec))
+        # freeing placed buffers while nothing is queued on them, then a fresh call: the context is still usable
+        L.dwt_hip_free(src)
+        L.dwt_hip_free(dst)
+        d = dwt.DeviceImage(h, w).upload(imgs[0])
+        getattr(dwt, "dwt_" + ff)(d.ptr, w * 4, 4, w, h, w, h, J)
+        assert np.array_equal(bits(d.download(dt)), bits(want[0]))
+        d.free()
+    finally:
+        dwt.set_option("place_min_mib", 1024)
+        dwt.set_option("place_tries", 4)
+        dwt.set_option("place_max_gib", 0)
+
+
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
+def test_resident_shards_from_c_abi(dwt, oracle, wname):
+    """dwt_hip_transform2d_batch_multi: every shard already lies where it is transformed (the >= 7x case) --
+    four shards of unequal size on devices {0, 0, 0, 0}, an empty shard among them, each in buffers of its own; the
+    library's slot workers run all of them at once.  Forward and inverse == oracle; a shard that names a device the
+    process does not have is refused."""
+    ff, fi, dt = NAMES[wname]
+    L = dwt.lib
+    h, w, J = 300, 1030, 3
+    counts = [3, 0, 2, 4, 1]
+    rng = np.random.default_rng(17)
+    shards = [rand(rng, (n, h, w), dt) for n in counts]
+    srcs = [L.dwt_hip_malloc(max(s.nbytes, 16)) for s in shards]
+    dsts = [L.dwt_hip_malloc(max(s.nbytes, 16)) for s in shards]
+    for p, s in zip(srcs, shards):
+        if s.size:
+            assert L.dwt_hip_memcpy_h2d(p, s.ctypes.data, s.nbytes) == 0
+    devices = [0] * len(counts)
+    assert dwt.transform2d_batch_multi(wname, 0, srcs, dsts, counts, devices, h * w * 4, w * 4, w, h, J) == J
+    coeffs = []
+    for p, s in zip(dsts, shards):
+        got = np.empty_like(s)
+        if s.size:
+            assert L.dwt_hip_memcpy_d2h(got.ctypes.data, p, got.nbytes) == 0
+        want = s.copy()
+        for k in range(s.shape[0]):
+            oracle.fwd(ff, want[k], J)
+        assert np.array_equal(bits(got), bits(want))
+        coeffs.append(want)
+    # inverse: coefficients in dsts -> srcs
+    assert dwt.transform2d_batch_multi(wname, 1, dsts, srcs, counts, devices, h * w * 4, w * 4, w, h, J) == J
+    for p, c in zip(srcs, coeffs):
+        got = np.empty_like(c)
+        if c.size:
+            assert L.dwt_hip_memcpy_d2h(got.ctypes.data, p, got.nbytes) == 0
+        want = c.copy()
+        for k in range(c.shape[0]):
+            oracle.inv(fi, want[k], J)
+        assert np.array_equal(bits(got), bits(want))
+    with pytest.raises(dwt.DwtError):
+        dwt.transform2d_batch_multi(wname, 0, srcs, dsts, counts, [0, 0, 0, 99, 0], h * w * 4, w * 4, w, h, J)
+    with pytest.raises(dwt.DwtError):
+        dwt.transform2d_batch_multi(wname, 0, srcs, [None] * 5, counts, devices, h * w * 4, w * 4, w, h, J)
+    for p in srcs + dsts:
+        L.dwt_hip_free(p)
+
+
+def test_tuning_in_four_slots_at_once(dwt, oracle):
+    """dwt_hip_tune_batch_multi on {0, 0, 0, 0}: four host threads ask for the placement search (spacers of 14 + 28 GiB
+    each) and the tile tuner on the one GPU at the same time.  The library runs one measurement at a time per device:
+    no deadlock, no out-of-memory, every slot ends up with measured tile heights, and the transforms that follow give
+    the oracle's bits (spot-checked per shard) in exactly J launches per shard."""
+    L = dwt.lib
+    n, J, per = 4096, 3, 2   # 2 x 4096^2 per shard: level 0 moves 128 MiB -> measured
+    rng = np.random.default_rng(23)
+    shards = [rng.random((per, n, n), dtype=np.float32) for _ in range(4)]
+    srcs = [L.dwt_hip_malloc(s.nbytes) for s in shards]
+    dsts = [L.dwt_hip_malloc(s.nbytes) for s in shards]
+    for p, s in zip(srcs, shards):
+        assert L.dwt_hip_memcpy_h2d(p, s.ctypes.data, s.nbytes) == 0
+    try:
+        dwt.set_option("place_min_mib", 0)
+        dwt.set_option("place_tries", 3)
+        dwt.dwt_util_finish()
+        dwt.tune_batch_multi("cdf97_s", 0, srcs, dsts, [per] * 4, [0] * 4, n * n * 4, n * 4, n, n, J)
+        assert len(dwt.placement_report()[0]) >= 1 and dwt.get_option("tile_cache_size") >= 1   # (the caller's own slot)
+        for p, s in zip(dsts, shards):
+            assert L.dwt_hip_memcpy_h2d(p, np.zeros_like(s).ctypes.data, s.nbytes) == 0
+        launches = dwt.get_option("stat_launches")
+        assert dwt.transform2d_batch_multi("cdf97_s", 0, srcs, dsts, [per] * 4, [0] * 4, n * n * 4, n * 4, n, n, J) == J
+        assert dwt.get_option("stat_launches") - launches == J
+        for k, (p, s) in enumerate(zip(dsts, shards)):
+            got = np.empty_like(s)
+            assert L.dwt_hip_memcpy_d2h(got.ctypes.data, p, got.nbytes) == 0
+            want = s[k % per].copy()
+            oracle.fwd("cdf97_2f_s", want, J)
+            assert np.array_equal(bits(got[k % per]), bits(want)), k
+    finally:
+        dwt.set_option("place_min_mib", 1024)
+        dwt.set_option("place_tries", 4)
+        for p in srcs + dsts:
+            L.dwt_hip_free(p)
+
+
+def test_a_transform_call_measures_nothing(dwt, oracle):
+    """The first forward call on a batch that needs more than 1 GiB of scratch (16 x 8192^2, J = 5): exactly J kernel
+    launches and exactly the two scratch allocations -- no placement search, no spacers, no tile tuner, no extra runs of
+    the caller's transform (round 4 did all of that inside the call).  dwt_hip_tune is where measurement happens: it
+    searches and tunes, the call after it is again J launches and allocates nothing, and the bits are the same -- the
+    oracle's (two images spot-checked)."""
+    L = dwt.lib
+    nb, n, J = 16, 8192, 5
+    rng = np.random.default_rng(3)
+    one = rng.random((2, n, n), dtype=np.float32)
+    src, dst = L.dwt_hip_malloc(nb * n * n * 4), L.dwt_hip_malloc(nb * n * n * 4)
+    assert src and dst
+    for b in range(nb):  # images 0, 2, 4 ... = one[0], the odd ones = one[1]
+        assert L.dwt_hip_memcpy_h2d(src + b * n * n * 4, one[b & 1].ctypes.data, n * n * 4) == 0
+    want = one.copy()
+    for k in range(2):
+        oracle.fwd("cdf97_2f_s", want[k], J)
+    try:
+        dwt.dwt_util_finish()
+        l0, a0 = dwt.get_option("stat_launches"), dwt.get_option("stat_allocs")
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J) == J
+        dwt.sync()
+        assert dwt.get_option("stat_launches") - l0 == J and dwt.get_option("stat_allocs") - a0 == 2
+        assert dwt.placement_report()[0] == [] and dwt.get_option("tile_cache_size") == 0
+        first = np.empty((2, n, n), dtype=np.float32)
+        for k, b in ((0, 14), (1, 15)):
+            assert L.dwt_hip_memcpy_d2h(first[k].ctypes.data, dst + b * n * n * 4, n * n * 4) == 0
+        assert np.array_equal(bits(first), bits(want))
+        # the explicit measurement, then the same call again
+        dwt.dwt_util_finish()
+        dwt.tune("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
+        assert len(dwt.placement_report()[0]) >= 2 and dwt.get_option("tile_cache_size") >= 2
+        assert L.dwt_hip_memcpy_h2d(dst + 15 * n * n * 4, np.zeros((n, n), np.float32).ctypes.data, n * n * 4) == 0
+        l0, a0 = dwt.get_option("stat_launches"), dwt.get_option("stat_allocs")
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J) == J
+        dwt.sync()
+        assert dwt.get_option("stat_launches") - l0 == J and dwt.get_option("stat_allocs") - a0 == 0
+        again = np.empty_like(first)
+        for k, b in ((0, 14), (1, 15)):
+            assert L.dwt_hip_memcpy_d2h(again[k].ctypes.data, dst + b * n * n * 4, n * n * 4) == 0
+        assert np.array_equal(bits(again), bits(want))
+    finally:
+        L.dwt_hip_free(src)
+        L.dwt_hip_free(dst)
+        dwt.dwt_util_finish()

@@ -579,6 +579,9 @@ def test_c_example_program(dwt, tmp_path):
                            "-L", libdir, "-l:libdwt_hip.so", "-Wl,-rpath," + libdir, "-lm"])
     out = subprocess.run([str(exe), "7", "1024", "4", "3"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "bits equal the single-GPU call" in out.stdout, (out.stdout, out.stderr)
+    # ... and with every shard resident where it is transformed (dwt_hip_transform2d_batch_multi; 4 slots)
+    out = subprocess.run([str(exe), "--resident", "9", "1024", "4", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "shards resident per device" in out.stdout and "bits equal the single-GPU call" in out.stdout, (out.stdout, out.stderr)
 
 
 def test_harness_helpers(dwt):
@@ -952,6 +955,7 @@ def test_placement_entries(dwt, oracle):
         dwt.dwt_util_finish()                # no scratch from earlier tests
         src, dst = dwt.alloc_batch("cdf97_s", nb, w, h, J)
         rep = dwt.alloc_batch_report()
+        assert dwt.alloc_batch_note() == ""
         assert rep["arena_GiB"] >= 8 and rep["dst_positions_tried"] >= 1 and rep["scratch_positions_tried"] >= 1, rep
         assert 0 < rep["whole_call_ms_best_worst"][0] <= rep["whole_call_ms_best_worst"][1]
         assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
@@ -960,13 +964,47 @@ def test_placement_entries(dwt, oracle):
         got = np.empty_like(imgs)
         assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
         assert np.array_equal(bits(got), bits(want))
-        # the library's own search: a fresh context, plain allocations of the caller
-        dwt.dwt_util_finish()
+        # a caller-owned workspace right after alloc_batch, no finish in between: the scratch the arena left with the
+        # context is a mapped range that only the library's own release can free (round 4 called hipFree on it)
+        b0 = nb * ((w + 1) // 2 + 3) * ((h + 1) // 2) * 4 + 64
+        b1 = nb * ((w + 3) // 4 + 3) * ((h + 3) // 4) * 4 + 64
+        w0, w1 = L.dwt_hip_malloc(b0), L.dwt_hip_malloc(b1)
+        assert L.dwt_hip_set_workspace(w0, b0, w1, b1) == 0, dwt.last_error()
+        assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
         assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
-        trials, kept = dwt.placement_report()
-        assert len(trials) >= 1 and 0 <= kept < len(trials)
         assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
         assert np.array_equal(bits(got), bits(want))
+        assert L.dwt_hip_set_workspace(None, 0, None, 0) == 0
+        for p in (w0, w1):
+            L.dwt_hip_free(p)
+        # the library's own search is EXPLICIT (dwt_hip_tune): a fresh context, the caller's buffers; a plain
+        # transform call never searches
+        dwt.dwt_util_finish()
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
+        assert dwt.placement_report()[0] == [], "no search inside a transform call"
+        dwt.dwt_util_finish()
+        dwt.tune("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J)
+        trials, kept = dwt.placement_report()
+        assert len(trials) >= 1 and 0 <= kept < len(trials)
+        assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        # ... unless the environment asks for it (DWT_HIP_TUNE=1 = option "tune_in_call"): programs that only know libdwt.h
+        dwt.dwt_util_finish()
+        dwt.set_option("tune_in_call", 1)
+        assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
+        dwt.set_option("tune_in_call", 0)
+        assert len(dwt.placement_report()[0]) >= 1
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        # a batch too small for the search says so instead of hiding it
+        dwt.set_option("place_min_mib", 1024)
+        s2_, d2_ = dwt.alloc_batch("cdf97_s", nb, w, h, J)
+        assert dwt.alloc_batch_report()["arena_GiB"] == 0 and "plain allocations" in dwt.alloc_batch_note()
+        for p in (s2_, d2_):
+            L.dwt_hip_free(p)
+        dwt.set_option("place_min_mib", 0)
         # caller-owned workspace
         b0 = nb * ((w + 1) // 2 + 3) * ((h + 1) // 2) * 4 + 64
         b1 = nb * ((w + 3) // 4 + 3) * ((h + 3) // 4) * 4 + 64
@@ -985,8 +1023,9 @@ def test_placement_entries(dwt, oracle):
             L.dwt_hip_free(p)
     finally:
         L.dwt_hip_set_workspace(None, 0, None, 0)
+        dwt.set_option("tune_in_call", 0)
         dwt.set_option("place_min_mib", 1024)
-        dwt.set_option("place_tries", 3)
+        dwt.set_option("place_tries", 4)
 
 
 @pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
@@ -1028,9 +1067,9 @@ def test_batch_sharded_over_devices_in_one_process(dwt, oracle, wname):
 
 
 def test_measured_tile_heights_do_not_change_the_bits(dwt, oracle):
-    """Large forward levels (64 MiB and more) pick their tile height by timing 64 / 32 / 16 row pairs once per
-    shape (option tune_tiles, default on): a scheduling choice only -- the batch's coefficients are the oracle's
-    with the tuner on, off, and on again (cache cleared in between)."""
+    """Large levels (64 MiB and more) get their tile height from dwt_hip_tune, which times 64 / 32 / 16 row pairs once
+    per shape: a scheduling choice only -- the batch's coefficients are the oracle's with measured heights, with the
+    launcher's rule (tune_tiles = 0) and with measured heights again; the transform calls themselves measure nothing."""
     L = dwt.lib
     nb, n, J = 5, 2048, 3
     imgs = np.random.default_rng(61).random((nb, n, n), dtype=np.float32)
@@ -1043,9 +1082,15 @@ def test_measured_tile_heights_do_not_change_the_bits(dwt, oracle):
         for tune in (1, 0, 1):
             dwt.set_option("tune_tiles", tune)
             assert dwt.get_option("tune_tiles") == tune
+            dwt.dwt_util_finish()  # forget what was measured
+            before = dwt.get_option("tile_cache_size")
+            dwt.tune("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
+            assert dwt.get_option("tile_cache_size") - before == (1 if tune else 0)  # level 0 is the one level of 64 MiB or more
             assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
-            for _ in range(2):  # the first call measures, the second finds the height remembered
+            launches = dwt.get_option("stat_launches")
+            for _ in range(2):
                 assert dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J) == J
+            assert dwt.get_option("stat_launches") - launches == 2 * J, "a transform call is J launches, nothing else"
             got = np.empty_like(imgs)
             assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
             assert np.array_equal(bits(got[0]), bits(want0)) and np.array_equal(bits(got[4]), bits(want4)), tune
@@ -1090,11 +1135,12 @@ def test_randomised_soak():
 @pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
 @pytest.mark.parametrize("shape,levels", [((4096, 8192), 5), ((8192, 8192), 5), ((5001, 4097), 3), ((8192, 2100), 1), ((2049, 8200), -1), ((16390, 1100), 2)],
                          ids=lambda v: str(v))
-def test_host_pointer_call_pipelined_under_the_transfers(dwt, wname, shape, levels):
+def test_host_pointer_call_pipelined_under_the_transfers(dwt, oracle, wname, shape, levels):
     """Host-pointer calls on images of 64 MiB and more run level 0 (forward: and level 1) band by band while the image is
     still crossing PCIe (the caller's memory pinned in place, uploads, kernels and downloads on three streams).  Same bits
     as the plain upload / transform / download path (host_pipeline = 0), forward and inverse, in place and out of place,
-    odd sizes and padded rows; the round trip closes."""
+    odd sizes and padded rows; the round trip closes -- and both are the ORACLE's bits (forward coefficients and
+    reconstruction), so the default drop-in path for large host images is pinned directly, not through its sibling."""
     h, w = shape
     ff, fi, dt = NAMES[wname]
     rng = np.random.default_rng(h + w)
@@ -1134,3 +1180,77 @@ def test_host_pointer_call_pipelined_under_the_transfers(dwt, wname, shape, leve
         assert np.array_equal(bits(outs[0][k]), bits(outs[1][k])) and np.array_equal(bits(outs[0][k]), bits(outs[2][k]))
     rec = outs[0][2]
     assert np.array_equal(rec, img) if dt == np.int32 else np.abs(rec - img).max() < 1e-4
+    want = img.copy()
+    jw = oracle.fwd(ff, want, levels)
+    assert jw == outs[1][0] and np.array_equal(bits(outs[1][1]), bits(want)), "pipelined forward == oracle"
+    oracle.inv(fi, want, jw)
+    assert np.array_equal(bits(outs[1][2]), bits(want)), "pipelined inverse == oracle"
+
+
+def test_host_pointer_call_from_a_read_only_mapping(dwt, oracle, tmp_path):
+    """`_s2` with a source the library cannot pin for writing -- a read-only file mapping (the caller's memory is
+    pinned in place with hipHostRegister for the pipelined path; a mapping that refuses takes the plain path): the call
+    succeeds either way and gives the oracle's bits; the source is untouched."""
+    import mmap
+
+    h, w, J = 4096, 8192, 4   # 128 MiB: above the pipelined path's threshold
+    img = np.random.default_rng(12).random((h, w), dtype=np.float32)
+    path = tmp_path / "src.raw"
+    img.tofile(path)
+    want = img.copy()
+    jw = oracle.fwd("cdf97_2f_s", want, J)
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        src = np.frombuffer(mm, dtype=np.float32).reshape(h, w)
+        assert not src.flags.writeable
+        dst = np.zeros((h, w), dtype=np.float32)
+        assert dwt._fwd(dwt.CDF97_S, src.ctypes.data, dst, w * 4, 4, w, h, w, h, J, 0, 0, "dwt_cdf97_2f_s2, read-only source") == jw
+        assert np.array_equal(bits(dst), bits(want))
+        assert np.array_equal(bits(src), bits(img))
+        rec = np.zeros((h, w), dtype=np.float32)
+        dwt._inv(dwt.CDF97_S, dst, rec, w * 4, 4, w, h, w, h, jw, 0, 0, "dwt_cdf97_2i_s2")
+        oracle.inv("cdf97_2i_s", want, jw)
+        assert np.array_equal(bits(rec), bits(want))
+        del src
+        mm.close()
+
+
+def test_two_threads_on_the_halves_of_one_allocation(dwt, oracle):
+    """Two host threads (each with its own context) transform the two halves of ONE allocation at the same time through
+    the host-pointer entries: the halves share the page at their boundary, so the pinning of one call meets the pinning
+    of the other (whichever loses takes the plain path).  Both halves give the oracle's bits, forward and inverse."""
+    import threading
+
+    h, w, J = 2304, 8200, 3   # 72 MiB per half; a row is not a multiple of the page size
+    buf = np.random.default_rng(99).random((2 * h, w), dtype=np.float32)
+    orig = buf.copy()
+    want = buf.copy()
+    for k in range(2):
+        oracle.fwd("cdf97_2f_s", want[k * h:(k + 1) * h], J)
+    errs = []
+
+    def run(k, inverse):
+        try:
+            half = buf[k * h:(k + 1) * h]
+            if inverse:
+                dwt.dwt_cdf97_2i_s(half.ctypes.data, w * 4, 4, w, h, w, h, J)
+            else:
+                assert dwt.dwt_cdf97_2f_s(half.ctypes.data, w * 4, 4, w, h, w, h, J) == J
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, inverse, repr(e)))
+        finally:
+            dwt.dwt_util_finish()  # the thread's own context
+
+    for inverse in (False, True):
+        th = [threading.Thread(target=run, args=(k, inverse)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        if not inverse:
+            assert np.array_equal(bits(buf), bits(want))
+            for k in range(2):
+                oracle.inv("cdf97_2i_s", want[k * h:(k + 1) * h], J)
+        else:
+            assert np.array_equal(bits(buf), bits(want)) and np.abs(buf - orig).max() < 1e-4

@@ -106,5 +106,10 @@ def test_shard_range_partitions():
                 assert b == c and a <= b and c <= d
             sizes = [b - a for a, b in blocks]
             assert max(sizes) - min(sizes) <= 1
+            # SURVEY.md s8e, literally: item b belongs to rank b*world//n
+            for r, (a, b) in enumerate(blocks):
+                assert all((i * world) // n == r for i in range(a, b))
     # config 4: 256 images over 8 GPUs -> 32 contiguous images each
     assert shard_range(256, 3, 8) == (96, 128)
+    # five images over three ranks: 2, 2, 1 (b*3//5 = 0, 0, 1, 1, 2)
+    assert [shard_range(5, r, 3) for r in range(3)] == [(0, 2), (2, 4), (4, 5)]

@@ -61,11 +61,14 @@ def main():
     m = timeit(lambda: dwt.transform2d_batch("cdf53_i", 0, IB, OB, n3*n3*4, 16, n3*4, n3, n3, 3)); rep("cdf53 int fwd 4096^2 J=3 batch of 16", *m, 16*n3*n3, 16*alg3)
     m = timeit(lambda: dwt.transform2d_batch("cdf53_i", 1, OB, IB, n3*n3*4, 16, n3*4, n3, n3, 3)); rep("cdf53 int inv 4096^2 J=3 batch of 16", *m, 16*n3*n3, 16*alg3)
     del IB, OB
-    # host-pointer drop-in call (PCIe inclusive)
-    h = np.random.default_rng(0).random((n, n), dtype=np.float32)
-    m = timeit(lambda: dwt.dwt_cdf97_2f_s(h, n*4, 4, n, n, n, n, J), reps=3, warm=1); rep("cdf97 fwd 8192^2 J=5 HOST pointer (H2D + kernels + D2H)", *m, n*n, alg)
-    hs = np.random.default_rng(0).random((512, 512), dtype=np.float32)
-    m = timeit(lambda: dwt.dwt_cdf97_2f_s(hs, 2048, 4, 512, 512, 512, 512, -1), reps=10, warm=2); rep("cdf97 fwd 512^2 full HOST pointer (examples/simple size)", *m, 512*512, sum(2*4*(512>>j)**2 for j in range(9)))
+    # host-pointer drop-in call (PCIe inclusive; ENTRIES_NO_HOST=1 skips it: counter passes)
+    if os.environ.get("ENTRIES_NO_HOST"):
+        h = None
+    else:
+      h = np.random.default_rng(0).random((n, n), dtype=np.float32)
+      m = timeit(lambda: dwt.dwt_cdf97_2f_s(h, n*4, 4, n, n, n, n, J), reps=3, warm=1); rep("cdf97 fwd 8192^2 J=5 HOST pointer (H2D + kernels + D2H)", *m, n*n, alg)
+      hs = np.random.default_rng(0).random((512, 512), dtype=np.float32)
+      m = timeit(lambda: dwt.dwt_cdf97_2f_s(hs, 2048, 4, 512, 512, 512, 512, -1), reps=10, warm=2); rep("cdf97 fwd 512^2 full HOST pointer (examples/simple size)", *m, 512*512, sum(2*4*(512>>j)**2 for j in range(9)))
     # 3-D: in place (two passes per level) and out of place (one fused pass per level)
     for nn, lv in ((512, 3), (1024, 3)):
         try:
@@ -80,6 +83,8 @@ def main():
             rep(f"cdf97 3-D fwd {nn}^3 {lv} levels in place (two passes per level)", *m, vox, algv)
             m = timeit(lambda: dwt.transform3d(0, V, nn*4, nn*nn*4, nn, nn, nn, 1), reps=5, warm=2)
             rep(f"cdf97 3-D fwd {nn}^3 1 level in place", *m, vox, 8*vox)
+            m = timeit(lambda: dwt.transform3d(1, V, nn*4, nn*nn*4, nn, nn, nn, 1), reps=5, warm=2)
+            rep(f"cdf97 3-D inv {nn}^3 1 level in place", *m, vox, 8*vox)
             m = timeit(lambda: dwt.transform3d(1, V, nn*4, nn*nn*4, nn, nn, nn, lv), reps=5, warm=2)
             rep(f"cdf97 3-D inv {nn}^3 {lv} levels in place", *m, vox, algv)
             del V

@@ -293,7 +293,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			if (detour) {
 				// copy the staged subbands to their place: right half, bottom-left, and the LL
 				// quadrant too when it was written here (in line: on a side stream beside the deeper
-				// levels it measured 8-10 us slower, profiles/r03_entries_summary.md)
+				// levels it measured 8-10 us slower, profiles/archive/r03_entries_summary.md)
 				const Rect rc[3] = {{Wd, 0, Wd, 0, Wo - Wd, Ho}, {0, Hd, 0, Hd, Wd, Ho - Hd}, {0, 0, 0, 0, last ? Wd : 0, Hd}};
 				if (copy_rects_on(g.stream, dst, hdst, rc, 3))
 					return 1;

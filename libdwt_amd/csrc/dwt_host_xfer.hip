@@ -142,7 +142,7 @@ static void scatter_row(char *strided, const char *dense, int w, int stride)
 
 // a 2-D copy straight from / to the caller's rows runs at the PCIe rate for every pitch that is a multiple of 4 bytes
 // (57 GB/s at 8192, 8196 and 8256 B, pageable or pinned) and at 1 GB/s for an odd one (8205 B):
-// scripts/probes/r04_oddpitch_probe.py
+// scripts/archive/probes/r04_oddpitch_probe.py
 static bool host_pitch_is_fast(const void *hp, int stride_x, int stride_y, int es)
 {
 	return stride_y == es && stride_x % 4 == 0 && (uintptr_t)hp % 4 == 0;
@@ -227,7 +227,7 @@ int host_download(void *hp, int stride_x, int stride_y, int es, int w, int h, co
 }
 
 // A host volume with awkward strides (libdwt's own "optimal" strides are odd numbers of bytes: a 2-D copy with such a
-// pitch runs at 1 GB/s, scripts/probes/r04_oddpitch_probe.py) <-> a device volume: batches of slices of about 32 MiB
+// pitch runs at 1 GB/s, scripts/archive/probes/r04_oddpitch_probe.py) <-> a device volume: batches of slices of about 32 MiB
 // are repacked by the row pool into / out of the halves of a pinned buffer laid out like the device volume, one copy
 // per batch, the CPU on batch k+1 while batch k crosses PCIe.  (Round 3 moved slice by slice with a stream
 // synchronisation each: 0.8 ns per voxel against 0.14 for the bytes alone.)
@@ -379,7 +379,7 @@ int host_forward_pipelined(Wavelet w, const void *src, void *dst, int stride_x, 
 		// One copy per band and direction.  (Measured: cutting them into pieces of 2-16 MiB, or plain instead of 2-D
 		// copies where the rows lie back to back, made the call slower or erratic -- 7.8-10.8 ms against 7.5.  The two
 		// directions overlap only in part on this platform: 256 MiB each way at once from pinned memory take 9.4 ms as two
-		// copies, 5.9 ms as 32 + 32; scripts/probes/r04_duplex_probe.py.)
+		// copies, 5.9 ms as 32 + 32; scripts/archive/probes/r04_duplex_probe.py.)
 		auto up_rows = [&](int r0, int r1) -> int {
 			if (r1 > r0)
 				HIP_TRY(hipMemcpy2DAsync(A + (long)r0 * pitch, pitch, (const char *)src + (long)r0 * stride_x, stride_x, (size_t)W * 4, r1 - r0,

@@ -10,7 +10,7 @@
 //   - the product's allocators: dwt_hip_alloc_batch / dwt_hip_alloc_volumes over arena_place -- most of the
 //     free memory mapped as ONE arena (HIP virtual-memory API, 1 GiB physical chunks), every arrangement of
 //     destination and workspace measured with the workload itself, the best kept mapped where it was measured;
-//   - the instruments the diagnosis was made with and scripts/probes/r04_*.py call: dense two-stream write /
+//   - the instruments the diagnosis was made with and scripts/archive/probes/r04_*.py call: dense two-stream write /
 //     copy probes (dwt_hip_probe_pair_us / _copy_us: they do NOT see the classes the sweeps see -- their DRAM
 //     pages stay open), buffers mapped from physical pieces of far-apart groups (dwt_hip_malloc_mapped) or from
 //     pieces at even distances through ALL free memory (dwt_hip_malloc_spread: the same mix of the classes for
@@ -742,7 +742,7 @@ using namespace dwtb;
 extern "C" {
 
 // Time of the two-stream probe on device buffers a and b (`bytes` each; b may be NULL: one stream),
-// in microseconds; negative on error.  Diagnostic entry (scripts/probes/r04_*).
+// in microseconds; negative on error.  Diagnostic entry (scripts/archive/probes/r04_*).
 double dwt_hip_probe_pair_us(void *a, void *b, size_t bytes)
 {
 	if (check_inited())

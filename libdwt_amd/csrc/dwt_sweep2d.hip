@@ -187,7 +187,7 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	// Rows are addressed as BUFFERS (a descriptor per row in scalar registers, per-lane byte
 	// offsets): the hardware checks every dword against the row's length, zero-fills loads and
 	// drops stores beyond it, and 16-byte accesses need only 4-byte alignment (probed:
-	// scripts/probes/buf_probe.hip).  So every tile -- overhanging the image or not, rows aligned
+	// scripts/archive/probes/buf_probe.hip).  So every tile -- overhanging the image or not, rows aligned
 	// or not -- takes the same 16-byte path; the up to four reflected columns right of the edge
 	// that a valid output can reach come by one 4-byte DMA per row.
 	const int n_edge = min(4, c0 + TW - a.W); // columns of this tile's main block right of the edge (<= 0: none)
@@ -501,7 +501,7 @@ static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid,
 	// at once), 7 (non-temporal loads and detail stores, the LL band's stores temporal), 3 (the LL band
 	// non-temporal too: launches whose LL bands exceed the Infinity Cache), 15 (= 7 with the neighbour taps
 	// by wavefront shifts instead of LDS reads: bit-identical, 0.8 % slower, the cross-check variant).  The
-	// other policies and ring depths of rounds 1-3 measured slower and are gone (profiles/r02_experiments.md).
+	// other policies and ring depths of rounds 1-3 measured slower and are gone (profiles/archive/r02_experiments.md).
 	const int nt = a.temporal ? 6 : (t.nt & 8) ? 15 : (t.nt & 4) ? 7 : 3;
 	if (t.ring == 16) {
 		switch (nt) {

@@ -443,7 +443,7 @@ static int vol_ip_march(const VolFusedArgs &a, const VolTuning &vt, int nw = 4)
 
 // Waves per workgroup: tiles of 64 rows (8 waves, one workgroup per CU) halve the halo rows and win at
 // every size measured (1024^3 in place: forward 2.30 -> 1.96 ms, inverse 2.38 -> 2.16; 512^3 0.40 -> 0.36;
-// scripts/r03_vol_ip_waves.py) -- unless the volume has a single tile row of 32 anyway.
+// scripts/archive/r03/r03_vol_ip_waves.py) -- unless the volume has a single tile row of 32 anyway.
 static int vol_ip_waves(const VolFusedArgs &a, const VolTuning &vt)
 {
 	if (vt.ip_waves == 4 || vt.ip_waves == 8)
@@ -486,7 +486,7 @@ bool vol_level_ip_can(const VolFusedArgs &a)
 bool vol_level_ip_applies(const VolFusedArgs &a)
 {
 	// about one workgroup per CU at 32 slice pairs per march, tiles mostly used.  Measured (one level,
-	// forward / inverse, ms; scripts/r03_vol_ip_sizes.py): 448^3 one pass 0.33 / 0.36 against two passes
+	// forward / inverse, ms; scripts/archive/r03/r03_vol_ip_sizes.py): 448^3 one pass 0.33 / 0.36 against two passes
 	// 0.28 / 0.29 (which run partly out of the Infinity Cache); 512^3 0.38 / 0.41 against 0.41 / 0.42;
 	// 640^3 0.80 / 0.87 against 0.90 / 0.86; 768^3 1.05 / 1.13 against 1.50 / 1.46
 	if (!vol_level_ip_can(a) || a.nx < 128)

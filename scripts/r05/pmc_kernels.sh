@@ -2,7 +2,7 @@
 # Round 5: kernel trace + PMC passes (one counter group per pass, never with other trace domains) over EVERY entry of
 # the path (scripts/measure_entries.py: 2-D forward / inverse single image and batches, int 5/3, the interleaved layout,
 # 3-D out of place and in place) -- the counters of every kernel that is not the headline.
-#   gpurun --timeout 1200 -- 'bash scripts/r05/pmc_kernels.sh'        (last on a box: see scripts/r04/final.sh)
+#   gpurun --timeout 1200 -- 'bash scripts/r05/pmc_kernels.sh'        (last on a box: see scripts/archive/r04/final.sh)
 set -u
 OUT=gpurun_out/r05/pmc_kernels
 rm -rf $OUT; mkdir -p $OUT

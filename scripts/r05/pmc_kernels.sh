@@ -15,4 +15,4 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_AN
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/pmc_sq2.log 2>&1; echo "sq2 rc=$?"
 python3 scripts/r05/pmc_kernels_table.py $OUT > gpurun_out/r05/kernels_pmc.md; head -60 gpurun_out/r05/kernels_pmc.md
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) gpurun_out/r05/entries_kernel_stats.csv
-find $OUT -name "*.csv" -size +2M -delete
+find $OUT -name "*.csv" -size +24M -delete  # (gpurun merges at most 64 MiB back)

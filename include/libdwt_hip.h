@@ -93,10 +93,11 @@ int dwt_hip_alloc_volumes(int size_x, int size_y, int size_z, int levels, void *
 int dwt_hip_placement_report(double *ms, int n);
 /* "" when the last dwt_hip_alloc_batch / _volumes of this thread ran its search, else why it allocated plainly */
 const char *dwt_hip_alloc_batch_note(void);
-/* Buffers of dwt_hip_alloc_batch / _volumes are mapped through the virtual-memory API and made reachable for
- * every peer device when they are made (hipDeviceEnablePeerAccess does not cover such ranges);
- * dwt_hip_grant_access does the same for a later / narrower choice and, for plain allocations, enables peer
- * access from each device named.  0 = every device named can reach the buffer. */
+/* Buffers of dwt_hip_alloc_batch / _volumes are mapped through the virtual-memory API with access for their owner
+ * alone (hipDeviceEnablePeerAccess does not cover such ranges).  dwt_hip_transform2d_batch_sharded grants its
+ * slots' devices by itself; dwt_hip_grant_access does it for a caller's own peer copies (`dev_ptr` may point
+ * anywhere into the buffer) and, for plain allocations, enables peer access from each device named.
+ * 0 = every device named can reach the buffer. */
 int dwt_hip_grant_access(void *dev_ptr, const int *devices, int n_devices);
 /* MEASUREMENT IS EXPLICIT (round 5).  A transform call never measures anything: it allocates its scratch plainly,
  * launches every level once and uses the launcher's tile rule -- unless dwt_hip_tune has run for its shape on

@@ -131,6 +131,7 @@ struct Geom {
 
 int grow(void **p, size_t *have, size_t need);
 void dev_free(void *p); // hipFree, or the release of a buffer mapped by dwt_placement.hip
+int grant_range(const void *p, int owner, const int *devices, int n_devices); // a placed (VMM) buffer made reachable for these devices; plain allocations: no-op
 int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
 int copy_rect(Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h);
 int zero_rect(Img img, long x, long y, long w, long h);

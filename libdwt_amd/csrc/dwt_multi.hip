@@ -327,6 +327,10 @@ int dwt_hip_transform2d_batch_sharded(int wavelet, int inverse, const void *src,
 	std::lock_guard<std::mutex> turn(g_slots_mu);
 	// everything queued on the caller's stream so far (the batch's producers) before the other devices read it
 	HIP_TRY(hipStreamSynchronize(g.stream));
+	// a batch from dwt_hip_alloc_batch is mapped through the virtual-memory API with access for its owner alone:
+	// the slots' devices are granted now (hipDeviceEnablePeerAccess, which the slots call, does not cover such ranges)
+	if (grant_range(src, root, devices, G) || grant_range(dst, root, devices, G))
+		return 1;
 	const SlotOpts opts = SlotOpts::of_caller();
 	std::vector<int> js(G, *j);
 	const int j_in = *j;

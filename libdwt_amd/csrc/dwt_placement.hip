@@ -102,9 +102,11 @@ struct VmmBuf {
 static std::map<void *, VmmBuf> g_vmm;
 static std::mutex g_vmm_mu;
 
-// Read-write access for the owning device and (peers = true) for every device that can reach it as a peer, so that
-// a placed buffer can be the source / destination of hipMemcpyPeerAsync (dwt_multi.hip) and of RCCL transfers
-// (bench.py's batch split): hipDeviceEnablePeerAccess does not cover ranges mapped through the virtual-memory API.
+// Read-write access for the owning device and for the peers named (devices == nullptr: every device that can reach it
+// as a peer): hipDeviceEnablePeerAccess does not cover ranges mapped through the virtual-memory API, so a placed buffer
+// that is to be the source / destination of hipMemcpyPeerAsync (dwt_multi.hip) is granted to exactly the devices of that
+// call, when the call is made (grant_range).  Buffers are CREATED with access for their owner alone: a process that
+// drives one GPU of eight (one rank of bench.py) never touches the other seven.
 static std::vector<hipMemAccessDesc> access_descs(int owner, const int *devices, int n_devices)
 {
 	std::vector<hipMemAccessDesc> v;
@@ -223,7 +225,7 @@ static void *vmm_alloc(size_t bytes, size_t piece, int slices, size_t ballast)
 			mapped++;
 	}
 	if (ok)
-		ok = set_access(va, b.bytes, g.device, true);
+		ok = set_access(va, b.bytes, g.device, false);
 	if (!ok) {
 		fail("mapping %zu bytes from %zu-byte pieces failed: %s", bytes, piece, hipGetErrorString(hipGetLastError()));
 		vmm_release(va, b, mapped);
@@ -308,7 +310,7 @@ static void *spread_alloc(size_t bytes, size_t piece, size_t reserve)
 			mapped++;
 	}
 	if (ok)
-		ok = set_access(va, b.bytes, g.device, true);
+		ok = set_access(va, b.bytes, g.device, false);
 	if (!ok) {
 		fail("spread allocation of %zu bytes from %zu-byte pieces failed: %s", bytes, piece, hipGetErrorString(hipGetLastError()));
 		vmm_release(va, b, mapped);
@@ -561,7 +563,6 @@ static int arena_place(const ArenaJob &job, void **out)
 			used[keep[k].first + i] = 1;
 		}
 		out[k] = arena + keep[k].first * C;
-		set_access(out[k], b.bytes, g.device, true); // what is kept can be reached by the peers too
 		std::lock_guard<std::mutex> lk(g_vmm_mu);
 		g_vmm[out[k]] = std::move(b);
 	}
@@ -727,6 +728,35 @@ static int alloc_volumes_arena(int nx, int ny, int nz, int levels, void **src_ou
 	return 0;
 }
 
+// the mapped buffer that contains p (null: p is not in one)
+static bool vmm_find(const void *p, void **base, size_t *bytes)
+{
+	std::lock_guard<std::mutex> lk(g_vmm_mu);
+	auto it = g_vmm.upper_bound((void *)p);
+	if (it == g_vmm.begin())
+		return false;
+	--it;
+	if ((const char *)p >= (const char *)it->first + it->second.bytes)
+		return false;
+	*base = it->first;
+	*bytes = it->second.bytes;
+	return true;
+}
+
+// 0: every device named may now read and write the buffer p lies in (a plain allocation: nothing to do here, the
+// devices enable peer access themselves); 1: a mapped buffer could not be granted
+int grant_range(const void *p, int owner, const int *devices, int n_devices)
+{
+	void *base = nullptr;
+	size_t bytes = 0;
+	if (!vmm_find(p, &base, &bytes))
+		return 0;
+	std::vector<hipMemAccessDesc> v = access_descs(owner, devices, n_devices);
+	if (hipMemSetAccess(base, bytes, v.data(), v.size()) != hipSuccess)
+		return fail("hipMemSetAccess for %zu device(s) on a placed buffer failed: %s", v.size(), hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+
 // device memory of either kind back to the system
 void dev_free(void *p)
 {
@@ -847,10 +877,11 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
 // "" when the last dwt_hip_alloc_batch / _volumes of this thread ran its search; otherwise why it fell back to plain allocations
 const char *dwt_hip_alloc_batch_note(void) { return g_arena_note; }
 
-// Makes a device buffer reachable from other devices of this process (peer copies, RCCL): buffers of
-// dwt_hip_alloc_batch / _volumes / _malloc_mapped get the access on their mapping (they are granted to every peer when
-// they are made; this entry is for a narrower or later choice), plain allocations through hipDeviceEnablePeerAccess
-// from each of the devices.  0 = every device named can reach the buffer.
+// Makes a device buffer reachable from other devices of this process (peer copies): buffers of dwt_hip_alloc_batch /
+// _volumes / _malloc_mapped get the access on their mapping (they are created with access for their owner alone;
+// dwt_hip_transform2d_batch_sharded grants its slots' devices by itself), plain allocations through
+// hipDeviceEnablePeerAccess from each of the devices.  `ptr` may point anywhere into the buffer.  0 = every device
+// named can reach it.
 int dwt_hip_grant_access(void *ptr, const int *devices, int n_devices)
 {
 	if (check_inited())
@@ -863,52 +894,37 @@ int dwt_hip_grant_access(void *ptr, const int *devices, int n_devices)
 		return fail("dwt_hip_grant_access: not a device pointer");
 	}
 	const int owner = at.device;
-	size_t bytes = 0;
-	bool mapped = false;
-	{
-		std::lock_guard<std::mutex> lk(g_vmm_mu);
-		auto it = g_vmm.find(ptr);
-		if (it != g_vmm.end()) {
-			mapped = true;
-			bytes = it->second.bytes;
-		}
-	}
 	int bad = 0;
-	if (mapped) {
-		std::vector<hipMemAccessDesc> v = access_descs(owner, devices, n_devices);
-		if (hipMemSetAccess(ptr, bytes, v.data(), v.size()) != hipSuccess)
-			return fail("hipMemSetAccess for %zu device(s) failed: %s", v.size(), hipGetErrorString(hipGetLastError()));
-		for (int i = 0; i < n_devices; i++) {
-			bool have = false;
-			for (auto &a : v)
-				have = have || a.location.id == devices[i];
-			bad += !have;
-		}
-	} else {
-		int cur = 0;
-		HIP_TRY(hipGetDevice(&cur));
-		for (int i = 0; i < n_devices; i++) {
-			const int d = devices[i];
-			if (d == owner)
-				continue;
-			int can = 0;
-			if (hipDeviceCanAccessPeer(&can, d, owner) != hipSuccess || !can) {
-				bad++;
-				continue;
-			}
-			if (hipSetDevice(d) == hipSuccess) {
-				const hipError_t e = hipDeviceEnablePeerAccess(owner, 0);
-				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-					bad++;
-			} else {
-				bad++;
-			}
-			(void)hipGetLastError();
-		}
-		HIP_TRY(hipSetDevice(cur));
+	for (int i = 0; i < n_devices; i++) {
+		int can = devices[i] == owner;
+		if (!can && (hipDeviceCanAccessPeer(&can, devices[i], owner) != hipSuccess || !can))
+			bad++;
 	}
+	(void)hipGetLastError();
 	if (bad)
 		return fail("%d of the %d device(s) cannot reach device %d's memory as peers", bad, n_devices, owner);
+	void *base = nullptr;
+	size_t bytes = 0;
+	if (vmm_find(ptr, &base, &bytes))
+		return grant_range(ptr, owner, devices, n_devices);
+	// a plain allocation: peer access is a property of the device pair, enabled from each of the devices
+	int cur = 0;
+	HIP_TRY(hipGetDevice(&cur));
+	for (int i = 0; i < n_devices; i++) {
+		if (devices[i] == owner)
+			continue;
+		if (hipSetDevice(devices[i]) == hipSuccess) {
+			const hipError_t e = hipDeviceEnablePeerAccess(owner, 0);
+			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+				bad++;
+		} else {
+			bad++;
+		}
+		(void)hipGetLastError();
+	}
+	HIP_TRY(hipSetDevice(cur));
+	if (bad)
+		return fail("peer access to device %d could not be enabled from %d device(s)", owner, bad);
 	return 0;
 }
 

@@ -105,8 +105,8 @@ int dwt_hip_grant_access(void *dev_ptr, const int *devices, int n_devices);
  * (`dst` receives the transform of `src`, as after a call; src != dst, device pointers, batch_stride may be 0
  * for one image) a few times: the scratch placement search (forward, two levels or more, "place_min_mib" MiB of
  * scratch or more: up to "place_tries" allocations behind growing spacers, each timed with the call itself,
- * the fastest kept) and the tile-height tuner (every level of 64 MiB or more: 64 / 32 / 16 row pairs forward,
- * 32 / 16 / 8 inverse).  Synchronous, one at a time per device; results are kept by the calling thread's
+ * the fastest kept) and the tile-height tuner (every level whose input is 512 MiB or more -- a level that fits the
+ * 256 MiB Infinity Cache cannot be measured by repeating it: 64 / 32 / 16 row pairs forward, 32 / 16 / 8 inverse).  Synchronous, one at a time per device; results are kept by the calling thread's
  * context per (wavelet, direction, width, height, batch) until dwt_hip_finish.  Same bits with and without.
  * The reference's analogue is explicit too: dwt_util_get_opt_stride, src/libdwt.c:20641-20707.
  * Programs that only know libdwt.h: DWT_HIP_TUNE=1 in the environment (option "tune_in_call") lets the first
@@ -129,7 +129,7 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * halos; 0 = through a staging copy of the image, the cross-check),
  * "il_exact_borders" (0 = no border strips at all: the top 8 rows / last 5 columns of a level keep the sweep's
  * rows-then-columns rounding -- NOT the reference's bits there, a few ulp, far inside 1e-5; opt-in like "fma"),
- * "tune_tiles" (1 = levels of 64 MiB and more use the tile height dwt_hip_tune measured for their shape;
+ * "tune_tiles" (1 = levels of 512 MiB and more use the tile height dwt_hip_tune measured for their shape;
  * 0 = always the launcher's rule), "tune_in_call" (1 = the first large call of a shape measures by itself;
  * default: DWT_HIP_TUNE), "place_tries" / "place_min_mib" (placement search, below), "place_max_gib" (cap of the
  * arena dwt_hip_alloc_batch / _volumes map for their search; 0 = free memory - 8 GiB).
@@ -143,6 +143,7 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * "vol_inplace_fused" (in-place calls: 1 = one fused pass per level in place over a snapshot of the tile
  * halos, forward and inverse; 0 = two passes per level).
  * Environment (diagnostics only, read once): DWT_HIP_PLACE_VERBOSE (the placement search prints its timings),
+ * DWT_HIP_TUNE_VERBOSE (the tile tuner prints every candidate's time),
  * DWT_HIP_PIPE_VERBOSE (a pipelined host-pointer call prints when its upload / download streams end),
  * DWT_HIP_PIPE_BAND (row pairs per band of such a call, a multiple of 64; default 256). */
 int dwt_hip_set_option(const char *name, int value);

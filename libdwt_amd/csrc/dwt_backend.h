@@ -148,8 +148,9 @@ int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int ba
 int tune2d(Wavelet w, bool inverse, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db);
 bool stream_is_capturing();
 bool may_measure(); // inside dwt_hip_tune, or DWT_HIP_TUNE=1 / option "tune_in_call"
-int tuned_tile_pairs(Wavelet w, const FwdLevelArgs &a);
+int tuned_tile_pairs(Wavelet w, const FwdLevelArgs &a); // the measured choice for this level (packed; 0: none) ...
 int tuned_tile_pairs(Wavelet w, const InvLevelArgs &a);
+void apply_tile_choice(int choice, SweepTuning *t, bool inverse); // ... applied to the launch's tuning
 int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompose_one, int zero_padding, int batch, long src_bstride, long dst_bstride);
 int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decompose_one, int zero_padding, int batch, long src_bstride, long dst_bstride);
 bool level_fused_ok(const Geom &ge, int j); // level j runs on the fused sweeps (dense frame, both sides >= 2)

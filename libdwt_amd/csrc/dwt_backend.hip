@@ -283,7 +283,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			}
 			SweepTuning tune = g.tune;
 			if (!dbl && tune.tile_pairs <= 0)
-				tune.tile_pairs = tuned_tile_pairs(w, a); // 0: the launcher's own rule
+				apply_tile_choice(tuned_tile_pairs(w, a), &tune, false); // (nothing measured: the launcher's own rule)
 			prof_before(j);
 			hipError_t e = dbl ? launch_fwd_level_d(w, a, tune, g.stream)
 			                   : launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, tune, g.stream);
@@ -429,7 +429,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 			}
 			SweepTuning tune = g.tune;
 			if (!dbl && tune.tile_pairs <= 0)
-				tune.tile_pairs = tuned_tile_pairs(w, a);
+				apply_tile_choice(tuned_tile_pairs(w, a), &tune, true);
 			prof_before(j - 1);
 			hipError_t e = dbl ? launch_inv_level_d(w, a, tune, g.stream)
 			                   : launch_inv_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, tune, g.stream);

@@ -8,8 +8,8 @@ namespace dwtb {
 // The launcher's rule (64 row pairs per tile unless that leaves too few tiles) is within 1-2 % of the best
 // height for level 0 of most calls, but the best height of a level depends on more than its tile count --
 // level 1 of 32 images wants 32 pairs (735 against 765 us), level 0 of 8 images wants 64 (761 against 778),
-// both have 8192 tiles of 64 pairs; level 3 of 64 images wants 16 (113 against 141 us).  So a level that
-// moves 64 MiB or more is timed ONCE per (wavelet, width, height, batch) with 64, 32 and 16 pairs -- the level
+// both have 8192 tiles of 64 pairs; level 3 of 64 images wants 16 (113 against 141 us).  So a level whose
+// input is 512 MiB or more is timed ONCE per (wavelet, width, height, batch) with 64, 32 and 16 pairs -- the level
 // is idempotent while its input stands, which it does until the next level runs -- and the fastest height is
 // remembered by the calling thread's context.  Same bits with every height (tests: tile variants).  Measured
 // only inside dwt_hip_tune (or with DWT_HIP_TUNE=1): an ordinary transform call looks the height up and
@@ -23,7 +23,25 @@ bool may_measure()
 	return g.tuning || g.tune_in_call > 0;
 }
 
-static int tune_tile_pairs(unsigned long long key, std::initializer_list<int> heights, const std::function<hipError_t(const SweepTuning &)> &launch)
+// A measured choice: tile height, and (forward) columns per lane / ring depth where the candidate names them, packed
+// into one int: bits 0-15 row pairs, 16-23 columns per lane (0: the launcher's), 24-31 ring rows (0: the launcher's).
+struct TileCand {
+	int pairs, cpt, ring;
+};
+static int pack_choice(const TileCand &c) { return c.pairs | (c.cpt << 16) | (c.ring << 24); }
+
+void apply_tile_choice(int choice, SweepTuning *t, bool inverse)
+{
+	if (choice <= 0)
+		return;
+	t->tile_pairs = choice & 0xffff;
+	if ((choice >> 16) & 0xff)
+		t->cpt = (choice >> 16) & 0xff;
+	if ((choice >> 24) & 0xff)
+		(inverse ? t->ring_inv : t->ring) = (choice >> 24) & 0xff;
+}
+
+static int tune_tile_pairs(unsigned long long key, bool inverse, std::initializer_list<TileCand> cands, const std::function<hipError_t(const SweepTuning &)> &launch)
 {
 	auto it = g.tile_cache.find(key);
 	if (it != g.tile_cache.end())
@@ -35,19 +53,30 @@ static int tune_tile_pairs(unsigned long long key, std::initializer_list<int> he
 		return 0;
 	int best = 0;
 	float best_ms = 0;
-	for (int tp : heights) {
+	static const bool verbose = getenv("DWT_HIP_TUNE_VERBOSE") != nullptr;
+	for (const TileCand &c : cands) {
+		if ((c.cpt && g.tune.cpt) || (c.ring && (inverse ? g.tune.ring_inv != 8 : g.tune.ring != 0)))
+			continue; // a width / ring depth set by hand stands
 		SweepTuning t = g.tune;
-		t.tile_pairs = tp;
+		apply_tile_choice(pack_choice(c), &t, inverse);
+		// three launches, the faster of the last two (the first one warms the caches it can)
 		float ms = 0;
 		bool ok = true;
-		for (int r = 0; r < 2 && ok; r++) {
+		for (int r = 0; r < 3 && ok; r++) {
+			float one = 0;
 			hipEventRecord(e0, g.stream);
 			ok = launch(t) == hipSuccess;
 			hipEventRecord(e1, g.stream);
+			g.stat_launches++;
+			ok = ok && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&one, e0, e1) == hipSuccess;
+			if (r == 1 || (r == 2 && one < ms))
+				ms = one;
 		}
-		ok = ok && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+		if (verbose)
+			fprintf(stderr, "tune %s W %d: %d pairs, cpt %d, ring %d: %.1f us%s\n", inverse ? "inv" : "fwd", (int)((key >> 38) & 0xfffff), c.pairs, c.cpt, c.ring,
+				ms * 1e3, ok ? "" : " (failed)");
 		if (ok && (!best || ms < best_ms)) {
-			best = tp;
+			best = pack_choice(c);
 			best_ms = ms;
 		}
 	}
@@ -63,21 +92,35 @@ static unsigned long long tile_key(Wavelet w, bool inverse, int W, int H, int ba
 	return ((unsigned long long)w << 59) ^ ((unsigned long long)inverse << 58) ^ ((unsigned long long)W << 38) ^ ((unsigned long long)H << 18) ^ (unsigned long long)batch;
 }
 
+// Which levels are measured: those whose input does not fit the 256 MiB Infinity Cache.  The tuner launches a level
+// several times on the SAME input; a level of 64 ... 256 MiB (one 8192^2 image, its level 1) then runs out of that cache
+// and the ranking it gives does not hold for the call on fresh data -- round 5: one image tuned this way ran its inverse
+// at 172.8-180.8 us against 170.1-174.4 with the launcher's rule (scripts/r05/tuned_single.py).
+static bool tunable(int W, int H, int batch, int interleaved)
+{
+	return g.tune_tiles && !interleaved && (size_t)W * H * batch * sizeof(float) >= ((size_t)512 << 20) && W >= 1024 && H >= 256;
+}
+
+// the packed choice (apply_tile_choice) for a large forward level; 0: the launcher's own rule
 int tuned_tile_pairs(Wavelet w, const FwdLevelArgs &a)
 {
-	if (!g.tune_tiles || a.interleaved || (size_t)a.W * a.H * a.batch * sizeof(float) < ((size_t)64 << 20) || a.W < 1024 || a.H < 256)
+	if (!tunable(a.W, a.H, a.batch, a.interleaved))
 		return 0;
 	const Wavelet wk = (g.fma && w == kCdf97S) ? kCdf97SFma : w;
-	return tune_tile_pairs(tile_key(w, false, a.W, a.H, a.batch), {64, 32, 16}, [&](const SweepTuning &t) { return launch_fwd_level(wk, a, t, g.stream); });
+	// (round 5 also tried 128 pairs and the 256-column tile with the deep ring: never the fastest on a batch, and on one
+	// image -- 100.5 against 105.1 us in a variant scan -- inside the noise of where the image lies; scripts/r05/tuned_single.py)
+	return tune_tile_pairs(tile_key(w, false, a.W, a.H, a.batch), false, {{64, 0, 0}, {32, 0, 0}, {16, 0, 0}},
+		[&](const SweepTuning &t) { return launch_fwd_level(wk, a, t, g.stream); });
 }
 
 // the inverse levels alike (32 images of 8192^2: 16 pairs 520 against 507-510 Gsamples/s with the rule's 32)
 int tuned_tile_pairs(Wavelet w, const InvLevelArgs &a)
 {
-	if (!g.tune_tiles || a.interleaved || (size_t)a.W * a.H * a.batch * sizeof(float) < ((size_t)64 << 20) || a.W < 1024 || a.H < 256)
+	if (!tunable(a.W, a.H, a.batch, a.interleaved))
 		return 0;
 	const Wavelet wk = (g.fma && w == kCdf97S) ? kCdf97SFma : w;
-	return tune_tile_pairs(tile_key(w, true, a.W, a.H, a.batch), {32, 16, 8}, [&](const SweepTuning &t) { return launch_inv_level(wk, a, t, g.stream); });
+	return tune_tile_pairs(tile_key(w, true, a.W, a.H, a.batch), true, {{32, 0, 0}, {16, 0, 0}, {8, 0, 0}},
+		[&](const SweepTuning &t) { return launch_inv_level(wk, a, t, g.stream); });
 }
 // ---- placement of the LL scratch ------------------------------------------------------------------
 // The rate of a forward level depends on where in PHYSICAL memory its three streams lie relative to each

@@ -146,7 +146,7 @@ def test_tuning_in_four_slots_at_once(dwt, oracle):
     no deadlock, no out-of-memory, every slot ends up with measured tile heights, and the transforms that follow give
     the oracle's bits (spot-checked per shard) in exactly J launches per shard."""
     L = dwt.lib
-    n, J, per = 4096, 3, 2   # 2 x 4096^2 per shard: level 0 moves 128 MiB -> measured
+    n, J, per = 4096, 3, 8   # 8 x 4096^2 per shard: level 0 reads 512 MiB -> measured
     rng = np.random.default_rng(23)
     shards = [rng.random((per, n, n), dtype=np.float32) for _ in range(4)]
     srcs = [L.dwt_hip_malloc(s.nbytes) for s in shards]

@@ -1067,15 +1067,15 @@ def test_batch_sharded_over_devices_in_one_process(dwt, oracle, wname):
 
 
 def test_measured_tile_heights_do_not_change_the_bits(dwt, oracle):
-    """Large levels (64 MiB and more) get their tile height from dwt_hip_tune, which times 64 / 32 / 16 row pairs once
+    """Large levels (an input of 512 MiB and more) get their tile height from dwt_hip_tune, which times 64 / 32 / 16 row pairs once
     per shape: a scheduling choice only -- the batch's coefficients are the oracle's with measured heights, with the
     launcher's rule (tune_tiles = 0) and with measured heights again; the transform calls themselves measure nothing."""
     L = dwt.lib
-    nb, n, J = 5, 2048, 3
+    nb, n, J = 33, 2048, 3   # level 0: 528 MiB
     imgs = np.random.default_rng(61).random((nb, n, n), dtype=np.float32)
     src, dst = L.dwt_hip_malloc(imgs.nbytes), L.dwt_hip_malloc(imgs.nbytes)
     assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
-    want0, want4 = imgs[0].copy(), imgs[4].copy()
+    want0, want4 = imgs[0].copy(), imgs[nb - 1].copy()
     oracle.fwd("cdf97_2f_s", want0, J)
     oracle.fwd("cdf97_2f_s", want4, J)
     try:
@@ -1085,7 +1085,7 @@ def test_measured_tile_heights_do_not_change_the_bits(dwt, oracle):
             dwt.dwt_util_finish()  # forget what was measured
             before = dwt.get_option("tile_cache_size")
             dwt.tune("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
-            assert dwt.get_option("tile_cache_size") - before == (1 if tune else 0)  # level 0 is the one level of 64 MiB or more
+            assert dwt.get_option("tile_cache_size") - before == (1 if tune else 0)  # level 0 is the one level beyond the Infinity Cache
             assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
             launches = dwt.get_option("stat_launches")
             for _ in range(2):
@@ -1093,7 +1093,7 @@ def test_measured_tile_heights_do_not_change_the_bits(dwt, oracle):
             assert dwt.get_option("stat_launches") - launches == 2 * J, "a transform call is J launches, nothing else"
             got = np.empty_like(imgs)
             assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
-            assert np.array_equal(bits(got[0]), bits(want0)) and np.array_equal(bits(got[4]), bits(want4)), tune
+            assert np.array_equal(bits(got[0]), bits(want0)) and np.array_equal(bits(got[nb - 1]), bits(want4)), tune
     finally:
         dwt.set_option("tune_tiles", 1)
         L.dwt_hip_free(src)

@@ -166,142 +166,68 @@ void dwt_hip_sync(void)
 		hipStreamSynchronize(g.stream);
 }
 
+// One table for dwt_hip_set_option / dwt_hip_get_option: the option's name, where it lives in the calling thread's
+// context, whether measured tile heights depend on it (they are forgotten when it changes), how a value is normalised.
+namespace {
+enum OptKind { kPlain, kSweep /* tile heights were measured under it */, kBool, kNonNegative };
+struct Opt {
+	const char *name;
+	int *(*ref)(Ctx &);
+	OptKind kind;
+};
+#define DWT_OPT(name_, member_, kind_) {name_, [](Ctx &c) -> int * { return &c.member_; }, kind_}
+const Opt kOpts[] = {
+	DWT_OPT("generic", force_generic, kSweep), DWT_OPT("cpt", tune.cpt, kSweep), DWT_OPT("tile_pairs", tune.tile_pairs, kSweep),
+	DWT_OPT("waves", tune.waves, kSweep), DWT_OPT("xcd_swizzle", tune.xcd_swizzle, kSweep), DWT_OPT("ring", tune.ring, kSweep),
+	DWT_OPT("ring_inv", tune.ring_inv, kSweep), DWT_OPT("nt", tune.nt, kSweep), DWT_OPT("nt_auto", tune.nt_auto, kSweep),
+	DWT_OPT("fma", fma, kSweep), DWT_OPT("fused_d", fused_d, kPlain), DWT_OPT("il_exact_borders", il_exact_borders, kPlain),
+	DWT_OPT("il_inplace_shell", il_inplace_shell, kPlain), DWT_OPT("host_pipeline", host_pipeline, kPlain),
+	DWT_OPT("tune_tiles", tune_tiles, kPlain), DWT_OPT("tune_in_call", tune_in_call, kBool), DWT_OPT("place_tries", place_tries, kPlain),
+	DWT_OPT("place_min_mib", place_min_mib, kNonNegative), DWT_OPT("place_max_gib", place_max_gib, kNonNegative),
+	DWT_OPT("vol_ip_waves", vol.ip_waves, kPlain), DWT_OPT("vol_tile_pairs", vol.tile_pairs, kPlain), DWT_OPT("vol_nt", vol.nt, kPlain),
+	DWT_OPT("vol_fused", vol.fused, kPlain), DWT_OPT("vol_direct", vol.direct, kPlain), DWT_OPT("vol_whole", vol.whole, kPlain),
+	DWT_OPT("vol_inplace_fused", vol.inplace_fused, kBool), DWT_OPT("vol_swizzle", vol.swizzle, kPlain), DWT_OPT("vol_rows", vol.rows, kPlain),
+};
+#undef DWT_OPT
+const Opt *find_opt(const char *name)
+{
+	for (const Opt &o : kOpts)
+		if (!strcmp(name, o.name))
+			return &o;
+	return nullptr;
+}
+} // namespace
+
 int dwt_hip_set_option(const char *name, int value)
 {
-	// measured tile heights belong to the sweep options they were measured under
-	for (const char *k : {"generic", "cpt", "tile_pairs", "waves", "xcd_swizzle", "ring", "ring_inv", "nt", "nt_auto", "fma"})
-		if (!strcmp(name, k))
-			g.tile_cache.clear();
-	if (!strcmp(name, "generic"))
-		g.force_generic = value;
-	else if (!strcmp(name, "cpt"))
-		g.tune.cpt = value;
-	else if (!strcmp(name, "tile_pairs"))
-		g.tune.tile_pairs = value;
-	else if (!strcmp(name, "waves"))
-		g.tune.waves = value;
-	else if (!strcmp(name, "xcd_swizzle"))
-		g.tune.xcd_swizzle = value;
-	else if (!strcmp(name, "ring"))
-		g.tune.ring = value;
-	else if (!strcmp(name, "nt_auto"))
-		g.tune.nt_auto = value;
-	else if (!strcmp(name, "il_exact_borders"))
-		g.il_exact_borders = value;
-	else if (!strcmp(name, "il_inplace_shell"))
-		g.il_inplace_shell = value;
-	else if (!strcmp(name, "host_pipeline"))
-		g.host_pipeline = value;
-	else if (!strcmp(name, "vol_ip_waves"))
-		g.vol.ip_waves = value;
-	else if (!strcmp(name, "nt"))
-		g.tune.nt = value;
-	else if (!strcmp(name, "ring_inv"))
-		g.tune.ring_inv = value;
-	else if (!strcmp(name, "fma"))
-		g.fma = value;
-	else if (!strcmp(name, "fused_d"))
-		g.fused_d = value;
-	else if (!strcmp(name, "tune_tiles"))
-		g.tune_tiles = value;
-	else if (!strcmp(name, "place_tries"))
-		g.place_tries = value;
-	else if (!strcmp(name, "place_min_mib"))
-		g.place_min_mib = value < 0 ? 0 : value;
-	else if (!strcmp(name, "place_max_gib"))
-		g.place_max_gib = value < 0 ? 0 : value;
-	else if (!strcmp(name, "tune_in_call"))
-		g.tune_in_call = value ? 1 : 0;
-	else if (!strcmp(name, "vol_tile_pairs"))
-		g.vol.tile_pairs = value;
-	else if (!strcmp(name, "vol_nt"))
-		g.vol.nt = value;
-	else if (!strcmp(name, "vol_fused"))
-		g.vol.fused = value;
-	else if (!strcmp(name, "vol_direct"))
-		g.vol.direct = value;
-	else if (!strcmp(name, "vol_whole"))
-		g.vol.whole = value;
-	else if (!strcmp(name, "vol_inplace_fused"))
-		g.vol.inplace_fused = value ? 1 : 0;
-	else if (!strcmp(name, "vol_swizzle"))
-		g.vol.swizzle = value;
-	else if (!strcmp(name, "vol_rows"))
-		g.vol.rows = value;
-	else
-		return fail("unknown option '%s'", name);
+	const Opt *o = name ? find_opt(name) : nullptr;
+	if (!o)
+		return fail("unknown option '%s'", name ? name : "(null)");
+	if (o->kind == kSweep)
+		g.tile_cache.clear();
+	*o->ref(g) = o->kind == kBool ? (value ? 1 : 0) : (o->kind == kNonNegative && value < 0) ? 0 : value;
 	return 0;
 }
 
 int dwt_hip_get_option(const char *name)
 {
-	if (!strcmp(name, "generic"))
-		return g.force_generic;
-	if (!strcmp(name, "cpt"))
-		return g.tune.cpt;
-	if (!strcmp(name, "tile_pairs"))
-		return g.tune.tile_pairs;
-	if (!strcmp(name, "waves"))
-		return g.tune.waves;
-	if (!strcmp(name, "xcd_swizzle"))
-		return g.tune.xcd_swizzle;
-	if (!strcmp(name, "ring"))
-		return g.tune.ring;
-	if (!strcmp(name, "nt_auto"))
-		return g.tune.nt_auto;
-	if (!strcmp(name, "il_exact_borders"))
-		return g.il_exact_borders;
-	if (!strcmp(name, "il_inplace_shell"))
-		return g.il_inplace_shell;
-	if (!strcmp(name, "host_pipeline"))
-		return g.host_pipeline;
-	if (!strcmp(name, "vol_ip_waves"))
-		return g.vol.ip_waves;
-	if (!strcmp(name, "nt"))
-		return g.tune.nt;
-	if (!strcmp(name, "ring_inv"))
-		return g.tune.ring_inv;
-	if (!strcmp(name, "vol_swizzle"))
-		return g.vol.swizzle;
-	if (!strcmp(name, "vol_rows"))
-		return g.vol.rows;
-	if (!strcmp(name, "fma"))
-		return g.fma;
-	if (!strcmp(name, "fused_d"))
-		return g.fused_d;
-	if (!strcmp(name, "vol_tile_pairs"))
-		return g.vol.tile_pairs;
-	if (!strcmp(name, "vol_nt"))
-		return g.vol.nt;
-	if (!strcmp(name, "vol_fused"))
-		return g.vol.fused;
-	if (!strcmp(name, "vol_direct"))
-		return g.vol.direct;
-	if (!strcmp(name, "vol_whole"))
-		return g.vol.whole;
-	if (!strcmp(name, "vol_inplace_fused"))
-		return g.vol.inplace_fused;
-	if (!strcmp(name, "tune_tiles"))
-		return g.tune_tiles;
-	if (!strcmp(name, "place_tries"))
-		return g.place_tries;
-	if (!strcmp(name, "place_min_mib"))
-		return g.place_min_mib;
-	if (!strcmp(name, "place_max_gib"))
-		return g.place_max_gib;
+	if (!name)
+		return -1;
+	// read-only figures of the calling thread's context
 	if (!strcmp(name, "tune_in_call"))
-		return may_measure() && !g.tuning ? 1 : 0;
+		return may_measure() && !g.tuning ? 1 : 0; // (DWT_HIP_TUNE is read on first use)
+	if (!strcmp(name, "place_last_tries")) // candidates the last placement search timed (0: none ran)
+		return g.place_n;
+	if (!strcmp(name, "place_last_best"))
+		return g.place_best;
 	if (!strcmp(name, "stat_launches")) // kernel launches of this context's 2-D drivers so far (tests)
 		return (int)(g.stat_launches & 0x7fffffff);
 	if (!strcmp(name, "stat_allocs"))   // device allocations of this context's 2-D drivers so far (tests)
 		return (int)(g.stat_allocs & 0x7fffffff);
 	if (!strcmp(name, "tile_cache_size"))
 		return (int)g.tile_cache.size();
-	if (!strcmp(name, "place_last_tries")) // candidates the last placement search timed (0: none ran)
-		return g.place_n;
-	if (!strcmp(name, "place_last_best"))
-		return g.place_best;
-	return -1;
+	const Opt *o = find_opt(name);
+	return o ? *o->ref(g) : -1;
 }
 
 int dwt_hip_is_device_pointer(const void *p)

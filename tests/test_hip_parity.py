@@ -1132,6 +1132,19 @@ def test_randomised_soak():
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, (out.stdout[-2000:], out.stderr[-1000:])
 
 
+def test_calls_are_graph_capturable():
+    """scripts/graph_replay.py: device-pointer calls captured into a HIP graph and replayed give the eager call's bits --
+    a call is launches on the caller's stream and nothing else (no allocation, no synchronisation, no measurement)."""
+    import os
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "graph_replay.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
 @pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
 @pytest.mark.parametrize("shape,levels", [((4096, 8192), 5), ((8192, 8192), 5), ((5001, 4097), 3), ((8192, 2100), 1), ((2049, 8200), -1), ((16390, 1100), 2)],
                          ids=lambda v: str(v))

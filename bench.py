@@ -75,7 +75,7 @@ def _log_dir():
         return tempfile.gettempdir()
 
 
-def launch_ranks(n, argv, timeout_s=420.0, grace_s=10.0):
+def launch_ranks(n, argv, timeout_s=600.0, grace_s=10.0):
     """Start `n` rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
     environment) and relay rank 0's JSON line.  The parent watches ALL children: when any of
     them exits non-zero the others get `grace_s` seconds and are then terminated (exactly the
@@ -1215,10 +1215,11 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the single-image entry timings")
     ap.add_argument("--no-sweep", action="store_true", help="skip the shard-size sweep (N = 1)")
     ap.add_argument("--no-split", action="store_true", help="skip the RCCL scatter/gather timing (N > 1)")
-    ap.add_argument("--timeout", type=float, default=420.0,
+    ap.add_argument("--timeout", type=float, default=600.0,
                     help="whole-run deadline in seconds: the launcher terminates its ranks, a rank prints what it has and leaves")
     ap.add_argument("--split-timeout", type=float, default=90.0, help="deadline of the RCCL batch-split side measurement")
-    ap.add_argument("--pg-timeout", type=float, default=180.0, help="process-group rendezvous / collective timeout")
+    ap.add_argument("--pg-timeout", type=float, default=300.0,
+                    help="process-group rendezvous / collective timeout (the first `import torch` of eight ranks on a fresh box takes minutes)")
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")
     ap.add_argument("--workload", default="headline", choices=["headline", "config3", "config4", "config5"],
                     help="headline = BASELINE.json's metric (default); config3/4/5 = the other BASELINE configs, same JSON contract")

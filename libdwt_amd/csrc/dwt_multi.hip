@@ -125,12 +125,23 @@ static int slot_job(SlotWorker *wk, const SlotOpts &opts, int device, int root_d
 	if (dwt_hip_set_device(device))
 		return 1;
 	opts.apply();
-	if (wk->device != device) { // the slot moved to another device: its staging is on the old one
+	if (wk->device != device) { // the slot moved to another device: its staging, streams and events are on the old one
 		for (int k = 0; k < 4; k++) {
 			if (wk->stage[k])
 				dev_free(wk->stage[k]);
 			wk->stage[k] = nullptr;
 			wk->stage_bytes[k] = 0;
+		}
+		if (wk->cin) {
+			hipStreamDestroy(wk->cin);
+			hipStreamDestroy(wk->cout);
+			for (int k = 0; k < 2; k++) {
+				hipEventDestroy(wk->ev_in[k]);
+				hipEventDestroy(wk->ev_done[k]);
+				hipEventDestroy(wk->ev_out[k]);
+			}
+			wk->cin = wk->cout = nullptr;
+			(void)hipGetLastError();
 		}
 		wk->device = device;
 		if (device != root_device) {

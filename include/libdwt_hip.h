@@ -123,6 +123,8 @@ void dwt_hip_alloc_batch_report(int *chunks, int *dst_tried, int *ll_tried, int 
  * non-temporal too, 15 = 7 with the neighbour taps by wavefront shifts instead of LDS reads), "nt_auto"
  * (1 = policy 3 by itself when a launch's LL bands exceed 1 GiB), "fma" (1 = contracted lifting steps:
  * NOT the reference's rounding, within 1e-5), "fused_d" (0 = double precision through the exact line passes),
+ * "ride_copy" (1 = in-place Mallat calls on one image: the copy of level 0's staged subbands rides along with the deeper
+ * levels' launches as extra workgroups; 0 = a launch of its own, the cross-check) and "ride_mib" (MiB of it per small level),
  * "host_pipeline" (1 = host-pointer calls on images of 64 MiB and more run band by band under their own
  * PCIe transfers, the caller's memory pinned in place for the call; 0 = upload, transform, download),
  * "il_inplace_shell" (1 = in-place calls of the interleaved entries run level 0 in place over a snapshot of the tile

@@ -74,6 +74,8 @@ struct Ctx {
 	double place_ms[8] = {0};   // what the last search measured, per candidate
 	int place_n = 0, place_best = -1;
 	int fused_d = 1; // double-precision wavelets through the fused sweeps (0: exact line passes only)
+	int ride_copy = 1; // in-place calls on one image: the staged subbands' copy rides along with the deeper levels' launches (0: a launch of its own)
+	int ride_mib = 32; // ... MiB of it per small level (8192^2: 8 / 16 / 24 / 32 / 48 MiB: forward 202 / 202 / 199 / 199 / 199 us, inverse 224 / 227 / 225 / 224 / 229)
 	// profiling
 	int prof_on = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -59,7 +59,7 @@ bool skip_single(Wavelet w) { return w == kCdf97S; } // only the 9/7 drivers gua
 struct Rect {
 	long dx, dy, sx, sy, w, h;
 };
-int copy_rects_on(hipStream_t st, Img dst, Img src, const Rect *rc, int n, int policy = 3)
+static CopyRects make_copy_rects(Img dst, Img src, const Rect *rc, int n, int policy)
 {
 	CopyRects r{};
 	r.n = 0;
@@ -75,12 +75,50 @@ int copy_rects_on(hipStream_t st, Img dst, Img src, const Rect *rc, int n, int p
 		r.wbytes[i] = (int)(rc[k].w * dst.es);
 		r.h[i] = (int)rc[k].h;
 	}
-	hipError_t e = launch_copy_rects(r, st);
+	return r;
+}
+
+int copy_rects_on(hipStream_t st, Img dst, Img src, const Rect *rc, int n, int policy = 3)
+{
+	hipError_t e = launch_copy_rects(make_copy_rects(dst, src, rc, n, policy), st);
 	g.stat_launches++;
 	if (e != hipSuccess)
 		return fail("rectangle copy launch failed: %s", hipGetErrorString(e));
 	return 0;
 }
+
+// A rectangle copy that RIDES ALONG with the levels it does not depend on (one image, in place: the staged subbands of
+// level 0 going back / aside): its blocks are handed out to those levels' launches as extra workgroups behind their
+// tiles (FwdLevelArgs::ride).  The levels below level 0 of one image are latency-bound -- one round of waves, 9-33 us
+// each, the memory system mostly idle -- and the copy is bandwidth-bound (402 MB, 62 us as a launch of its own): together
+// they take what the larger of the two takes.  Whatever is left when the levels are through goes out as a plain launch.
+struct RideCopy {
+	CopyRects r;
+	int next = 0, total = 0;
+	bool on = false;
+	// blocks for a level with `own_bytes` of input when `carriers_after` later launches can take some too
+	int share(size_t own_bytes, int carriers_after) const
+	{
+		const int left = total - next;
+		const int small = std::min(left, g.ride_mib * 32); // blocks of 32 KiB
+		if (carriers_after <= 0)
+			return left;
+		if (own_bytes <= ((size_t)32 << 20))
+			return small;
+		return std::max(small, left - carriers_after * g.ride_mib * 32);
+	}
+	int flush()
+	{
+		if (!on || next >= total)
+			return 0;
+		hipError_t e = launch_copy_rects_range(r, next, total, g.stream);
+		g.stat_launches++;
+		next = total;
+		if (e != hipSuccess)
+			return fail("rectangle copy launch failed: %s", hipGetErrorString(e));
+		return 0;
+	}
+};
 
 int copy_rect_on(hipStream_t st, Img dst, long dx, long dy, Img src, long sx_, long sy_, long w, long h)
 {
@@ -233,6 +271,14 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 	// where the running LL band lives: -1 = in `cur` image (src before level 0, dst after), else scratch index
 	int ll_in = -1;
 	Img cur = src;
+	RideCopy ride;
+	// the fused levels from j on that can carry copy blocks (one image, a sweep variant with the ride-along kernel)
+	auto carriers_from = [&](int j0) {
+		int n = 0;
+		for (int j = j0; j < J && level_fused_ok(ge, j); j++)
+			n += !dbl && sweep_ride_ok(g.tune, ge.Wo(j), ge.Ho(j), batch, false);
+		return n;
+	};
 	for (int j = 0; j < J; j++) {
 		const int Wo = ge.Wo(j), Ho = ge.Ho(j), Wi = ge.Wi(j), Hi = ge.Hi(j);
 		const int Wd = ge.Wo(j + 1), Hd = ge.Ho(j + 1);
@@ -284,6 +330,12 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 			SweepTuning tune = g.tune;
 			if (!dbl && tune.tile_pairs <= 0)
 				apply_tile_choice(tuned_tile_pairs(w, a), &tune, false); // (nothing measured: the launcher's own rule)
+			if (ride.on && ride.next < ride.total && !dbl && sweep_ride_ok(tune, Wo, Ho, batch, false)) {
+				a.ride = &ride.r;
+				a.ride_lo = ride.next;
+				a.ride_hi = ride.next + ride.share((size_t)Wo * Ho * es, carriers_from(j + 1));
+				ride.next = a.ride_hi;
+			}
 			prof_before(j);
 			hipError_t e = dbl ? launch_fwd_level_d(w, a, tune, g.stream)
 			                   : launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, tune, g.stream);
@@ -295,7 +347,11 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				// quadrant too when it was written here (in line: on a side stream beside the deeper
 				// levels it measured 8-10 us slower, profiles/archive/r03_entries_summary.md)
 				const Rect rc[3] = {{Wd, 0, Wd, 0, Wo - Wd, Ho}, {0, Hd, 0, Hd, Wd, Ho - Hd}, {0, 0, 0, 0, last ? Wd : 0, Hd}};
-				if (copy_rects_on(g.stream, dst, hdst, rc, 3))
+				ride.r = make_copy_rects(dst, hdst, rc, 3, 3);
+				ride.total = copy_rects_plan(&ride.r);
+				ride.next = 0;
+				ride.on = g.ride_copy && ride.total > 0 && carriers_from(j + 1) > 0;
+				if (!ride.on && copy_rects_on(g.stream, dst, hdst, rc, 3))
 					return 1;
 			}
 			ll_in = ll_out;
@@ -304,6 +360,8 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 		}
 
 		// ---- generic level: exact line semantics, in place on dst ----
+		if (ride.flush()) // (the line passes borrow the staging image the copy still reads)
+			return 1;
 		if (batch != 1)
 			return fail("batched transforms need dense frames with both sides >= 2 at every level");
 		if (ll_in >= 0) {
@@ -345,7 +403,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				return 1;
 		}
 	}
-	return 0;
+	return ride.flush();
 }
 
 // ---- inverse ---------------------------------------------------------------------
@@ -376,6 +434,27 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 	long cur_bstride = src_bstride;
 	int ll_in = -1;         // -1: LL band is in `cur`; else scratch index
 	bool copied = false;
+	// In place (one image), every level fused: the final level would overwrite subbands it still reads, so they are
+	// moved aside first -- a copy that depends on none of the deeper levels and rides along with them (RideCopy)
+	RideCopy ride;
+	if (src.p == dst.p && batch == 1 && J >= 2 && g.ride_copy && !dbl) {
+		bool all = true;
+		int carriers = 0;
+		for (int j = J; j >= 1; j--)
+			all = all && fused_ok(j);
+		for (int j = J; j >= 2; j--)
+			carriers += sweep_ride_ok(g.tune, ge.Wo(j - 1), ge.Ho(j - 1), batch, true);
+		if (all && carriers > 0) {
+			const int Ws = ge.Wo(1), Hs = ge.Ho(1), Wo = ge.Wo(0), Ho = ge.Ho(0);
+			if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
+				return 1;
+			Img st{(char *)g.stage_img, dst.sx, es};
+			const Rect rc[2] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}};
+			ride.r = make_copy_rects(st, src, rc, 2, /* temporal both ways: the final level reads the staged subbands */ 0);
+			ride.total = copy_rects_plan(&ride.r);
+			ride.on = ride.total > 0;
+		}
+	}
 	for (int j = J; j >= 1; j--) {
 		const int Ws = ge.Wo(j), Hs = ge.Ho(j);       // subband sizes (= Mallat offsets)
 		const int Wo = ge.Wo(j - 1), Ho = ge.Ho(j - 1); // produced frame
@@ -411,10 +490,12 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 					if (grow(&g.stage_img, &g.stage_bytes, (size_t)dst.sx * Ho))
 						return 1;
 					Img st{(char *)g.stage_img, dst.sx, es};
-					// (in line, like the forward copy-back: started early on a side stream beside the deeper levels it
-					// measured slower)
 					const Rect rc[3] = {{Ws, 0, Ws, 0, Wo - Ws, Ho}, {0, Hs, 0, Hs, Ws, Ho - Hs}, {0, 0, 0, 0, ll_in < 0 ? Ws : 0, Hs}};
-					if (copy_rects_on(g.stream, st, cur, rc, 3, /* temporal both ways: the final level reads the staged subbands (233 against 237 us) */ 0))
+					if (ride.on) {
+						// (most of it went with the deeper levels' launches; what is left goes now)
+						if (ride.flush())
+							return 1;
+					} else if (copy_rects_on(g.stream, st, cur, rc, 3, /* temporal both ways: the final level reads the staged subbands (233 against 237 us) */ 0))
 						return 1;
 					a.in_h = st.p;
 					a.h_bstride = 0;
@@ -430,6 +511,15 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 			SweepTuning tune = g.tune;
 			if (!dbl && tune.tile_pairs <= 0)
 				apply_tile_choice(tuned_tile_pairs(w, a), &tune, true);
+			if (ride.on && !last && ride.next < ride.total && sweep_ride_ok(tune, Wo, Ho, batch, true)) {
+				int after = 0;
+				for (int m = j - 1; m >= 2; m--)
+					after += sweep_ride_ok(g.tune, ge.Wo(m - 1), ge.Ho(m - 1), batch, true);
+				a.ride = &ride.r;
+				a.ride_lo = ride.next;
+				a.ride_hi = ride.next + ride.share((size_t)Wo * Ho * es, after);
+				ride.next = a.ride_hi;
+			}
 			prof_before(j - 1);
 			hipError_t e = dbl ? launch_inv_level_d(w, a, tune, g.stream)
 			                   : launch_inv_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, tune, g.stream);

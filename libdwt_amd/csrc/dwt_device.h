@@ -174,11 +174,11 @@ static __device__ __forceinline__ unsigned lds_offset(const void *p)
 // Workgroup -> tile mapping shared by both sweeps.  Each XCD has its own L2 and
 // workgroups are dealt round-robin over the 8 XCDs, so with `swz` consecutive
 // tiles are handed to the same XCD (neighbouring tiles share halo lines).
-static __device__ __forceinline__ int tile_block_id(int swz, int first = 0)
+static __device__ __forceinline__ int tile_block_id(int swz, int first = 0, int tile_blocks = 0)
 {
-	// (`first`: leading workgroups of the launch that do not take tiles)
+	// (`first`: leading workgroups of the launch that do not take tiles; `tile_blocks` > 0: trailing ones neither)
 	int b = blockIdx.x - first;
-	const int nb = gridDim.x - first;
+	const int nb = tile_blocks > 0 ? tile_blocks : gridDim.x - first;
 	if (swz && (nb & 7) == 0)
 		b = (b & 7) * (nb >> 3) + (b >> 3);
 	return b;
@@ -205,6 +205,46 @@ static __device__ __forceinline__ void wg_barrier_lds()
 {
 	// LDS traffic of this wave done, then the barrier; outstanding LDS-DMA keeps flying
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One block of a rectangle copy (CopyRects): 8 rows x 4 KiB per workgroup of 256 threads, 16 B per lane, rows as
+// buffers (any 4-byte alignment; the dwords past a row's end are zero-filled / dropped by the bounds check).  Rows past
+// the rectangle's end load the last row again (never stored): straight-line loads, all eight in flight (with the loads
+// under `if (i < rows)` the compiler built a 236-register kernel).
+template <bool NTL, bool NTS>
+static __device__ __forceinline__ void copy_rects_block(const CopyRects &r, int b)
+{
+	int k = 0;
+	while (k + 1 < r.n && b >= r.first_block[k + 1])
+		k++;
+	if (b >= r.first_block[r.n])
+		return;
+	b -= r.first_block[k];
+	constexpr int kRows = 8;
+	constexpr int seg = 256 * 16; // bytes per workgroup row segment
+	const int nbx = (r.wbytes[k] + seg - 1) / seg;
+	const int bx = b % nbx, by = b / nbx;
+	const unsigned x = (unsigned)bx * seg + threadIdx.x * 16;
+	const char *s = r.src[k] + (long)by * kRows * r.spitch[k];
+	char *d = r.dst[k] + (long)by * kRows * r.dpitch[k];
+	const int rows = min(kRows, r.h[k] - by * kRows);
+	u4 v[kRows];
+#pragma unroll
+	for (int i = 0; i < kRows; i++)
+		v[i] = load16_row<NTL>(row_rsrc(s + (long)min(i, rows - 1) * r.spitch[k], (unsigned)r.wbytes[k]), x);
+#pragma unroll
+	for (int i = 0; i < kRows; i++)
+		if (i < rows)
+			store16_row<NTS>(row_rsrc(d + (long)i * r.dpitch[k], (unsigned)r.wbytes[k]), x, v[i]);
+}
+
+// the trailing workgroups of a sweep launch that carry a copy along (FwdLevelArgs::ride)
+static __device__ __forceinline__ void ride_copy_block(const CopyRects &r, int b)
+{
+	if ((r.policy & 3) == 0)
+		copy_rects_block<false, false>(r, r.block0 + b);
+	else
+		copy_rects_block<true, true>(r, r.block0 + b);
 }
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }

@@ -253,59 +253,51 @@ __global__ __launch_bounds__(256) void k_compare(const char *__restrict__ p1, co
 template <bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void k_copy_rects(CopyRects r)
 {
-	int b = blockIdx.x, k = 0;
-	while (k + 1 < r.n && b >= r.first_block[k + 1])
-		k++;
-	b -= r.first_block[k];
-	constexpr int kRows = 8;
-	constexpr int seg = 256 * 16; // bytes per workgroup row segment
-	const int nbx = (r.wbytes[k] + seg - 1) / seg;
-	const int bx = b % nbx, by = b / nbx;
-	const unsigned x = (unsigned)bx * seg + threadIdx.x * 16;
-	const char *s = r.src[k] + (long)by * kRows * r.spitch[k];
-	char *d = r.dst[k] + (long)by * kRows * r.dpitch[k];
-	const int rows = min(kRows, r.h[k] - by * kRows);
-	// rows as buffers: 16 B per lane whatever the alignment, the dwords past a row's end are
-	// zero-filled / dropped by the bounds check.  Rows past the rectangle's end load the last row
-	// again (never stored): straight-line loads, all eight in flight (with the loads under
-	// `if (i < rows)` the compiler built a 236-register kernel).
-	u4 v[kRows];
-#pragma unroll
-	for (int i = 0; i < kRows; i++)
-		v[i] = load16_row<NTL>(row_rsrc(s + (long)min(i, rows - 1) * r.spitch[k], (unsigned)r.wbytes[k]), x);
-#pragma unroll
-	for (int i = 0; i < kRows; i++)
-		if (i < rows)
-			store16_row<NTS>(row_rsrc(d + (long)i * r.dpitch[k], (unsigned)r.wbytes[k]), x, v[i]);
+	copy_rects_block<NTL, NTS>(r, r.block0 + (int)blockIdx.x);
+}
+
+int copy_rects_plan(CopyRects *r)
+{
+	int n = 0;
+	for (int k = 0; k < r->n; k++) {
+		if (r->wbytes[k] <= 0 || r->h[k] <= 0)
+			continue;
+		r->src[n] = r->src[k]; r->dst[n] = r->dst[k]; r->spitch[n] = r->spitch[k]; r->dpitch[n] = r->dpitch[k];
+		r->wbytes[n] = r->wbytes[k]; r->h[n] = r->h[k];
+		if (r->wbytes[n] % 4 || ((uintptr_t)r->src[n] | (uintptr_t)r->dst[n] | (uintptr_t)r->spitch[n] | (uintptr_t)r->dpitch[n]) % 4)
+			return -1;
+		n++;
+	}
+	r->n = n;
+	const int seg = 256 * 16;
+	int total = 0;
+	for (int k = 0; k < n; k++) {
+		r->first_block[k] = total;
+		total += ((r->wbytes[k] + seg - 1) / seg) * ((r->h[k] + 7) / 8);
+	}
+	for (int k = n; k < 4; k++)
+		r->first_block[k] = total;
+	return total;
+}
+
+hipError_t launch_copy_rects_range(CopyRects r, int lo, int hi, hipStream_t s)
+{
+	if (hi <= lo)
+		return hipSuccess;
+	r.block0 = lo;
+	if ((r.policy & 3) == 0)
+		k_copy_rects<false, false><<<hi - lo, 256, 0, s>>>(r);
+	else
+		k_copy_rects<true, true><<<hi - lo, 256, 0, s>>>(r);
+	return hipGetLastError();
 }
 
 hipError_t launch_copy_rects(CopyRects r, hipStream_t s)
 {
-	int n = 0;
-	for (int k = 0; k < r.n; k++) {
-		if (r.wbytes[k] <= 0 || r.h[k] <= 0)
-			continue;
-		r.src[n] = r.src[k]; r.dst[n] = r.dst[k]; r.spitch[n] = r.spitch[k]; r.dpitch[n] = r.dpitch[k];
-		r.wbytes[n] = r.wbytes[k]; r.h[n] = r.h[k];
-		if (r.wbytes[n] % 4 || ((uintptr_t)r.src[n] | (uintptr_t)r.dst[n] | (uintptr_t)r.spitch[n] | (uintptr_t)r.dpitch[n]) % 4)
-			return hipErrorInvalidValue;
-		n++;
-	}
-	r.n = n;
-	if (n == 0)
-		return hipSuccess;
-	const int seg = 256 * 16;
-	int total = 0;
-	for (int k = 0; k < n; k++) {
-		r.first_block[k] = total;
-		total += ((r.wbytes[k] + seg - 1) / seg) * ((r.h[k] + 7) / 8);
-	}
-	r.first_block[n] = total;
-	if ((r.policy & 3) == 0)
-		k_copy_rects<false, false><<<total, 256, 0, s>>>(r);
-	else
-		k_copy_rects<true, true><<<total, 256, 0, s>>>(r);
-	return hipGetLastError();
+	const int total = copy_rects_plan(&r);
+	if (total < 0)
+		return hipErrorInvalidValue;
+	return launch_copy_rects_range(r, 0, total, s);
 }
 
 hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s)

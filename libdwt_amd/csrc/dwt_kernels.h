@@ -49,12 +49,15 @@ size_t il_shell_bytes(int W, int H, int tile_pairs);
 hipError_t launch_il_shell(const float *img, long pitch, int W, int H, int tile_pairs, float *scratch, IlShell *sh, hipStream_t s);
 // the tile height launch_fwd_level / launch_inv_level give an interleaved single-image level under these settings
 int il_sweep_tile_pairs(const SweepTuning &t, int W, int H, bool inverse);
+// whether launch_fwd_level / launch_inv_level take a kernel that can carry a copy along (FwdLevelArgs::ride) for this Mallat level
+bool sweep_ride_ok(const SweepTuning &t, int W, int H, int batch, bool inverse);
 
 // One decomposition level, forward, dense frame (size_o == size_i, W,H >= 2).
 // Reads the W x H region at `in`; writes LL (ceil(W/2) x ceil(H/2)) to `out_ll` and
 // the three detail subbands at their Mallat offsets relative to `out_h`:
 // HL at (0, Wd), LH at (Hd, 0), HH at (Hd, Wd), Wd = ceil(W/2), Hd = ceil(H/2).
 // Pitches are in ELEMENTS.  `batch` images lie `*_bstride` elements apart.
+struct CopyRects;
 struct FwdLevelArgs {
 	const void *in;
 	long in_pitch, in_bstride;
@@ -69,6 +72,11 @@ struct FwdLevelArgs {
 	int pair_lo = 0, pair_hi = 0; // pair_hi > 0: only the tiles that start at a row pair in [pair_lo, pair_hi) -- multiples of 64 --
 	                              // run (a level computed band by band while its input is still arriving over PCIe)
 	IlShell sh;          // interleaved only, in place (in == out_h, out_step 1): the neighbours' samples come from this snapshot
+	// Mallat layout, one image: copy blocks [ride_lo, ride_hi) of a rectangle copy that does not depend on this level run
+	// as extra workgroups BEHIND the level's tiles in the same launch (the staged subbands of an in-place call going back
+	// while the small, latency-bound levels run: launch_copy_rects_plan)
+	const CopyRects *ride = nullptr;
+	int ride_lo = 0, ride_hi = 0;
 	int out_step = 1;    // interleaved only: elements between neighbouring samples of an output row -- 2^j when the level
 	                     // is written straight to the lattice it lives on in a larger image (h_pitch: that lattice's row
 	                     // pitch); with il_ll the samples at (even row, even column) are then left to the deeper levels
@@ -87,6 +95,8 @@ struct InvLevelArgs {
 	int W, H, batch;
 	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
 	int pair_lo = 0, pair_hi = 0; // pair_hi > 0: only the tiles that start at a row pair in [pair_lo, pair_hi) run (see FwdLevelArgs)
+	const CopyRects *ride = nullptr; // see FwdLevelArgs
+	int ride_lo = 0, ride_hi = 0;
 	// interleaved only -- a level read straight from the lattice it lives on in a larger image:
 	IlShell sh;                   // in place (in_ll == out, in_step 1): the neighbours' samples come from this snapshot
 	int in_step = 1;              // elements between neighbouring samples of a source row (2^j on the lattice of level j)
@@ -241,8 +251,13 @@ struct CopyRects {
 	int first_block[4];
 	int n;
 	int policy = 3; // 3: non-temporal loads and stores (data moved once); 0: temporal both ways (the copy is read again at once)
+	int block0 = 0; // a launch's workgroup b copies block block0 + b
 };
 hipError_t launch_copy_rects(CopyRects r, hipStream_t s);
+// the same copy cut into blocks of 8 rows x 4 KiB: fills first_block / n, returns the number of blocks (< 0: bad
+// arguments); launch_copy_rects_range runs blocks [lo, hi) as a launch of their own
+int copy_rects_plan(CopyRects *r);
+hipError_t launch_copy_rects_range(CopyRects r, int lo, int hi, hipStream_t s);
 
 // device-side view helpers: pitch in BYTES, 4-byte elements
 hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s);

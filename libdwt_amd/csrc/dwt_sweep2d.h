@@ -10,6 +10,7 @@ struct SweepGeom {
 	int tile_pairs, ntx, swz;
 	int wave_horiz; // 1: the waves of a workgroup take horizontally adjacent tiles
 	int first = 0;  // k_*_sweep_x: the leading workgroups of the launch that take border strips, not tiles
+	int tile_blocks = 0; // k_*_sweep_r: the workgroups [0, tile_blocks) take tiles, the ones behind them copy blocks
 };
 
 static inline int pick_cpt(const SweepTuning &t, int W, bool inverse)

@@ -155,7 +155,7 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
 	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int bid = tile_block_id(g.swz, X ? g.first : 0);
+	const int bid = tile_block_id(g.swz, X ? g.first : 0, g.tile_blocks);
 	int tx, ty;
 	if (g.wave_horiz) {
 		const int ntxb = (g.ntx + nwv - 1) / nwv;
@@ -472,6 +472,17 @@ __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 	fwd_sweep_tile<W, CPT, RING, NT, IL, false>(a, g);
 }
 
+// a level with a rectangle copy riding along: the workgroups behind the tiles' copy blocks of `r` (FwdLevelArgs::ride)
+template <class W, int CPT, int RING, int NT>
+__global__ __launch_bounds__(256) void k_fwd_sweep_r(FwdLevelArgs a, SweepGeom g, CopyRects r)
+{
+	if ((int)blockIdx.x >= g.tile_blocks) {
+		ride_copy_block(r, (int)blockIdx.x - g.tile_blocks);
+		return;
+	}
+	fwd_sweep_tile<W, CPT, RING, NT, false, false>(a, g);
+}
+
 // one level of a phase-ordered interleaved transform, exact: workgroups [0, g.first) compute the border strips
 template <class W, int CPT, int RING, int NT>
 __global__ __launch_bounds__(256) void k_fwd_sweep_x(FwdLevelArgs a, SweepGeom g, IlStripArgs strip)
@@ -488,6 +499,21 @@ template <class W, int CPT, int RING, int NT, bool IL = false>
 static hipError_t fwd_launch(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, hipStream_t s)
 {
 	const size_t lds = (size_t)waves * RING * (64 * CPT + 8) * 4;
+	if constexpr (!IL && RING == 8 && (NT == 7 || NT == 3)) {
+		// (the variants a level of one image takes; the launcher has checked batch == 1 and four waves)
+		if (a.ride && a.ride_hi > a.ride_lo) {
+			if (hipError_t e = allow_lds((const void *)k_fwd_sweep_r<W, CPT, RING, NT>, lds))
+				return e;
+			SweepGeom gr = g;
+			gr.tile_blocks = (int)grid.x;
+			CopyRects r = *a.ride;
+			r.block0 = a.ride_lo;
+			k_fwd_sweep_r<W, CPT, RING, NT><<<dim3(grid.x + (unsigned)(a.ride_hi - a.ride_lo), 1), 64 * waves, lds, s>>>(a, gr, r);
+			return hipGetLastError();
+		}
+	}
+	if (a.ride && a.ride_hi > a.ride_lo)
+		return hipErrorInvalidValue; // the caller asked for a variant that has no ride-along kernel
 	if (hipError_t e = allow_lds((const void *)k_fwd_sweep<W, CPT, RING, NT, IL>, lds))
 		return e;
 	k_fwd_sweep<W, CPT, RING, NT, IL><<<grid, 64 * waves, lds, s>>>(a, g);
@@ -564,6 +590,8 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 		grid = dim3(g.ntx * ((nty + waves - 1) / waves), a.batch);
 	if (a.sh.rows && (!a.interleaved || a.batch != 1 || a.out_step != 1 || g.tile_pairs != a.sh.tile_pairs))
 		return hipErrorInvalidValue; // the snapshot of an in-place level was taken for other tiles
+	if (a.ride && a.ride_hi > a.ride_lo && (a.interleaved || a.batch != 1 || waves != 4 || tt.ring != 8 || a.temporal || (tt.nt & 8)))
+		return hipErrorInvalidValue; // (fwd_ride_ok says when a copy may ride along)
 	if (a.interleaved) {
 		// 3-D path: float 9/7 only; always 4 columns per lane so that each row leaves the
 		// wave as ONE contiguous 16 B/lane store (two strided stores per row cost 40 %)
@@ -596,6 +624,24 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	if (tt.nt_auto && (tt.nt & 12) == 4 && (size_t)a.batch * ((a.W + 1) / 2) * ((a.H + 1) / 2) * sizeof(typename W::T) >= ((size_t)1 << 30))
 		tt.nt = 3;
 	return cpt == 8 ? fwd_pick<W, 8>(a, g, grid, waves, tt, s) : fwd_pick<W, 4>(a, g, grid, waves, tt, s);
+}
+
+// whether launch_fwd_level / launch_inv_level would take a kernel that can carry a copy along for this level
+bool sweep_ride_ok(const SweepTuning &t, int W, int H, int batch, bool inverse)
+{
+	if (batch != 1 || W < 2 || H < 2 || !(t.waves >= 1 && t.waves <= 4 ? t.waves == 4 : true) || (t.nt & 8))
+		return false;
+	if (inverse)
+		return t.ring_inv != 16;
+	if (t.ring == 16)
+		return false;
+	if (t.ring == 8)
+		return true;
+	// the launcher's own ring choice (fwd_level_t): the deep ring from 3072 tiles on
+	const int cpt = pick_cpt(t, W, false);
+	const int tp = pick_tile_pairs(t, W, H, cpt, 1);
+	const long ntx = (W + 64 * cpt - 1) / (64 * cpt), nty = ((H + 1) / 2 + tp - 1) / tp;
+	return !(ntx >= 4 && ntx * nty >= 3072);
 }
 
 int il_sweep_tile_pairs(const SweepTuning &t, int W, int H, bool inverse)

@@ -44,7 +44,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
 	// wave-uniform on purpose: tile geometry, row indices and row pointers then live in SGPRs
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int bid = tile_block_id(g.swz, X ? g.first : 0);
+	const int bid = tile_block_id(g.swz, X ? g.first : 0, g.tile_blocks);
 	int tx, ty;
 	if (g.wave_horiz) {
 		const int ntxb = (g.ntx + nwv - 1) / nwv;
@@ -434,6 +434,17 @@ __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 }
 
 // interleaved input, 4 columns per lane; SP: split even rows (InvLevelArgs::in_ll2)
+// a level with a rectangle copy riding along (InvLevelArgs::ride; see k_fwd_sweep_r)
+template <class W, int CPT, int RING, int NT>
+__global__ __launch_bounds__(256) void k_inv_sweep_r(InvLevelArgs a, SweepGeom g, CopyRects r)
+{
+	if ((int)blockIdx.x >= g.tile_blocks) {
+		ride_copy_block(r, (int)blockIdx.x - g.tile_blocks);
+		return;
+	}
+	inv_sweep_tile<W, CPT, RING, NT, false, false>(a, g);
+}
+
 template <class W, int RING, int NT, bool SP>
 __global__ __launch_bounds__(256) void k_inv_sweep_il(InvLevelArgs a, SweepGeom g)
 {
@@ -455,6 +466,22 @@ template <class W, int CPT, int RING, int NT, bool IL>
 static hipError_t inv_launch(const InvLevelArgs &a, const SweepGeom &g, dim3 grid, int waves, hipStream_t s)
 {
 	const size_t lds = (size_t)waves * RING * (64 * CPT + 16) * 4;
+	if constexpr (!IL && RING == 8) {
+		if (a.ride && a.ride_hi > a.ride_lo) {
+			if (a.batch != 1 || waves != 4)
+				return hipErrorInvalidValue;
+			if (hipError_t e = allow_lds((const void *)k_inv_sweep_r<W, CPT, RING, NT>, lds))
+				return e;
+			SweepGeom gr = g;
+			gr.tile_blocks = (int)grid.x;
+			CopyRects r = *a.ride;
+			r.block0 = a.ride_lo;
+			k_inv_sweep_r<W, CPT, RING, NT><<<dim3(grid.x + (unsigned)(a.ride_hi - a.ride_lo), 1), 64 * waves, lds, s>>>(a, gr, r);
+			return hipGetLastError();
+		}
+	}
+	if (a.ride && a.ride_hi > a.ride_lo)
+		return hipErrorInvalidValue;
 	if (hipError_t e = allow_lds((const void *)k_inv_sweep<W, CPT, RING, NT, IL>, lds))
 		return e;
 	k_inv_sweep<W, CPT, RING, NT, IL><<<grid, 64 * waves, lds, s>>>(a, g);

@@ -1132,6 +1132,40 @@ def test_randomised_soak():
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, (out.stdout[-2000:], out.stderr[-1000:])
 
 
+@pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i", "cdf53_s", "cdf97_i"])
+def test_in_place_copy_rides_along_with_the_deeper_levels(dwt, oracle, wname):
+    """In-place device calls on one image stage level 0's detail subbands; the copy that brings them back (forward) / moves
+    them aside (inverse) is handed out block by block to the deeper levels' launches (option ride_copy, default on).  Same
+    bits as the oracle with the copy riding along -- a lot per level, a little per level plus a remainder launch, nothing --
+    for odd shapes, padded pitches and level counts from 1 up."""
+    ff, fi, dt = NAMES[wname]
+    rng = np.random.default_rng(31)
+    try:
+        for (h, w, pitch_e, J) in ((1030, 2100, 2100, 4), (2048, 4096, 4100, 5), (771, 517, 520, 3), (600, 900, 900, 1), (4096, 1024, 1024, -1)):
+            img = rand_img(rng, h, w, dt)
+            want = img.copy()
+            jw = oracle.fwd(ff, want, J)
+            rec = want.copy()
+            oracle.inv(fi, rec, jw)
+            for ride, mib in ((1, 32), (1, 1), (1, 4096), (0, 32)):
+                dwt.set_option("ride_copy", ride)
+                dwt.set_option("ride_mib", mib)
+                d = dwt.DeviceImage(h, w, pitch_bytes=pitch_e * 4)
+                buf = np.full((h, pitch_e), 9, dtype=dt)
+                buf[:, :w] = img
+                d.upload(buf)
+                assert getattr(dwt, "dwt_" + ff)(d.ptr, pitch_e * 4, 4, w, h, w, h, J) == jw
+                got = d.download(dt)
+                assert np.array_equal(bits(got[:, :w]), bits(want)) and np.all(got[:, w:] == 9), (h, w, J, ride, mib)
+                getattr(dwt, "dwt_" + fi)(d.ptr, pitch_e * 4, 4, w, h, w, h, jw)
+                got = d.download(dt)
+                assert np.array_equal(bits(got[:, :w]), bits(rec)) and np.all(got[:, w:] == 9), (h, w, J, ride, mib, "inverse")
+                d.free()
+    finally:
+        dwt.set_option("ride_copy", 1)
+        dwt.set_option("ride_mib", 32)
+
+
 def test_calls_are_graph_capturable():
     """scripts/graph_replay.py: device-pointer calls captured into a HIP graph and replayed give the eager call's bits --
     a call is launches on the caller's stream and nothing else (no allocation, no synchronisation, no measurement)."""

@@ -113,3 +113,11 @@ def test_shard_range_partitions():
     assert shard_range(256, 3, 8) == (96, 128)
     # five images over three ranks: 2, 2, 1 (b*3//5 = 0, 0, 1, 1, 2)
     assert [shard_range(5, r, 3) for r in range(3)] == [(0, 2), (2, 4), (4, 5)]
+    # the C entry a one-process caller uses gives the same bounds (no device call inside: runs without a GPU)
+    import libdwt_amd as dwt
+
+    for n in (1, 5, 7, 64, 256):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                a, cnt = dwt.shard_bounds(n, world, r)
+                assert (a, a + cnt) == shard_range(n, r, world)

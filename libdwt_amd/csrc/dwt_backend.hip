@@ -308,9 +308,10 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 					return 1;
 				hdst = Img{(char *)g.stage_img, dst.sx, es};
 				h_bstride = 0;
-				// the copy-back below reads the staged subbands at once: temporal stores leave them in the 256 MiB
-				// Infinity Cache (one 8192^2 image: 218.5 -> 205 us; the copy's own stores stay non-temporal: 204 against 219-225)
-				a.temporal = 1;
+				// a copy-back that follows at once reads the staged subbands out of the 256 MiB Infinity Cache when they were
+				// stored temporal (one 8192^2 image: 218.5 -> 205 us); a copy that rides along with the deeper levels is spread
+				// over their launches and gains nothing from it (202 against 205 us)
+				a.temporal = (g.ride_copy && carriers_from(j + 1) > 0) ? 0 : 1;
 			}
 			a.out_h = hdst.p;
 			a.h_pitch = hdst.sx / es;

@@ -13,6 +13,15 @@
  * variants and 17 loop schedules (src/libdwt.c:10551-10742); they all compute the
  * same thing, which is restated here once per wavelet as whole-line sweeps with
  * whole-sample symmetric reflection at both ends.
+ *
+ * Line ends of every float and double kernel (Mallat, interleaved and 3-D paths): the reference writes
+ * the reflected pair of taps as `2*c*x` (src/libdwt.c:9545-9552, 9873-9907, 10228-10360;
+ * 10994-11017, 2024-2083; src/dwt-simple.c:596-603), i.e. (2c)*x: one rounding, like c*(x+x), and the same bits
+ * -- EXCEPT when x+x overflows (|x| > FLT_MAX/2) while (2c)*x does not.  The restatement
+ * follows the reference ((2c)*x).  oracle_set_end_form(0) switches every such end to the
+ * reflected form c*(x+x): that is what the HIP kernels evaluate (reflection is applied to
+ * their load addresses), so the GPU tests on near-overflow data can separate this one
+ * documented difference from everything else.
  */
 #include "dwt_oracle.h"
 
@@ -87,10 +96,27 @@ static inline int refl(int i, int N)
 	return i < N ? i : period - i;
 }
 
-/* one lifting sweep over samples of given parity: a[i] += c*(a[i-1]+a[i+1]) */
+/* 1: line ends as the reference writes them, (2c)*x; 0: as reflection gives them, c*(x+x) */
+static int g_end_form = 1;
+
+void oracle_set_end_form(int faithful)
+{
+	g_end_form = faithful != 0;
+}
+
+/* the doubled tap of a line end, c applied to the pair (x, x): as the reference writes it, 2*c*x, or
+ * as reflection gives it, c*(x+x) */
+#define END2(c, x) (g_end_form ? 2 * (c) * (x) : (c) * ((x) + (x)))
+
+/* one lifting sweep over samples of given parity: a[i] += c*(a[i-1]+a[i+1]); at the two line
+ * ends both taps are one sample x and the reference adds 2*c*x (:9545, :9552, :9873, :9879) */
 static inline void sweep_s(float *a, int N, int parity, float c)
 {
 	for (int i = parity; i < N; i += 2) {
+		if (g_end_form && (i == 0 || i == N - 1)) {
+			a[i] += 2 * c * a[i == 0 ? 1 : N - 2];
+			continue;
+		}
 		const float l = a[refl(i - 1, N)];
 		const float r = a[refl(i + 1, N)];
 		a[i] += c * (l + r);
@@ -100,7 +126,7 @@ static inline void sweep_s(float *a, int N, int parity, float c)
 /* ---- 1-D CDF 9/7 float, forward (interleaved result: even = L, odd = H) ----
  * src/libdwt.c:10744-10800 calls accel_lift_op4s_s(tmp,1,N,-p1,u1,-p2,u2,s1,+1):
  * predict1, update1, predict2, update2 (:2331-2341), then even*=zeta, odd*=1/zeta
- * (:2344-2353); ends use 2*c*neighbour (:9545,:9873), equal to c*(x+x) in fp32. */
+ * (:2344-2353); ends use 2*c*neighbour (:9545,:9873): equal to c*(x+x) unless x+x overflows. */
 void oracle_line_cdf97_f_s(float *a, int N)
 {
 	if (N < 2) {
@@ -236,10 +262,10 @@ void oracle_line_cdf53_f_s(float *a, int N)
 	for (int i = 1; i < N - 2 + (N & 1); i += 2)
 		a[i] -= C53_P1 * (a[i - 1] + a[i + 1]);
 	if (N & 1)
-		a[N - 1] += 2 * C53_U1 * a[N - 2];
+		a[N - 1] += END2(C53_U1, a[N - 2]);
 	else
-		a[N - 1] -= 2 * C53_P1 * a[N - 2];
-	a[0] += 2 * C53_U1 * a[1];
+		a[N - 1] -= END2(C53_P1, a[N - 2]);
+	a[0] += END2(C53_U1, a[1]);
 	for (int i = 2; i < N - (N & 1); i += 2)
 		a[i] += C53_U1 * (a[i - 1] + a[i + 1]);
 	for (int i = 0; i < N; i += 2)
@@ -262,11 +288,11 @@ void oracle_line_cdf53_i_s(float *a, int N)
 		a[i] = a[i] * C53_S1;
 	for (int i = 2; i < N - (N & 1); i += 2)
 		a[i] -= C53_U1 * (a[i - 1] + a[i + 1]);
-	a[0] -= 2 * C53_U1 * a[1];
+	a[0] -= END2(C53_U1, a[1]);
 	if (N & 1)
-		a[N - 1] -= 2 * C53_U1 * a[N - 2];
+		a[N - 1] -= END2(C53_U1, a[N - 2]);
 	else
-		a[N - 1] += 2 * C53_P1 * a[N - 2];
+		a[N - 1] += END2(C53_P1, a[N - 2]);
 	for (int i = 1; i < N - 2 + (N & 1); i += 2)
 		a[i] += C53_P1 * (a[i - 1] + a[i + 1]);
 }
@@ -279,10 +305,10 @@ static void pu_fwd_d(double *a, int N, double p, double u)
 	for (int i = 1; i < N - 2 + (N & 1); i += 2)
 		a[i] -= p * (a[i - 1] + a[i + 1]);
 	if (N & 1)
-		a[N - 1] += 2 * u * a[N - 2];
+		a[N - 1] += END2(u, a[N - 2]);
 	else
-		a[N - 1] -= 2 * p * a[N - 2];
-	a[0] += 2 * u * a[1];
+		a[N - 1] -= END2(p, a[N - 2]);
+	a[0] += END2(u, a[1]);
 	for (int i = 2; i < N - (N & 1); i += 2)
 		a[i] += u * (a[i - 1] + a[i + 1]);
 }
@@ -291,11 +317,11 @@ static void pu_inv_d(double *a, int N, double p, double u)
 {
 	for (int i = 2; i < N - (N & 1); i += 2)
 		a[i] -= u * (a[i - 1] + a[i + 1]);
-	a[0] -= 2 * u * a[1];
+	a[0] -= END2(u, a[1]);
 	if (N & 1)
-		a[N - 1] -= 2 * u * a[N - 2];
+		a[N - 1] -= END2(u, a[N - 2]);
 	else
-		a[N - 1] += 2 * p * a[N - 2];
+		a[N - 1] += END2(p, a[N - 2]);
 	for (int i = 1; i < N - 2 + (N & 1); i += 2)
 		a[i] += p * (a[i - 1] + a[i + 1]);
 }
@@ -791,11 +817,14 @@ static void il_step(char *line, long stride, int N, int parity, float c, int lo,
 		lo++;
 	for (int t = lo; t <= hi; t += 2) {
 		float *x = il_at(line, stride, t);
-		if (t == 0)
+		if (t == 0 && g_end_form)
 			*x += 2 * c * *il_at(line, stride, 1);
-		else if (t == N - 1)
+		else if (t == N - 1 && g_end_form)
 			*x += 2 * c * *il_at(line, stride, N - 2);
-		else
+		else if (t == 0 || t == N - 1) {
+			const float m = *il_at(line, stride, t == 0 ? 1 : N - 2);
+			*x += c * (m + m);
+		} else
 			*x += c * (*il_at(line, stride, t - 1) + *il_at(line, stride, t + 1));
 	}
 }

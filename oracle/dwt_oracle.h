@@ -133,6 +133,9 @@ int oracle_ceil_div_pow2(int i, int j);
 /* number of OpenMP threads the 2-D drivers will use (1 if built without OpenMP) */
 int oracle_max_threads(void);
 void oracle_set_threads(int n);
+/* float / double line ends: 1 (default) = the reference's own (2c)*x, 0 = the reflected c*(x+x) the
+ * HIP kernels evaluate -- the two differ only where x+x overflows (dwt_oracle.c header) */
+void oracle_set_end_form(int faithful);
 
 #ifdef __cplusplus
 }

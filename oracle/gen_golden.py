@@ -216,6 +216,84 @@ def gen_volumes(ref, manifest):
     print(path, os.path.getsize(path), "bytes", len(meta), "cases")
 
 
+# ---- the whole float range (subnormals, +-0, near-overflow, +-Inf, NaN): tests/conftest.py full_range_floats ----
+# (entry pair key, shapes (h, w, j, decompose_one)); inputs are regenerated from the seed by the tests (the
+# generator is deterministic), small cases also stored in full; outputs of the larger ones by a sha256 over
+# their bits with every NaN replaced by one canonical NaN (payloads are outside the parity criterion)
+FR_ENTRIES = {
+    "cdf97_s": ("cdf97_2f_s", "cdf97_2i_s", np.float32),
+    "cdf53_s": ("cdf53_2f_s", "cdf53_2i_s", np.float32),
+    "cdf97_d": ("cdf97_2f_d", "cdf97_2i_d", np.float64),
+    "cdf53_d": ("cdf53_2f_d", "cdf53_2i_d", np.float64),
+    "cdf97_il": ("cdf97_2f_inplace_s", "cdf97_2i_inplace_s", np.float32),
+    "cdf53_il": ("cdf53_2f_inplace_s", "cdf53_2i_inplace_s", np.float32),
+}
+FR_CLASSES = [("subnormal", 0), ("tiny", 0), ("huge", 0), ("mixed", 0), ("mixed", 1)]
+FR_SHAPES = [(37, 53, -1, 0, True), (2, 7, -1, 1, True), (9, 1, -1, 1, True), (64, 80, 2, 0, True),
+             (300, 600, 3, 0, False), (515, 1030, -1, 0, False)]
+FR_VOLS = [((9, 7, 6), True), ((12, 40, 272), False), ((33, 70, 300), False)]
+
+
+def canonical_sha(a):
+    a = np.ascontiguousarray(a).copy()
+    a[np.isnan(a)] = np.nan
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def gen_float_range(ref, manifest):
+    import ctypes as C
+    import warnings
+
+    from conftest import full_range_floats
+
+    warnings.simplefilter("ignore")
+    arrays, meta = {}, []
+    seed = 9000
+    for wname, (ff, fi, dt) in FR_ENTRIES.items():
+        for klass, nf in FR_CLASSES:
+            for (h, w, j, d1, full) in FR_SHAPES:
+                if dt == np.float64 and not full:
+                    continue
+                seed += 1
+                src = full_range_floats(np.random.default_rng(seed), (h, w), dt, klass, bool(nf))
+                buf = src.copy()
+                jret = ref.fwd(ff, buf, j, decompose_one=d1)
+                fwd = buf.copy()
+                ref.inv(fi, buf, jret, decompose_one=d1)
+                name = f"{wname}.{klass}{'_nf' if nf else ''}.{h}x{w}"
+                m = {"name": name, "entry": wname, "klass": klass, "nonfinite": nf, "shape": (h, w), "j_in": j, "j_out": jret,
+                     "decompose_one": d1, "seed": seed, "full": full,
+                     "sha": {"in": canonical_sha(src), "fwd": canonical_sha(fwd), "inv": canonical_sha(buf)}}
+                if full:
+                    arrays[name + ".in"], arrays[name + ".fwd"], arrays[name + ".inv"] = src, fwd, buf.copy()
+                meta.append(m)
+
+    class Vol(C.Structure):
+        _fields_ = [("size_x", C.c_int), ("size_y", C.c_int), ("size_z", C.c_int), ("stride_x", C.c_size_t),
+                    ("stride_y", C.c_size_t), ("stride_z", C.c_size_t), ("data", C.c_void_p)]
+
+    for klass, nf in FR_CLASSES:
+        for shp, full in FR_VOLS:
+            seed += 1
+            flat = full_range_floats(np.random.default_rng(seed), (shp[0] * shp[1], shp[2]), np.float32, klass, bool(nf))
+            v = flat.reshape(shp).copy()
+            b = v.copy()
+            vs = Vol(shp[2], shp[1], shp[0], b.strides[2], b.strides[1], b.strides[0], b.ctypes.data)
+            ref.lib.cdf97_3f_ip_sep_horizontal_s(C.byref(vs))
+            f = b.copy()
+            ref.lib.cdf97_3i_ip_sep_horizontal_s(C.byref(vs))
+            name = f"vol.{klass}{'_nf' if nf else ''}.{shp[0]}x{shp[1]}x{shp[2]}"
+            m = {"name": name, "entry": "cdf97_3d", "klass": klass, "nonfinite": nf, "shape": shp, "seed": seed, "full": full,
+                 "sha": {"in": canonical_sha(v), "fwd": canonical_sha(f), "inv": canonical_sha(b)}}
+            if full:
+                arrays[name + ".in"], arrays[name + ".fwd"], arrays[name + ".inv"] = v, f, b.copy()
+            meta.append(m)
+    path = os.path.join(OUT, "float_range.npz")
+    np.savez_compressed(path, **arrays)
+    manifest["files"]["float_range.npz"] = {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "cases": meta}
+    print(path, os.path.getsize(path), "bytes", len(meta), "cases")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = Reference()
@@ -223,6 +301,13 @@ def main():
         with open(os.path.join(OUT, "manifest.json")) as f:
             manifest = json.load(f)
         gen_volumes(ref, manifest)
+        with open(os.path.join(OUT, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return
+    if sys.argv[1:] == ["float_range"]:
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_float_range(ref, manifest)
         with open(os.path.join(OUT, "manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1)
         return
@@ -345,6 +430,7 @@ def main():
 
     gen_multichannel(ref, manifest)
     gen_volumes(ref, manifest)
+    gen_float_range(ref, manifest)
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)

@@ -6,6 +6,7 @@ module.  `Oracle` wraps oracle/_build/libdwt_oracle.so (the CPU restatement) and
 sources by oracle/Makefile, present only where it was built).  Both expose the same
 numpy-level helpers so a test can swap one for the other.
 """
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -162,6 +163,7 @@ class Oracle(_Lib):
             getattr(L, n).argtypes = [_P, _I, _I, _I, _I, _I]
             getattr(L, n).restype = None
         L.oracle_set_threads.argtypes = [_I]
+        L.oracle_set_end_form.argtypes = [_I]
         L.oracle_max_threads.restype = _I
         # a GPU box exposes all host cores but only a share of them is ours: OpenMP with
         # hundreds of threads on a busy host is slower than 16
@@ -195,6 +197,17 @@ class Oracle(_Lib):
 
     def set_threads(self, n):
         self.lib.oracle_set_threads(n)
+
+    @contextlib.contextmanager
+    def reflected_ends(self):
+        """Within the block the float 9/7 line ends are evaluated as c*(x+x) -- what whole-sample
+        reflection of the taps gives and the HIP kernels compute -- instead of the reference's
+        (2c)*x.  Same bits unless x+x overflows (oracle/dwt_oracle.c header)."""
+        self.lib.oracle_set_end_form(0)
+        try:
+            yield self
+        finally:
+            self.lib.oracle_set_end_form(1)
 
 
 class Reference(_Lib):

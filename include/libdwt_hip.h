@@ -10,9 +10,14 @@
  *
  * Pointer rule for every transform entry: `src`/`dst`/`ptr` may be ordinary host
  * memory (any byte strides; staged through HBM, result copied back) or device
- * memory (hipMalloc / dwt_hip_malloc / a torch tensor's data_ptr; requires
- * stride_y == element size and stride_x a multiple of it; transformed in HBM, nothing
- * crosses PCIe).  Every wavelet runs on fused tile sweeps (float, int32 and, since round 2,
+ * memory (hipMalloc / dwt_hip_malloc / a torch tensor's data_ptr; transformed in HBM, nothing
+ * crosses PCIe).  Device images with adjacent, aligned elements (stride_y == element size, stride_x and
+ * the pointer multiples of it) are what the fused sweeps read and write directly.  Any other byte strides
+ * -- one channel of an interleaved multi-channel matrix as src/cvdwt.cpp:98-135 passes it (ptr = data +
+ * elemSize1*channel, stride_y = elemSize), odd pitches -- are packed into a dense image, transformed and
+ * spread back ON THE DEVICE, the device-side dwt_util_memcpy_stride_s / _i (src/system.c:102-164): only
+ * the image's own elements are written; rows must not overlap (stride_x >= (width-1)*stride_y + element
+ * size).  The batch and 3-D entries take dense rows only.  Every wavelet runs on fused tile sweeps (float, int32 and, since round 2,
  * double); the exact line-pass kernels serve sparse frames, single-line directions and accel 1.
  *
  * Threading: one context PER HOST THREAD (device binding, stream, workspace, options), so

@@ -353,18 +353,22 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	if (dev_src != dev_dst)
 		return fail("src and dst must both be host or both be device pointers");
 
-	if (dev_dst) {
-		if (stride_y != es || (stride_x % es) || stride_x < sox * es)
-			return fail("device images need stride_y == %d and stride_x a multiple of it >= width*%d (got %d, %d)", es, es, stride_x, stride_y);
+	if (dev_dst && stride_y == es && stride_x % es == 0 && stride_x >= sox * es && (uintptr_t)src % es == 0 && (uintptr_t)dst % es == 0) {
 		Img s{(char *)src, stride_x, es}, d{(char *)dst, stride_x, es};
 		if (!inverse && !decompose_one && (*j < 0 || *j >= 2) && place_ll_scratch(w, s, d, ge, *j, 1, 0, 0))
 			return 1;
 		return inverse ? inverse2d(w, s, d, ge, *j, decompose_one, zero_padding, 1, 0, 0)
 		               : forward2d(w, s, d, ge, j, decompose_one, zero_padding, 1, 0, 0);
 	}
+	// ---- a device image whose elements are not adjacent (one channel of an interleaved multi-channel image,
+	// src/cvdwt.cpp:98-135) or not aligned: the reference gathers every line through dwt_util_memcpy_stride_*
+	// (src/system.c:102-164); here the frame is packed into a dense image ON THE DEVICE, transformed there and spread
+	// back element by element (dwt_strided.hip) -- nothing crosses PCIe, nothing but the image's own elements is written
+	if (dev_dst && (stride_y < es || (long)stride_x < (long)(sox - 1) * stride_y + es))
+		return fail("device image: stride_y %d must be >= %d and stride_x %d >= (width-1)*stride_y + %d", stride_y, es, stride_x, es);
 
 	// ---- host pointers: stage the whole outer frame through HBM ----
-	if (ge.dense() && stride_y == es && es == 4) {
+	if (!dev_dst && ge.dense() && stride_y == es && es == 4) {
 		const int rc = inverse ? host_inverse_pipelined(w, src, dst, stride_x, sox, soy, *j, decompose_one)
 		                       : host_forward_pipelined(w, src, dst, stride_x, sox, soy, j, decompose_one);
 		if (rc >= 0)
@@ -375,8 +379,18 @@ int dwt_hip_transform2d(int wavelet, int inverse, const void *src, void *dst, in
 	if (grow(&g.host_a, &g.host_a_bytes, bytes) || grow(&g.host_b, &g.host_b_bytes, bytes))
 		return 1;
 	const bool s2 = (src != dst);
-	auto upload = [&](const void *hp, void *dp) -> int { return host_upload(hp, stride_x, stride_y, es, sox, soy, dp, pitch); };
-	auto download = [&](void *hp, const void *dp) -> int { return host_download(hp, stride_x, stride_y, es, sox, soy, dp, pitch); };
+	auto upload = [&](const void *hp, void *dp) -> int {
+		if (!dev_dst)
+			return host_upload(hp, stride_x, stride_y, es, sox, soy, dp, pitch);
+		const hipError_t e = launch_strided_pack(dp, pitch, hp, stride_x, stride_y, es, sox, soy, g.stream);
+		return e == hipSuccess ? 0 : fail("strided pack launch failed: %s", hipGetErrorString(e));
+	};
+	auto download = [&](void *hp, const void *dp) -> int {
+		if (!dev_dst)
+			return host_download(hp, stride_x, stride_y, es, sox, soy, dp, pitch);
+		const hipError_t e = launch_strided_unpack(hp, stride_x, stride_y, dp, pitch, es, sox, soy, g.stream);
+		return e == hipSuccess ? 0 : fail("strided unpack launch failed: %s", hipGetErrorString(e));
+	};
 	Img A{(char *)g.host_a, pitch, es}, B{(char *)g.host_b, pitch, es};
 	if (upload(src, A.p))
 		return 1;

@@ -449,23 +449,32 @@ int dwt_hip_transform2d_interleaved(int wavelet, int inverse, int flavour, const
 	const bool dev_src = dwt_hip_is_device_pointer(src), dev_dst = dwt_hip_is_device_pointer(dst);
 	if (dev_src != dev_dst)
 		return fail("src and dst must both be host or both be device pointers");
-	if (dev_dst) {
-		if (stride_y != 4 || (stride_x % 4) || stride_x < sox * 4)
-			return fail("device images need stride_y == 4 and stride_x a multiple of it >= width*4 (got %d, %d)", stride_x, stride_y);
+	if (dev_dst && stride_y == 4 && stride_x % 4 == 0 && stride_x >= sox * 4 && (uintptr_t)src % 4 == 0 && (uintptr_t)dst % 4 == 0) {
 		if (fixed)
 			return inplace_int2d(inverse != 0, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one);
 		return interleaved2d(w, inverse != 0, scale_single, Img{(char *)src, stride_x, 4}, Img{(char *)dst, stride_x, 4}, sox, soy, six, siy, j, decompose_one, dirs);
 	}
-	// host pointers: stage the outer frame through HBM (any byte strides)
+	if (dev_dst && (stride_y < 4 || (long)stride_x < (long)(sox - 1) * stride_y + 4))
+		return fail("device image: stride_y %d must be >= 4 and stride_x %d >= (width-1)*stride_y + 4", stride_y, stride_x);
+	// host pointers (any byte strides): the outer frame is staged through HBM; device images whose elements are not
+	// adjacent or not aligned: packed, transformed and spread back on the device (dwt_strided.hip)
 	const long pitch = align_up((long)sox * 4, 256);
 	if (grow(&g.host_a, &g.host_a_bytes, (size_t)pitch * soy))
 		return 1;
-	if (host_upload(src, stride_x, stride_y, 4, sox, soy, g.host_a, pitch))
+	if (dev_dst) {
+		if (hipError_t e = launch_strided_pack(g.host_a, pitch, src, stride_x, stride_y, 4, sox, soy, g.stream))
+			return fail("strided pack launch failed: %s", hipGetErrorString(e));
+	} else if (host_upload(src, stride_x, stride_y, 4, sox, soy, g.host_a, pitch))
 		return 1;
 	Img A{(char *)g.host_a, pitch, 4};
 	if (fixed ? inplace_int2d(inverse != 0, A, A, sox, soy, six, siy, j, decompose_one)
 	          : interleaved2d(w, inverse != 0, scale_single, A, A, sox, soy, six, siy, j, decompose_one, dirs))
 		return 1;
+	if (dev_dst) {
+		if (hipError_t e = launch_strided_unpack(dst, stride_x, stride_y, g.host_a, pitch, 4, sox, soy, g.stream))
+			return fail("strided unpack launch failed: %s", hipGetErrorString(e));
+		return 0;
+	}
 	return host_download(dst, stride_x, stride_y, 4, sox, soy, g.host_a, pitch);
 }
 

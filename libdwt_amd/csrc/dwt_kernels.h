@@ -259,6 +259,11 @@ hipError_t launch_copy_rects(CopyRects r, hipStream_t s);
 int copy_rects_plan(CopyRects *r);
 hipError_t launch_copy_rects_range(CopyRects r, int lo, int hi, hipStream_t s);
 
+// the strided gather / scatter (dwt_util_memcpy_stride_s / _i, src/system.c:102-164) on the device: w x h elements of
+// `es` bytes between a dense image (row pitch `pitch`) and one whose element (y, x) lies at y*sx + x*sy; all in BYTES
+hipError_t launch_strided_pack(void *dense, long pitch, const void *strided, long sx, long sy, int es, int w, int h, hipStream_t st);
+hipError_t launch_strided_unpack(void *strided, long sx, long sy, const void *dense, long pitch, int es, int w, int h, hipStream_t st);
+
 // device-side view helpers: pitch in BYTES, 4-byte elements
 hipError_t launch_conv_show(bool is_int, const void *src, void *dst, long pitch, int w, int h, hipStream_t s);
 hipError_t launch_compare(bool is_int, const void *p1, const void *p2, long pitch, int w, int h, unsigned *result, hipStream_t s);

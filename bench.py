@@ -637,26 +637,29 @@ def batch_split_times(torch, plane, src, total, n, rank, world, dev):
 
     dist = plane.dist
     lo, hi = B.shard_range(total, rank, world)
+    loop = world == 1  # --force-dist on one GPU: the block goes rank 0 -> rank 0 through RCCL's send / recv
     full = None
     if rank == 0:
         full = torch.empty((total, n, n), dtype=torch.float32, device=dev)
         full[lo:hi].copy_(src)
-    res = {}
+    res, intact = {}, None
     for rep in range(2):  # the first pass opens the RCCL point-to-point channels
         torch.cuda.synchronize()
         plane.barrier()
         t0 = time.perf_counter()
-        local = B.scatter_images(full, total, (n, n), torch.float32, dev)
+        local = B.scatter_images(full, total, (n, n), torch.float32, dev, loopback=loop)
         torch.cuda.synchronize()
         plane.barrier()
         t1 = time.perf_counter()
-        back = B.gather_images(local, total)
+        back = B.gather_images(local, total, loopback=loop)
+        if rep == 1 and rank == 0:
+            intact = bool(torch.equal(back, full))
         torch.cuda.synchronize()
         plane.barrier()
         t2 = time.perf_counter()
         res = {"scatter_ms": (t1 - t0) * 1e3, "gather_ms": (t2 - t1) * 1e3}
         del local, back
-    moved = (total - (hi - lo if rank == 0 else 0)) * n * n * 4
+    moved = (total - (hi - lo if rank == 0 and not loop else 0)) * n * n * 4
     t = torch.tensor([res["scatter_ms"], res["gather_ms"]], dtype=torch.float64, device=plane.dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     moved_t = torch.tensor([float(moved)], dtype=torch.float64, device=plane.dev)
@@ -665,7 +668,18 @@ def batch_split_times(torch, plane, src, total, n, rank, world, dev):
     b = float(moved_t[0])
     return {"scatter_ms": round(sc, 3), "gather_ms": round(ga, 3), "bytes_each_way": int(b),
             "scatter_GBps": round(b / sc / 1e6, 1), "gather_GBps": round(b / ga / 1e6, 1),
-            "how": "rank 0 -> all ranks and back, grouped isend/irecv (batch_isend_irecv), root-egress bound"}
+            "round_trip_intact": intact if rank == 0 else None,
+            "how": ("ONE rank (--force-dist rehearsal): the batch rank 0 -> rank 0 and back through RCCL's grouped send / recv, no xGMI hop"
+                    if loop else "rank 0 -> all ranks and back, grouped isend/irecv (batch_isend_irecv), root-egress bound")}
+
+
+def seeded_images(torch, gen, out, first):
+    """image k of the batch is seeded 1234 + k (its GLOBAL index, whatever rank holds it), generated on
+    the device it lives on -- so a rank's shard is the same data at every N and any image can be regenerated alone."""
+    for i in range(out.shape[0]):
+        gen.manual_seed(1234 + first + i)
+        torch.rand(out.shape[1:], generator=gen, out=out[i])
+    return out
 
 
 def raw_tensor(torch, dev, ptr, shape):
@@ -741,7 +755,7 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
         lo, hi = shard_range(total, rank, world)
         nb = hi - lo
         def make():
-            s_ = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
+            s_ = seeded_images(torch, gen, torch.empty((nb, n, n), device=dev, dtype=torch.float32), lo)
             return s_, torch.empty_like(s_)
         def run(b):
             dwt.transform2d_batch("cdf97_s", 0, b[0], b[1], n * n * 4, nb, n * 4, n, n, J)
@@ -802,8 +816,7 @@ def other_workload(args, dwt, torch, plane, world, rank, dev):
         dwt.set_option("place_tries", args.placements)
         p_src, p_dst = dwt.alloc_batch("cdf97_s", nb, n, n, J)
         bufs = (raw_tensor(torch, dev, p_src, (nb, n, n)), raw_tensor(torch, dev, p_dst, (nb, n, n)))
-        gen.manual_seed(1234 + rank)
-        torch.rand((nb, n, n), generator=gen, out=bufs[0])
+        seeded_images(torch, gen, bufs[0], lo)
         placement = {"by": "dwt_hip_alloc_batch", "attempts": [{"spacer_GiB": 0, "ms_per_step": round(first_ms, 4)}]}
         placement.update(dwt.alloc_batch_report())
     elif w == "config5" and args.placements > 1:
@@ -902,7 +915,12 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
 
-    use_dist = world > 1
+    # --force-dist: the distributed branch with whatever WORLD_SIZE is -- on one GPU the rehearsal of everything the first
+    # real N > 1 run executes for the first time (RCCL loads, communicator, first collective, gather_json, the batch
+    # split as a self send / recv): tests/test_hip_multi.py
+    use_dist = world > 1 or args.force_dist
+    if use_dist and "MASTER_PORT" not in os.environ:
+        os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     ndev = torch.cuda.device_count()  # does not initialise the GPU
     if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libdwt_amd has no CPU fallback)")
@@ -984,7 +1002,7 @@ def run_rank(args):
         return round(time.perf_counter() - t0, 3)
 
     dwt.set_option("place_tries", 1)
-    src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
+    src = seeded_images(torch, gen, torch.empty((nb, n, n), device=dev, dtype=torch.float32), lo)
     dst = src.clone() if args.inplace else torch.empty_like(src)
     tune_first_s = tune_shard(src, dst)  # (search off: tile heights only)
     for _ in range(2):
@@ -1006,12 +1024,11 @@ def run_rank(args):
         torch.cuda.empty_cache()
         dwt.set_option("place_tries", args.placements)
         t0 = time.perf_counter()
-        gen.manual_seed(1234 + rank)
         try:
             p_src, p_dst = dwt.alloc_batch("cdf97_s", nb, n, n, J)
             alloc_s = time.perf_counter() - t0
             src, dst = raw_tensor(torch, dev, p_src, (nb, n, n)), raw_tensor(torch, dev, p_dst, (nb, n, n))
-            torch.rand((nb, n, n), generator=gen, out=src)
+            seeded_images(torch, gen, src, lo)
             placement = {"by": "dwt_hip_alloc_batch", "seconds_total": round(alloc_s, 2)}
             placement.update(dwt.alloc_batch_report())
             note = dwt.alloc_batch_note()
@@ -1022,7 +1039,7 @@ def run_rank(args):
                                 "the source), the LL scratch at every step for the three best destinations (the shard's transform itself); "
                                 "the best arrangement kept, the rest of the arena returned; DESIGN s5")
         except Exception as e:  # noqa: BLE001 -- the run goes on with plain allocations and says so
-            src = torch.rand((nb, n, n), generator=gen, device=dev, dtype=torch.float32)
+            src = seeded_images(torch, gen, torch.empty((nb, n, n), device=dev, dtype=torch.float32), lo)
             dst = torch.empty_like(src)
             placement = {"by": f"plain allocations (dwt_hip_alloc_batch failed: {type(e).__name__}: {e})"}
         placement["tune_seconds"] = tune_shard(src, dst)
@@ -1114,9 +1131,8 @@ def run_rank(args):
             rates = [r.get("first_placement_gsamples_per_s") for r in per_rank if r.get("first_placement_gsamples_per_s")]
             out["value_first_placement"] = round((min(rates) if rates else first["gsamples_per_s_this_rank"]) * world, 3)
             out["first_placement"] = first
-        if world > 1:
-            out["per_rank"] = per_rank
         if use_dist:
+            out["per_rank"] = per_rank
             out["control_plane"] = control
         if shared:
             out["devices_shared"] = True
@@ -1223,6 +1239,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="backend option name=value (cpt, tile_pairs, waves, ...)")
     ap.add_argument("--workload", default="headline", choices=["headline", "config3", "config4", "config5"],
                     help="headline = BASELINE.json's metric (default); config3/4/5 = the other BASELINE configs, same JSON contract")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the torch.distributed branch (gloo + RCCL group, batch split) even with one rank: the one-GPU rehearsal of the N > 1 run")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:

@@ -65,7 +65,10 @@ int dwt_hip_device_count(void);
 const char *dwt_hip_device_name(void);
 const char *dwt_hip_last_error(void);
 
-/* Run on this hipStream_t (NULL = the default stream). */
+/* Run on this hipStream_t (NULL = the default stream).  The context's scratch is shared by its streams: a change of
+ * stream makes the new one wait (event) for everything the context queued on the old one, so alternating two streams
+ * on one thread is safe -- the chains are serialised where they share scratch.  Independent concurrent chains belong
+ * to different host threads (one context each).  Streams under capture are not ordered. */
 void dwt_hip_set_stream(void *hip_stream);
 /* The running-LL scratch of the 2-D Mallat drivers (two bands: the level-1 band, ceil(W/2) x ceil(H/2)
  * elements per image, and the level-2 band) in memory the CALLER owns and places -- the library then
@@ -181,6 +184,7 @@ int dwt_hip_transform2d_batch(int wavelet, int inverse, const void *src, void *d
  * whole batch leaves and re-enters one device. */
 int dwt_hip_transform2d_batch_sharded(int wavelet, int inverse, const void *src, void *dst,
 	size_t batch_stride, int batch, int stride_x, int size_x, int size_y, int *j, const int *devices, int n_devices);
+/* slot outside [0, n_slots) or batch < 0: *count = 0 */
 void dwt_hip_shard_bounds(int batch, int n_slots, int slot, int *first, int *count);
 
 /* The batch split for shards that are RESIDENT where they are transformed ("the >= 7x scaling
@@ -188,7 +192,8 @@ void dwt_hip_shard_bounds(int batch, int n_slots, int slot, int *first, int *cou
  * `batch_stride` bytes apart -- lies in the memory of devices[k] (allocated there by a thread bound to it with
  * dwt_hip_set_device; a device may be named more than once; counts[k] == 0 skips a shard).  All shards are
  * transformed at the same time, each by a persistent host thread with a context of its own on its device (the
- * calling thread takes the first shard on its own device); nothing crosses xGMI.  Synchronous.  `*j` as in
+ * calling thread takes the first shard on its own device); nothing crosses xGMI.  Synchronous; every shard's device is
+ * drained (hipDeviceSynchronize) before its shard is read, so producers on any stream of that device come first.  `*j` as in
  * dwt_hip_transform2d_batch.  dwt_hip_tune_batch_multi runs dwt_hip_tune in every slot instead (once, before
  * the first transform of shards that stay resident): the slots' contexts keep what it measures. */
 int dwt_hip_transform2d_batch_multi(int wavelet, int inverse, const void *const *srcs, void *const *dsts, const int *counts,

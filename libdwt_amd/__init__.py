@@ -449,7 +449,10 @@ def shard_bounds(batch, n_slots, slot):
 def _multi_args(srcs, dsts, counts, devices):
     n = len(srcs)
     assert len(dsts) == n and len(counts) == n and len(devices) == n
-    return (_P * n)(*[_addr(p) if p else None for p in srcs]), (_P * n)(*[_addr(p) if p else None for p in dsts]), (_I * n)(*counts), (_I * n)(*devices), n
+    # (`None if p is None`: truth-testing a tensor or array with several elements raises, and a one-element zero
+    # tensor must not turn into NULL)
+    ptrs = lambda ps: (_P * n)(*[None if p is None else _addr(p) for p in ps])  # noqa: E731
+    return ptrs(srcs), ptrs(dsts), (_I * n)(*counts), (_I * n)(*devices), n
 
 
 def transform2d_batch_multi(wavelet, inverse, srcs, dsts, counts, devices, batch_stride, stride_x, size_x, size_y, j_max=-1):

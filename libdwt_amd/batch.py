@@ -38,13 +38,25 @@ def _p2p(ops):
         req.wait()
 
 
-def scatter_images(batch_on_root, n_items, item_shape, dtype, device, root=0):
+def _loopback(src, dst):
+    """A group of ONE rank: the block goes through the backend's own point-to-point path, rank 0 -> rank 0
+    (one grouped isend + irecv).  The rehearsal of the split on a single GPU: the communicator, the grouped
+    launch and the copy kernels all run, only the xGMI hop is missing."""
+    _p2p([dist.P2POp(dist.isend, src, 0), dist.P2POp(dist.irecv, dst, 0)])
+
+
+def scatter_images(batch_on_root, n_items, item_shape, dtype, device, root=0, loopback=False):
     """Split a (B, H, W) batch held by `root` into per-rank blocks.  Every rank passes
     the same n_items/item_shape/dtype; only root passes the tensor.  Returns this
-    rank's block (a view of the input on a single rank)."""
+    rank's block (a view of the input on a single rank; with `loopback` and an initialised
+    group of one rank, a copy that travelled through the backend's send / recv)."""
     rank, world = _world()
     lo, hi = shard_range(n_items, rank, world)
     if world == 1:
+        if loopback and dist.is_available() and dist.is_initialized():
+            local = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=device)
+            _loopback(batch_on_root[lo:hi].contiguous(), local)
+            return local
         return batch_on_root[lo:hi]
     local = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=device)
     ops = []
@@ -64,10 +76,14 @@ def scatter_images(batch_on_root, n_items, item_shape, dtype, device, root=0):
     return local
 
 
-def gather_images(local, n_items, root=0):
+def gather_images(local, n_items, root=0, loopback=False):
     """Inverse of scatter_images: root gets the (B, ...) batch back, others get None."""
     rank, world = _world()
     if world == 1:
+        if loopback and dist.is_available() and dist.is_initialized():
+            out = torch.empty_like(local)
+            _loopback(local.contiguous(), out)
+            return out
         return local
     ops = []
     out = None

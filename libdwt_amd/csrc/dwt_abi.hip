@@ -102,6 +102,9 @@ void dwt_hip_finish(void)
 		hipHostFree(g.pin);
 	g.pin = nullptr;
 	g.pin_bytes = 0;
+	if (g.switch_ev)
+		hipEventDestroy(g.switch_ev);
+	g.switch_ev = nullptr;
 	for (auto &ev : g.prof_events) {
 		hipEventDestroy(ev.first);
 		hipEventDestroy(ev.second);
@@ -121,7 +124,25 @@ const char *dwt_hip_device_name(void)
 	return g.devname;
 }
 
-void dwt_hip_set_stream(void *s) { g.stream = (hipStream_t)s; }
+// The workspace of the context (LL scratch, staging image, pinned buffer) is shared by whatever stream comes next, so a
+// stream change ORDERS the new stream behind everything this context has queued on the old one: an event recorded on the
+// old stream at the switch, awaited by the new one.  No cost for calls that stay on one stream; a caller alternating two
+// streams on one thread gets the two chains serialised where they share scratch instead of a race on it.  Streams under
+// capture are left alone (the wait would pull the new stream into the capture).
+void dwt_hip_set_stream(void *s)
+{
+	hipStream_t ns = (hipStream_t)s;
+	if (g.inited && ns != g.stream) {
+		hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+		const bool plain = hipStreamIsCapturing(g.stream, &a) == hipSuccess && a == hipStreamCaptureStatusNone &&
+			hipStreamIsCapturing(ns, &b) == hipSuccess && b == hipStreamCaptureStatusNone;
+		if (plain && (g.switch_ev || hipEventCreateWithFlags(&g.switch_ev, hipEventDisableTiming) == hipSuccess) &&
+			hipEventRecord(g.switch_ev, g.stream) == hipSuccess)
+			(void)hipStreamWaitEvent(ns, g.switch_ev, 0);
+		(void)hipGetLastError();
+	}
+	g.stream = ns;
+}
 
 int dwt_hip_set_workspace(void *band0, size_t bytes0, void *band1, size_t bytes1)
 {

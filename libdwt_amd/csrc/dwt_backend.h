@@ -41,6 +41,7 @@ struct Ctx {
 	void *vol_host[2] = {nullptr, nullptr}; // device staging of host volumes (struct volume_t entries)
 	size_t vol_host_bytes[2] = {0, 0};
 	hipEvent_t dl_ev[8] = {}; // strip events of host_download, created once
+	hipEvent_t switch_ev = nullptr; // dwt_hip_set_stream: orders a newly set stream behind the old one's work
 	// host-pointer calls on large images: level 0 band by band while the image is still crossing PCIe (host_forward_pipelined)
 	hipStream_t up = nullptr, down = nullptr;
 	hipEvent_t pipe_ev[3][16] = {};

@@ -152,12 +152,30 @@ static int slot_job(SlotWorker *wk, const SlotOpts &opts, int device, int root_d
 		}
 	}
 	if (!wk->cin) {
-		HIP_TRY(hipStreamCreateWithFlags(&wk->cin, hipStreamNonBlocking));
-		HIP_TRY(hipStreamCreateWithFlags(&wk->cout, hipStreamNonBlocking));
+		// all or nothing: a slot with half of its streams and events would use the missing ones for ever
+		hipStream_t cin = nullptr, cout = nullptr;
+		hipEvent_t ev[6] = {};
+		bool ok = hipStreamCreateWithFlags(&cin, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&cout, hipStreamNonBlocking) == hipSuccess;
+		for (int k = 0; k < 6 && ok; k++)
+			ok = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+		if (!ok) {
+			const hipError_t e = hipGetLastError();
+			for (hipEvent_t x : ev)
+				if (x)
+					hipEventDestroy(x);
+			if (cin)
+				hipStreamDestroy(cin);
+			if (cout)
+				hipStreamDestroy(cout);
+			(void)hipGetLastError();
+			return fail("slot on device %d: creating its copy streams / events failed: %s", device, hipGetErrorString(e));
+		}
+		wk->cin = cin;
+		wk->cout = cout;
 		for (int k = 0; k < 2; k++) {
-			HIP_TRY(hipEventCreateWithFlags(&wk->ev_in[k], hipEventDisableTiming));
-			HIP_TRY(hipEventCreateWithFlags(&wk->ev_done[k], hipEventDisableTiming));
-			HIP_TRY(hipEventCreateWithFlags(&wk->ev_out[k], hipEventDisableTiming));
+			wk->ev_in[k] = ev[3 * k];
+			wk->ev_done[k] = ev[3 * k + 1];
+			wk->ev_out[k] = ev[3 * k + 2];
 		}
 	}
 	// The shard crosses in up to four pieces through two pairs of staging buffers: piece c+1 comes in and piece c-1
@@ -170,6 +188,21 @@ static int slot_job(SlotWorker *wk, const SlotOpts &opts, int device, int root_d
 			return 1;
 	hipStream_t st = g.stream;
 	int j = j_in;
+	// whatever fails half way: the peer copies still in flight write into the caller's `dst` and read this slot's
+	// staging, which the next call reuses -- drain the three streams before the error is reported
+	struct Drain {
+		hipStream_t a, b, c;
+		bool armed = true;
+		~Drain()
+		{
+			if (!armed)
+				return;
+			(void)hipStreamSynchronize(a);
+			(void)hipStreamSynchronize(b);
+			(void)hipStreamSynchronize(c);
+			(void)hipGetLastError();
+		}
+	} drain{wk->cin, wk->cout, st};
 	for (int c = 0; c < n_pieces; c++) {
 		const int a = shard_lo(c, n, n_pieces), cnt = shard_lo(c + 1, n, n_pieces) - a, s = c & 1;
 		const size_t off = (size_t)a * batch_stride, bytes = (size_t)cnt * batch_stride;
@@ -195,6 +228,7 @@ static int slot_job(SlotWorker *wk, const SlotOpts &opts, int device, int root_d
 	}
 	HIP_TRY(hipStreamSynchronize(wk->cout));
 	HIP_TRY(hipStreamSynchronize(st));
+	drain.armed = false;
 	*j_out = j;
 	return 0;
 }
@@ -213,6 +247,9 @@ static int resident_job(const SlotOpts *opts, int device, int wavelet, int inver
 			return fail("a buffer of the shard lies in the memory of device %d, not of device %d", at.device, device);
 		(void)hipGetLastError(); // (host pointers and the like are refused by the transform entry itself)
 	}
+	// The shard's producers may have run on any stream of this device (the caller's threads, torch side streams): the
+	// slot's own stream is not ordered behind them, so the device is drained first.  Once per shard and call.
+	HIP_TRY(hipDeviceSynchronize());
 	int j = j_in;
 	if (tune) {
 		if (dwt_hip_tune(wavelet, inverse, src, dst, batch_stride, n, stride_x, size_x, size_y, j_in))
@@ -242,7 +279,7 @@ static int batch_multi(bool tune, int wavelet, int inverse, const void *const *s
 			return fail("shard %d: bad count or null buffer", k);
 	}
 	std::lock_guard<std::mutex> turn(g_slots_mu);
-	HIP_TRY(hipStreamSynchronize(g.stream)); // whatever the caller queued (the shards' producers) comes first
+	// (every slot drains its own device before it reads its shard: resident_job)
 	const SlotOpts opts = SlotOpts::of_caller();
 	const int j_in = *j;
 	std::vector<int> js(n_shards, j_in);
@@ -310,6 +347,16 @@ int dwt_hip_tune_batch_multi(int wavelet, int inverse, const void *const *srcs, 
 void dwt_hip_shard_bounds(int batch, int n_slots, int slot, int *first, int *count)
 {
 	const int G = n_slots < 1 ? 1 : n_slots;
+	// a slot outside [0, n_slots) or a negative batch owns nothing: first = batch (clamped at 0), count = 0
+	if (batch < 0)
+		batch = 0;
+	if (slot < 0 || slot >= G) {
+		if (first)
+			*first = batch;
+		if (count)
+			*count = 0;
+		return;
+	}
 	const int a = shard_lo(slot, batch, G), b = shard_lo(slot + 1, batch, G);
 	if (first)
 		*first = a;

@@ -41,6 +41,16 @@ void apply_tile_choice(int choice, SweepTuning *t, bool inverse)
 		(inverse ? t->ring_inv : t->ring) = (choice >> 24) & 0xff;
 }
 
+// One measurement at a time per device: several contexts on one GPU (the slots of dwt_multi.hip, a caller's own threads)
+// would time each other's noise and stack their placement spacers up to an out-of-memory.  Recursive: dwt_hip_tune holds
+// it around the placement search and the tuned transform, whose levels take it again -- and so does a transform call
+// that measures by itself (DWT_HIP_TUNE=1 / option tune_in_call, which the slots of a sharded call inherit).
+static std::recursive_mutex &measure_mutex()
+{
+	static std::recursive_mutex per_device[64];
+	return per_device[g.device & 63];
+}
+
 static int tune_tile_pairs(unsigned long long key, bool inverse, std::initializer_list<TileCand> cands, const std::function<hipError_t(const SweepTuning &)> &launch)
 {
 	auto it = g.tile_cache.find(key);
@@ -48,6 +58,7 @@ static int tune_tile_pairs(unsigned long long key, bool inverse, std::initialize
 		return it->second;
 	if (!may_measure() || g.placing || stream_is_capturing())
 		return 0; // the launcher's rule; decided by dwt_hip_tune
+	std::lock_guard<std::recursive_mutex> turn(measure_mutex());
 	hipEvent_t e0, e1;
 	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
 		return 0;
@@ -180,15 +191,17 @@ int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int ba
 		need[0] + need[1] < ((size_t)g.place_min_mib << 20) || !ge.dense() || ge.Wo(2) < 2 || ge.Ho(2) < 2 || g.force_generic ||
 		stream_is_capturing())
 		return 0;
+	std::lock_guard<std::recursive_mutex> turn(measure_mutex());
 	struct Cand {
 		void *ll[2], *spacer;
 		double ms;
+		bool ok;
 	};
 	std::vector<Cand> cands;
 	int rc = 0;
 	bool own_released = false;
 	for (int k = 0; k < g.place_tries && k < 8 && !rc; k++) {
-		Cand c{{nullptr, nullptr}, nullptr, 0};
+		Cand c{{nullptr, nullptr}, nullptr, 0, false};
 		// the spacers stay allocated during the search, so the jumps add up: candidates 14, 44, 104 ... GiB
 		// further on (the classes come in 16 GiB granules, runs of one class can be 64 GiB long)
 		const size_t jump = place_jump(k);
@@ -221,15 +234,16 @@ int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int ba
 			g.ll_bytes[b] = need[b];
 		}
 		rc = timed_forward(w, s, d, ge, levels, batch, sb, db, &c.ms);
+		c.ok = rc == 0; // (a trial that failed has no time: never the best)
 		cands.push_back(c);
 	}
 	if (cands.empty())
 		return 0; // nothing allocated here and the context's scratch is as it was: the call allocates plainly
 	int best = 0;
 	for (size_t k = 0; k < cands.size(); k++) {
-		if (cands[k].ms < cands[best].ms)
+		if (cands[k].ok && (!cands[best].ok || cands[k].ms < cands[best].ms))
 			best = (int)k;
-		g.place_ms[k] = cands[k].ms;
+		g.place_ms[k] = cands[k].ok ? cands[k].ms : -1;
 	}
 	g.place_n = (int)cands.size();
 	g.place_best = best;
@@ -253,10 +267,7 @@ int place_ll_scratch(Wavelet w, Img s, Img d, const Geom &ge, int levels, int ba
 // tile tuner switched on -- every large level measures its tile heights on the way and the context keeps them
 int tune2d(Wavelet w, bool inverse, Img s, Img d, const Geom &ge, int levels, int batch, long sb, long db)
 {
-	// one measurement at a time per device: several contexts on one GPU (the slots of dwt_multi.hip, a caller's own
-	// threads) would time each other's noise and stack their spacers up to an out-of-memory
-	static std::mutex per_device[64];
-	std::lock_guard<std::mutex> turn(per_device[g.device & 63]);
+	std::lock_guard<std::recursive_mutex> turn(measure_mutex());
 	struct Guard {
 		Guard() { g.tuning = true; }
 		~Guard() { g.tuning = false; }

@@ -41,6 +41,9 @@ def test_shard_bounds_are_the_partition_of_the_survey(dwt):
                 assert (a, a + n) == shard_range(B, k, G)
                 assert all((b * G) // B == k for b in range(a, a + n))
     assert [dwt.shard_bounds(5, 3, k) for k in range(3)] == [(0, 2), (2, 2), (4, 1)]
+    # a slot outside [0, n_slots) or a negative batch owns nothing (it used to return a range past the batch's end)
+    assert dwt.shard_bounds(5, 3, 3) == (5, 0) and dwt.shard_bounds(5, 3, 7) == (5, 0) and dwt.shard_bounds(5, 3, -1) == (5, 0)
+    assert dwt.shard_bounds(-4, 3, 1) == (0, 0)
 
 
 @pytest.mark.parametrize("wname", ["cdf97_s", "cdf53_i"])
@@ -222,3 +225,158 @@ def test_a_transform_call_measures_nothing(dwt, oracle):
         L.dwt_hip_free(src)
         L.dwt_hip_free(dst)
         dwt.dwt_util_finish()
+
+
+TENSOR_SHARDS_SCRIPT = r"""
+import sys, numpy as np
+import torch                      # first: this process then shares torch's HIP runtime
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+import libdwt_amd as dwt
+from oraclelib import Oracle
+dwt.dwt_util_init()
+orc = Oracle()
+h, w, J = 128, 260, 2
+rng = np.random.default_rng(23)
+shards = [rng.random((n, h, w), dtype=np.float32) for n in (2, 1, 3)]
+shards[1][0, 0, 0] = 0.0
+srcs = [torch.from_numpy(s).to("cuda:0") for s in shards]
+dsts = [torch.zeros_like(t) for t in srcs]
+torch.cuda.synchronize()
+def check(scale):
+    for t, s in zip(dsts, shards):
+        want = s * scale
+        for k in range(s.shape[0]):
+            orc.fwd("cdf97_2f_s", want[k], J)
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), want.view(np.uint32))
+assert dwt.transform2d_batch_multi("cdf97_s", 0, srcs, dsts, [2, 1, 3], [0, 0, 0], h * w * 4, w * 4, w, h, J) == J
+check(np.float32(1))
+# the producers of a shard on a torch SIDE stream: the slots drain the device before they read
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    for t, s in zip(srcs, shards):
+        t.copy_(torch.from_numpy(s * 2).to("cuda:0", non_blocking=True))
+assert dwt.transform2d_batch_multi("cdf97_s", 0, srcs, dsts, [2, 1, 3], [0, 0, 0], h * w * 4, w * 4, w, h, J) == J
+check(np.float32(2))
+try:
+    dwt.transform2d_batch_multi("cdf97_s", 0, srcs, [dsts[0], None, dsts[2]], [2, 1, 3], [0, 0, 0], h * w * 4, w * 4, w, h, J)
+    raise SystemExit("a null shard was accepted")
+except dwt.DwtError:
+    pass
+# two physical devices, where the process sees them (the build box has one)
+if dwt.device_count() >= 2:
+    nb, hh, ww = 6, 300, 1030
+    imgs = rng.random((nb, hh, ww), dtype=np.float32)
+    want = imgs.copy()
+    for k in range(nb):
+        orc.fwd("cdf97_2f_s", want[k], 3)
+    s2 = [torch.from_numpy(np.ascontiguousarray(p)).to(f"cuda:{d}") for d, p in enumerate((imgs[:3], imgs[3:]))]
+    d2 = [torch.zeros_like(t) for t in s2]
+    for d in range(2):
+        torch.cuda.synchronize(d)
+    assert dwt.transform2d_batch_multi("cdf97_s", 0, s2, d2, [3, 3], [0, 1], hh * ww * 4, ww * 4, ww, hh, 3) == 3
+    assert np.array_equal(np.concatenate([t.cpu().numpy() for t in d2]).view(np.uint32), want.view(np.uint32))
+    print("two devices OK")
+print("tensor shards OK")
+"""
+
+
+def test_resident_shards_given_as_torch_tensors():
+    """The pointer arrays of dwt_hip_transform2d_batch_multi built from torch tensors (every other wrapper takes
+    them through `_addr`; truth-testing a tensor with several elements used to raise in `_multi_args`, and a
+    one-element zero tensor turned into NULL); producers on a torch side stream; and -- where the process sees two
+    GPUs -- shards resident on devices 0 and 1.  Own process: torch before the library (one HIP runtime)."""
+    import os
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + TENSOR_SHARDS_SCRIPT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "tensor shards OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_two_physical_devices_sharded_and_resident(dwt, oracle):
+    """Only where the process sees two GPUs (the build box has one: skipped there).  A placed (VMM) batch on device 0
+    sharded over devices {0, 1} -- peer copies over xGMI through the granted mapping -- and shards resident on devices
+    0 and 1, both bit-compared with the single-GPU call."""
+    if dwt.device_count() < 2:
+        pytest.skip("needs two GPUs in one process")
+    L = dwt.lib
+    nb, h, w, J = 6, 300, 1030, 3
+    rng = np.random.default_rng(31)
+    imgs = rng.random((nb, h, w), dtype=np.float32)
+    want = imgs.copy()
+    for k in range(nb):
+        oracle.fwd("cdf97_2f_s", want[k], J)
+    dwt.set_option("place_min_mib", 0)
+    dwt.set_option("place_max_gib", 24)
+    try:
+        src, dst = dwt.alloc_batch("cdf97_s", nb, w, h, J)
+        assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+        got = np.empty_like(imgs)
+        assert dwt.transform2d_batch_sharded("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J, [0, 1]) == J
+        assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+        assert np.array_equal(bits(got), bits(want))
+        L.dwt_hip_free(src)
+        L.dwt_hip_free(dst)
+    finally:
+        dwt.set_option("place_min_mib", 1024)
+        dwt.set_option("place_max_gib", 0)
+    # shards resident on devices 0 and 1 (allocated by threads bound to them)
+    import threading
+
+    halves = [np.ascontiguousarray(imgs[:3]), np.ascontiguousarray(imgs[3:])]
+    ptrs = [[None, None], [None, None]]
+
+    def alloc(d):
+        dwt.set_device(d)
+        ptrs[d][0] = L.dwt_hip_malloc(halves[d].nbytes)
+        ptrs[d][1] = L.dwt_hip_malloc(halves[d].nbytes)
+        assert L.dwt_hip_memcpy_h2d(ptrs[d][0], halves[d].ctypes.data, halves[d].nbytes) == 0
+
+    for d in range(2):
+        th = threading.Thread(target=alloc, args=(d,))
+        th.start()
+        th.join()
+    assert dwt.transform2d_batch_multi("cdf97_s", 0, [ptrs[0][0], ptrs[1][0]], [ptrs[0][1], ptrs[1][1]], [3, 3], [0, 1], h * w * 4, w * 4, w, h, J) == J
+    got = np.empty_like(imgs)
+
+    def fetch(d):
+        dwt.set_device(d)
+        assert L.dwt_hip_memcpy_d2h(got[3 * d:3 * d + 3].ctypes.data, ptrs[d][1], halves[d].nbytes) == 0
+        L.dwt_hip_free(ptrs[d][0])
+        L.dwt_hip_free(ptrs[d][1])
+
+    for d in range(2):
+        th = threading.Thread(target=fetch, args=(d,))
+        th.start()
+        th.join()
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_bench_distributed_branch_with_one_rank_over_rccl():
+    """The one-GPU rehearsal of what the first real N > 1 run executes for the first time: `bench.py --force-dist`
+    takes the torch.distributed branch with WORLD_SIZE = 1 -- the gloo + RCCL group is created ("cpu:gloo,cuda:nccl"),
+    RCCL's first all_reduce runs on a side stream under its deadline, the barrier / max of the timing go over RCCL
+    device tensors, per_rank is gathered, and the batch split sends the batch rank 0 -> rank 0 and back through
+    RCCL's grouped send / recv.  The line must say control_plane "rccl" and carry an intact split."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--images", "4", "--size", "2048",
+                          "--steps", "2", "--warmup", "1", "--placements", "1", "--no-cpu", "--no-sweep", "--no-single", "--timeout", "240",
+                          "--pg-timeout", "120", "--split-timeout", "60"], env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and lines, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads(lines[-1])
+    assert line["control_plane"] == "rccl", line["control_plane"]
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["per_rank"] and line["per_rank"][0]["rank"] == 0 and line["per_rank"][0]["images"] == 4
+    split = line["batch_split"]
+    assert "error" not in split and split["round_trip_intact"] is True and split["scatter_ms"] > 0 and split["gather_ms"] > 0, split
+    assert split["bytes_each_way"] == 4 * 2048 * 2048 * 4

@@ -469,6 +469,92 @@ def test_config4_per_gpu_shape_32x4096(dwt, oracle):
         one.free()
 
 
+def test_config4_images_of_ranks_1_and_7(dwt, oracle):
+    """SURVEY.md s8d C4 names the images 0, 31, 32 and 255 of the 256: 0 and 31 are rank 0's first and last (test
+    above); 32 is the FIRST image of rank 1's block and 255 the LAST of rank 7's, found through
+    dwt_hip_shard_bounds(256, 8, rank) as a rank of the sharded run finds them.  Each rank's block head / tail
+    (two images around them) goes through one batched call; 32 and 255 are bit-compared with the oracle."""
+    n, J, total, world = 4096, 5, 256, 8
+    a1, c1 = dwt.shard_bounds(total, world, 1)
+    a7, c7 = dwt.shard_bounds(total, world, 7)
+    assert (a1, c1) == (32, 32) and (a7, c7) == (224, 32)
+    for first, pick in ((a1, 0), (a7 + c7 - 2, 1)):  # images [32, 33] and [254, 255]
+        imgs = np.empty((2, n, n), np.float32)
+        for i in range(2):
+            imgs[i] = np.random.default_rng(1234 + first + i).random((n, n), dtype=np.float32)
+        src = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+        dst = dwt.lib.dwt_hip_malloc(imgs.nbytes)
+        try:
+            assert dwt.lib.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+            assert dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, 2, n * 4, n, n, J) == J
+            out = np.empty_like(imgs)
+            assert dwt.lib.dwt_hip_memcpy_d2h(out.ctypes.data, dst, imgs.nbytes) == 0
+            want = imgs[pick].copy()
+            assert oracle.fwd("cdf97_2f_s", want, J) == J
+            assert np.array_equal(bits(out[pick]), bits(want)), f"image {first + pick} differs from the oracle"
+        finally:
+            dwt.lib.dwt_hip_free(src)
+            dwt.lib.dwt_hip_free(dst)
+
+
+STREAMS_SCRIPT = r"""
+import sys, numpy as np
+import torch                      # first: this process then shares torch's HIP runtime
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+import libdwt_amd as dwt
+from oraclelib import Oracle
+dwt.dwt_util_init()
+orc = Oracle()
+n, J, reps = 2048, 4, 6
+rng = np.random.default_rng(321)
+imgs = [rng.random((n, n), dtype=np.float32) for _ in range(2 * reps)]
+wants = []
+for a in imgs:
+    w_ = a.copy(); orc.fwd("cdf97_2f_s", w_, J); wants.append(w_)
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+dev = [torch.from_numpy(a).to("cuda:0") for a in imgs]
+torch.cuda.synchronize()
+for i, t in enumerate(dev):
+    with torch.cuda.stream(streams[i & 1]):
+        dwt.use_torch_stream()
+        dwt.dwt_cdf97_2f_s(t, n * 4, 4, n, n, n, n, J)
+torch.cuda.synchronize()
+for i, t in enumerate(dev):
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), wants[i].view(np.uint32)), f"forward call {i} (stream {i & 1})"
+for i, t in enumerate(dev):   # and back, alternating the other way round
+    with torch.cuda.stream(streams[(i + 1) & 1]):
+        dwt.use_torch_stream()
+        dwt.dwt_cdf97_2i_s(t, n * 4, 4, n, n, n, n, J)
+torch.cuda.synchronize()
+for i, t in enumerate(dev):
+    assert np.abs(t.cpu().numpy() - imgs[i]).max() < 1e-5, f"inverse call {i}"
+# host-pointer calls (pinned staging, host_a / host_b) between two streams as well
+h = [rng.random((700, 900), dtype=np.float32) for _ in range(4)]
+for i, a in enumerate(h):
+    w_ = a.copy(); orc.fwd("cdf97_2f_s", w_, 3)
+    with torch.cuda.stream(streams[i & 1]):
+        dwt.use_torch_stream()
+        dwt.dwt_cdf97_2f_s(a, a.strides[0], 4, 900, 700, 900, 700, 3)
+    assert np.array_equal(a.view(np.uint32), w_.view(np.uint32)), i
+print("streams OK")
+"""
+
+
+def test_two_streams_alternating_on_one_thread():
+    """dwt_hip_set_stream orders a newly set stream behind what the context queued on the old one (the LL scratch,
+    the staging image and the pinned buffer are shared by the context's streams).  Two torch streams alternate call
+    by call on one thread -- in-place entries (staging + scratch), different images per stream, no synchronisation
+    in between -- and every result is the oracle's.  Own process: torch before the library (one HIP runtime)."""
+    import os
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + STREAMS_SCRIPT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "streams OK" in out.stdout, out.stderr[-2000:]
+
+
 def test_threads_have_their_own_context(dwt, oracle):
     """One context per host thread: four threads transform different images at the same time (device
     pointers and host pointers, different sizes, so their workspaces differ) and every result is

@@ -359,12 +359,16 @@ def cpu_baseline(size, levels):
     # dwt_util_get_stride(.,2) avoids power-of-two pitches (they alias in the CPU caches)
     pitches = [size, size + 144] if size % 1024 == 0 else [size]
     schedules = [(0, 1), (12, 4)] if kind == "reference" else [(0, 1)]
-    thread_counts = sorted({1, cores})
+    # 1 thread and ALL PHYSICAL CORES of the node; and this GPU's share of them (16 on the 8-GPU node)
+    phys = physical_cores()
+    thread_counts = sorted({1, cores, phys})
     rows = []
     for pitch_elems in pitches:
         buf = np.zeros((size, pitch_elems), np.float32)
         for threads in thread_counts:
             for accel, workers in schedules:
+                if threads == 1 and pitch_elems == size and size % 1024 == 0 and (accel, workers) != (0, 1):
+                    continue  # one thread on the power-of-two pitch takes seconds per run (cache aliasing): one schedule is the sample
                 if kind == "reference":
                     lib.lib.dwt_util_set_accel(accel)
                     lib.lib.dwt_util_set_num_workers(workers)
@@ -388,13 +392,36 @@ def cpu_baseline(size, levels):
                 rows.append({"threads": threads, "pitch_bytes": pitch_elems * 4, "accel": accel, "workers": workers,
                              "gsamples_per_s": round(size * size / best / 1e9, 3), "best_s": round(best, 4), "runs": timed})
     top = max(rows, key=lambda r: r["gsamples_per_s"])
+    share = max((r for r in rows if r["threads"] == cores), key=lambda r: r["gsamples_per_s"])
     return {"value": top["gsamples_per_s"], "unit": "Gsamples/s", "cores": top["threads"], "kind": kind, "cpu_model": cpu_model(),
+            "physical_cores": phys, "value_one_gpu_share": share["gsamples_per_s"], "cores_one_gpu_share": cores,
             "sample": f"1 image {size}x{size} float, {levels} levels, dwt_cdf97_2f_s in place, best single run per row "
-                      f"(dwt_util_perf protocol, M=1); value = best row: {top['threads']} OpenMP threads, pitch "
-                      f"{top['pitch_bytes']} B, accel {top['accel']} / {top['workers']} workers; threads = min(CPUs this process may "
-                      f"run on = {avail}, 16): one GPU's share of the host (a 1-GPU lease of the 8-GPU node gets 16 of its cores; "
-                      f"BENCH_CPU_THREADS overrides)",
+                      f"(dwt_util_perf protocol, M=1); rows: threads in {{1, {cores} = one GPU's share of the host (min(CPUs this process may run "
+                      f"on = {avail}, 16); BENCH_CPU_THREADS overrides), {phys} = all physical cores}} x pitch {{dense, dwt_util_get_stride}} x "
+                      f"{{accel 0, accel 12 / 4 workers}}; value = best row: {top['threads']} OpenMP threads, pitch "
+                      f"{top['pitch_bytes']} B, accel {top['accel']} / {top['workers']} workers",
             "rows": rows}
+
+
+def physical_cores():
+    """Physical cores among the CPUs this process may run on (distinct (package, core id) pairs of /proc/cpuinfo);
+    falls back to the logical count."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cores, cpu, pkg = set(), None, None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("processor"):
+                cpu = int(ln.split(":")[1])
+            elif ln.startswith("physical id"):
+                pkg = int(ln.split(":")[1])
+            elif ln.startswith("core id") and cpu in allowed:
+                cores.add((pkg, int(ln.split(":")[1])))
+    except (OSError, ValueError):
+        pass
+    return len(cores) or len(allowed)
 
 
 def cpu_model():
@@ -606,6 +633,52 @@ def single_image_stats(torch, dwt, src, dst, n, J):
         out[f"frac_{name}"] = round(ref_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     out["il_how"] = ("il_*: the interleaved layout's entries (dwt_cdf97_2f_inplace_s / _2i_inplace_s semantics), bit-exact default "
                      "path; frac_il_* = 2 x image bytes / median / 8 TB/s")
+    return out
+
+
+def extra_legs(torch, dwt, src, dst, n, J, nb, budget_s=6.0):
+    """What SURVEY.md s8(d) asks for beside the headline, each a few calls under one small time budget:
+    `batch_inverse` (the resident batch back: dwt_cdf97_2i_s2 semantics, one batched call per step), `inplace_batch`
+    (the in-place entry dwt_cdf97_2f_s image by image over the batch) and `host_pointer` (the drop-in call on an image
+    in HOST memory, end to end incl. PCIe both ways: never `value`)."""
+    import numpy as np
+
+    t_end = time.perf_counter() + budget_s
+    img_bytes = n * n * 4
+    out = {}
+    alg = algorithmic_bytes(n, n, J)
+
+    def rate(ms, images):
+        return {"ms_per_step": round(ms, 4), "gsamples_per_s": round(images * n * n / (ms * 1e-3) / 1e9, 2),
+                "hbm_frac_algorithmic": round(images * alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # batch inverse: coefficients (dst, as the headline left them) -> src
+    dwt.tune("cdf97_s", 1, dst, src, img_bytes, nb, n * 4, n, n, J)
+    ms = _event_times(torch, lambda i: dwt.transform2d_batch("cdf97_s", 1, dst, src, img_bytes, nb, n * 4, n, n, J), 5, 2)
+    out["batch_inverse"] = dict(rate(statistics.median(ms), nb), images=nb, how="HIP events, median of 5 steps after dwt_hip_tune; one batched call per step")
+    if time.perf_counter() < t_end:
+        def inplace_step(i):
+            for k in range(nb):
+                dwt.dwt_cdf97_2f_s(dst[k], n * 4, 4, n, n, n, n, J)
+        ms = _event_times(torch, inplace_step, 3, 1)
+        out["inplace_batch"] = dict(rate(statistics.median(ms), nb), images=nb, how="dwt_cdf97_2f_s per image over the batch, median of 3 steps")
+    if time.perf_counter() < t_end:
+        host = np.random.default_rng(1234).random((n, n), dtype=np.float32)
+        ts = {"fwd": [], "inv": []}
+        for rep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dwt.dwt_cdf97_2f_s(host, n * 4, 4, n, n, n, n, J)
+            t1 = time.perf_counter()
+            dwt.dwt_cdf97_2i_s(host, n * 4, 4, n, n, n, n, J)
+            t2 = time.perf_counter()
+            if rep:  # (the first call pins the image and allocates the staging)
+                ts["fwd"].append((t1 - t0) * 1e3)
+                ts["inv"].append((t2 - t1) * 1e3)
+        out["host_pointer"] = {"forward_ms": round(min(ts["fwd"]), 3), "inverse_ms": round(min(ts["inv"]), 3),
+                               "gsamples_per_s_forward": round(n * n / (min(ts["fwd"]) * 1e-3) / 1e9, 2),
+                               "how": "dwt_cdf97_2f_s / dwt_cdf97_2i_s on one image in pageable HOST memory, wall clock of the synchronous call, "
+                                      "best of 3: PCIe both ways included -- not comparable with `value`"}
     return out
 
 
@@ -1148,6 +1221,13 @@ def run_rank(args):
                 out["single_image"] = single_image_stats(torch, dwt, src, dst, n, J)
             except Exception as e:  # noqa: BLE001
                 out["single_image"] = {"error": f"{type(e).__name__}: {e}"}
+            STATE["line"] = dict(out)
+        if world == 1 and not args.no_single and not args.inplace:
+            try:
+                dwt.transform2d_batch("cdf97_s", 0, src, dst, img_bytes, nb, n * 4, n, n, J)  # coefficients of the whole batch in dst again
+                out.update(extra_legs(torch, dwt, src, dst, n, J, nb))
+            except Exception as e:  # noqa: BLE001
+                out["extra_legs"] = {"error": f"{type(e).__name__}: {e}"}
             STATE["line"] = dict(out)
         if world == 1 and not args.no_cpu:
             try:

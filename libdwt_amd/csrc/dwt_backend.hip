@@ -508,6 +508,7 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				a.out = ll_band(ll_out);
 				a.out_pitch = ll_pitch_elems(Wo);
 				a.out_bstride = a.out_pitch * Ho;
+				a.temporal_out = g.tune.inv_ll_temporal && (size_t)Wo * Ho * es * batch <= ((size_t)128 << 20);
 			}
 			SweepTuning tune = g.tune;
 			if (!dbl && tune.tile_pairs <= 0)

@@ -24,6 +24,8 @@ struct SweepTuning {
 	                     // stores temporal (the next level reads it), bit 3 takes the neighbour taps by wavefront shifts
 	int nt_auto = 1;     // forward: drop bit 2 of `nt` when the launch's LL bands exceed the Infinity Cache
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
+	int inv_pairs = 16;  // inverse: tile height (row pairs) of the large levels under the launcher's rule
+	int inv_ll_temporal = 1; // inverse: a level that is not the last stores its result temporal when it fits the Infinity Cache
 };
 
 // In-place level of the interleaved layout (input image == output image): a snapshot of what a tile reads of its
@@ -94,6 +96,7 @@ struct InvLevelArgs {
 	long out_pitch, out_bstride;
 	int W, H, batch;
 	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
+	int temporal_out = 0; // Mallat: the result is the next level's low-pass input and fits the Infinity Cache: stored temporal
 	int pair_lo = 0, pair_hi = 0; // pair_hi > 0: only the tiles that start at a row pair in [pair_lo, pair_hi) run (see FwdLevelArgs)
 	const CopyRects *ride = nullptr; // see FwdLevelArgs
 	int ride_lo = 0, ride_hi = 0;

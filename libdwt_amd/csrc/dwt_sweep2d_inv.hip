@@ -495,6 +495,10 @@ static hipError_t inv_pick(const InvLevelArgs &a, const SweepGeom &g, dim3 grid,
 	// loads measured 4.37 against 5.35 TB/s); ring 16 is the cross-check variant (5.21)
 	if (ring == 16)
 		return inv_launch<W, CPT, 16, 1, false>(a, g, grid, waves, s);
+	// the result of a level that is not the last is the next level's low-pass input: temporal stores let it wait in the
+	// 256 MiB Infinity Cache (the forward's LL bands alike, cache policy bit 2 there)
+	if (a.temporal_out)
+		return inv_launch<W, CPT, 8, 0, false>(a, g, grid, waves, s);
 	return inv_launch<W, CPT, 8, 1, false>(a, g, grid, waves, s);
 }
 

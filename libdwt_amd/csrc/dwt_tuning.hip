@@ -130,7 +130,8 @@ int tuned_tile_pairs(Wavelet w, const InvLevelArgs &a)
 	if (!tunable(a.W, a.H, a.batch, a.interleaved))
 		return 0;
 	const Wavelet wk = (g.fma && w == kCdf97S) ? kCdf97SFma : w;
-	return tune_tile_pairs(tile_key(w, true, a.W, a.H, a.batch), true, {{32, 0, 0}, {16, 0, 0}, {8, 0, 0}},
+	// (round 6: the 512-column tile joins the candidates; the launcher's rule is 16 pairs)
+	return tune_tile_pairs(tile_key(w, true, a.W, a.H, a.batch), true, {{16, 0, 0}, {32, 0, 0}, {8, 0, 0}, {16, 8, 0}, {32, 8, 0}},
 		[&](const SweepTuning &t) { return launch_inv_level(wk, a, t, g.stream); });
 }
 // ---- placement of the LL scratch ------------------------------------------------------------------

@@ -245,6 +245,27 @@ class Reference(_Lib):
         return img
 
 
+HYBRID_DIR = os.path.join(ORACLE_DIR, "_ref", "hybrid")
+HYBRID_SO = os.path.join(HYBRID_DIR, "libdwt_hybrid.so")
+
+
+class Hybrid(Reference):
+    """The reference compiled WITH the maintainer's dispatch lines (integration/libdwt_hip_dispatch.patch, built by
+    `make -C oracle ref_hybrid`) and linked against the product library: accel 0 is libdwt's own CPU path, accel 100
+    the MI355X backend -- in one binary."""
+
+    def __init__(self):
+        if not os.path.exists(HYBRID_SO) and os.path.isdir(os.path.join(REFERENCE_SRC, "src")):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref_hybrid"])
+        if not os.path.exists(HYBRID_SO):
+            raise FileNotFoundError(HYBRID_SO)
+        _Lib.__init__(self, HYBRID_SO)
+        L = self.lib
+        L.dwt_util_set_accel.argtypes = [_I]
+        L.dwt_util_set_num_workers.argtypes = [_I]
+        L.dwt_util_set_num_threads.argtypes = [_I]
+
+
 def have_reference():
     return os.path.exists(REF_SO) or os.path.isdir(os.path.join(REFERENCE_SRC, "src"))
 

@@ -2,6 +2,7 @@
 // strides, src/system.c:102-164 is the reference's gather / scatter), and the pipelined host-pointer
 // calls on large images (level 0 and 1 band by band under their own PCIe transfers).
 #include "dwt_backend.h"
+#include "dwt_host_pools.h"
 
 namespace dwtb {
 
@@ -24,91 +25,6 @@ static int grow_pinned(size_t need)
 	g.pin_bytes = need;
 	return 0;
 }
-
-// A small persistent pool for the host-side row repacking (starting 16 threads per call cost more
-// than the repacking of a 1080p frame).  Workers sleep on a condition variable between jobs; a job
-// is a range of row chunks handed out under the mutex; the caller works too.  One job at a time
-// (calls from several host threads take turns).  The pool is created on first use and never
-// destroyed (no static-destruction order to get wrong); a forked child builds its own.
-class RowPool {
-public:
-	static RowPool &get()
-	{
-		static RowPool *p = nullptr;
-		static std::mutex mk;
-		std::lock_guard<std::mutex> lk(mk);
-		if (!p || p->pid_ != getpid())
-			p = new RowPool();
-		return *p;
-	}
-	template <class F>
-	void run(int rows, int chunk, F f)
-	{
-		std::lock_guard<std::mutex> turn(turn_);
-		std::function<void(int, int)> fn = f;
-		{
-			std::lock_guard<std::mutex> lk(m_);
-			job_ = &fn; rows_ = rows; chunk_ = chunk; next_ = 0; active_ = 0; gen_++;
-		}
-		cv_job_.notify_all();
-		work();
-		std::unique_lock<std::mutex> lk(m_);
-		cv_done_.wait(lk, [&] { return next_ >= rows_ && active_ == 0; });
-		job_ = nullptr;
-	}
-	int workers() const { return (int)th_.size() + 1; }
-
-private:
-	RowPool() : pid_(getpid())
-	{
-		unsigned n = std::thread::hardware_concurrency();
-		n = n > 16 ? 16 : n;
-		for (unsigned i = 1; i < n; i++)
-			th_.emplace_back([this] { loop(); });
-		for (auto &t : th_)
-			t.detach();
-	}
-	void loop()
-	{
-		unsigned long seen = 0;
-		for (;;) {
-			{
-				std::unique_lock<std::mutex> lk(m_);
-				cv_job_.wait(lk, [&] { return gen_ != seen; });
-				seen = gen_;
-			}
-			work();
-		}
-	}
-	void work()
-	{
-		for (;;) {
-			int a, b;
-			const std::function<void(int, int)> *fn;
-			{
-				std::lock_guard<std::mutex> lk(m_);
-				if (!job_ || next_ >= rows_)
-					break;
-				a = next_; b = a + chunk_ < rows_ ? a + chunk_ : rows_;
-				next_ = b; active_++; fn = job_;
-			}
-			(*fn)(a, b);
-			{
-				std::lock_guard<std::mutex> lk(m_);
-				active_--;
-			}
-			cv_done_.notify_all();
-		}
-		cv_done_.notify_all();
-	}
-	pid_t pid_;
-	std::vector<std::thread> th_;
-	std::mutex m_, turn_;
-	std::condition_variable cv_job_, cv_done_;
-	const std::function<void(int, int)> *job_ = nullptr;
-	int rows_ = 0, chunk_ = 1, next_ = 0, active_ = 0;
-	unsigned long gen_ = 0;
-};
 
 template <class F>
 static void for_rows_parallel(int rows, size_t bytes_total, F f)

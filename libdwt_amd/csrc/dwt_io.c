@@ -8,6 +8,7 @@
 #include "../../include/libdwt.h"
 
 #include <ctype.h>
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -68,6 +69,14 @@ static int load_pgm(const char *filename, int is_float, float max_s, int max_i, 
 		dwt_util_log(LOG_ERR, "Invalid depth.\n");
 		fclose(f);
 		return 3;
+	}
+	/* The reference computes the row pitch in `int` (4 * width, then the next prime): from 2^29 columns on that wraps, and
+	 * the loop below would write the file's samples past a tiny allocation (the reference does exactly that).  The one
+	 * place where this loader departs from it: such a header is refused like any other bad one. */
+	if (*psize_x > (INT_MAX - 4096) / 4) {
+		dwt_util_log(LOG_ERR, "Invalid file metadata.\n");
+		fclose(f);
+		return 2;
 	}
 	*pstride_y = 4;
 	*pstride_x = dwt_util_get_opt_stride(*pstride_y * *psize_x);
@@ -219,6 +228,10 @@ static int load_mat(const char *path, int is_float, void **ptr, int *size_x, int
 	fclose(f);
 	int rows = 0, cols = 0;
 	if (mat_pass(text, n, is_float, NULL, 0, 0, 0, 0, &rows, &cols)) {
+		free(text);
+		return 2;
+	}
+	if (cols > (INT_MAX - 4096) / 4) { /* (a row pitch that does not fit an int: see load_pgm) */
 		free(text);
 		return 2;
 	}

@@ -17,67 +17,22 @@
 // (The Python harness does the same split across PROCESSES with RCCL point-to-point transfers,
 // libdwt_amd/batch.py; this file is what a C caller of libdwt.h gets.)
 #include "dwt_backend.h"
+#include "dwt_host_pools.h"
 
 #include <memory>
 #include <string>
 
 namespace dwtb {
 
-// A host thread that lives as long as the process and runs one job at a time: its thread-local
-// context (dwt_backend.hip's `g`) and its staging buffers persist between the calls.
-class SlotWorker {
-public:
-	SlotWorker() : th_([this] { loop(); }) { th_.detach(); }
-	void submit(std::function<int()> job)
-	{
-		std::lock_guard<std::mutex> lk(m_);
-		job_ = std::move(job);
-		busy_ = true;
-		rc_ = 0;
-		cv_.notify_all();
-	}
-	int wait(std::string &err)
-	{
-		std::unique_lock<std::mutex> lk(m_);
-		cv_.wait(lk, [&] { return !busy_; });
-		err = err_;
-		return rc_;
-	}
+// a slot's worker (dwt_host_pools.h: a persistent host thread running one job at a time) with the slot's staging
+struct SlotWorker : SlotThread {
+	SlotWorker() : SlotThread(dwt_hip_last_error) {}
 	// staging of this slot (owned by the worker thread's device): two source and two result pieces
 	void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t stage_bytes[4] = {0, 0, 0, 0};
 	hipStream_t cin = nullptr, cout = nullptr;
 	hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[2] = {};
 	int device = -1;
-
-private:
-	void loop()
-	{
-		for (;;) {
-			std::function<int()> job;
-			{
-				std::unique_lock<std::mutex> lk(m_);
-				cv_.wait(lk, [&] { return busy_ && job_; });
-				job = std::move(job_);
-				job_ = nullptr;
-			}
-			const int rc = job();
-			{
-				std::lock_guard<std::mutex> lk(m_);
-				rc_ = rc;
-				err_ = rc ? dwt_hip_last_error() : "";
-				busy_ = false;
-			}
-			cv_.notify_all();
-		}
-	}
-	std::mutex m_;
-	std::condition_variable cv_;
-	std::function<int()> job_;
-	bool busy_ = false;
-	int rc_ = 0;
-	std::string err_;
-	std::thread th_;
 };
 
 static std::mutex g_slots_mu;             // one multi-device call at a time (the workers are shared)

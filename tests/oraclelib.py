@@ -15,7 +15,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libdwt_oracle.so")
+# (DWT_ORACLE_SO: another build of the same restatement -- the sanitizer build of tests/san/Makefile)
+ORACLE_SO = os.environ.get("DWT_ORACLE_SO") or os.path.join(ORACLE_DIR, "_build", "libdwt_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libdwt_ref.so")
 REFERENCE_SRC = "/root/reference"
 

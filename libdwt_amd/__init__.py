@@ -24,7 +24,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdwt_hip.so")
+LIB_PATH = os.environ.get("DWT_HIP_LIB") or os.path.join(_HERE, "libdwt_hip.so")  # (DWT_HIP_LIB: another build of the library, for A/B scripts)
 
 CDF97_S, CDF53_I, CDF53_S, CDF97_D, CDF53_D, CDF97_I = 0, 1, 2, 3, 4, 5
 

@@ -109,7 +109,7 @@ static int vol_forward_op(const float *src, long ssy, long ssz, float *dst, long
 		a.in = b.in; a.in_pitch = j ? b.sy : ssy; a.in_bstride = j ? b.sz : ssz;
 		a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
 		a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
-		a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
+		a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1; a.plain_ends = 1;
 		hipError_t e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
 		if (e != hipSuccess)
 			return fail("3-D xy pass launch failed: %s", hipGetErrorString(e));
@@ -252,14 +252,14 @@ int dwt_hip_transform3d(int inverse, void *vol, size_t stride_y, size_t stride_z
 			a.in = b.p; a.in_pitch = b.sy; a.in_bstride = b.sz;
 			a.out_ll = S; a.ll_pitch = s_sy; a.ll_bstride = s_sz;
 			a.out_h = S; a.h_pitch = s_sy; a.h_bstride = s_sz;
-			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
+			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1; a.plain_ends = 1;
 			e = launch_fwd_level(kCdf97S, a, g.tune, g.stream);
 		} else {
 			InvLevelArgs a;
 			a.in_ll = b.p; a.ll_pitch = 2 * b.sy; a.ll_bstride = b.sz;
 			a.in_h = b.p + b.sy; a.h_pitch = 2 * b.sy; a.h_bstride = b.sz;
 			a.out = S; a.out_pitch = s_sy; a.out_bstride = s_sz;
-			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1;
+			a.W = b.lx; a.H = b.ly; a.batch = b.lz; a.interleaved = 1; a.plain_ends = 1;
 			e = launch_inv_level(kCdf97S, a, g.tune, g.stream);
 		}
 		if (e != hipSuccess)

@@ -76,7 +76,9 @@ static __device__ __forceinline__ void il_phase_piece(typename W::T (&v)[NE], in
 			} else {
 				r = (i == N - 1) ? v[j > 0 ? j - 1 : j] : v[j + 1];
 			}
-			const T nv = INV ? W::inv_step(st, v[j], l, r) : W::fwd_step(st, v[j], l, r);
+			// (a true line end: l and r are one sample, the reference adds (2c)*x -- dwt_lift.h)
+			const bool end = i == 0 || i == N - 1;
+			const T nv = INV ? inv_step_at<W>(st, end, v[j], l, r) : fwd_step_at<W>(st, end, v[j], l, r);
 			v[j] = ok ? nv : v[j];
 		}
 	}
@@ -113,7 +115,8 @@ static __device__ __forceinline__ void il_phase_lanes(typename W::T (&v)[NE], in
 		for (int j = 0; j < NE; j++) {
 			const T fl = from_bits<T>(from_left_lane(to_bits(v[j]))), fr = from_bits<T>(from_right_lane(to_bits(v[j])));
 			const T l = i == 0 ? fr : fl, r = i == N - 1 ? fl : fr;
-			const T nv = INV ? W::inv_step(st, v[j], l, r) : W::fwd_step(st, v[j], l, r);
+			const bool end = i == 0 || i == N - 1; // (both taps one sample: the reference's end form)
+			const T nv = INV ? inv_step_at<W>(st, end, v[j], l, r) : fwd_step_at<W>(st, end, v[j], l, r);
 			v[j] = ok ? nv : v[j];
 		}
 	}

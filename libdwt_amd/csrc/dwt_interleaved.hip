@@ -38,8 +38,11 @@ __global__ __launch_bounds__(256) void k_il_phase(const char *__restrict__ src, 
 	for (int st = 0; st < K; st++) {
 #pragma unroll
 		for (int j = st + 1; j <= NW - 2 - st; j += 2)
-			if (idx[j] >= ph.lo[st] && idx[j] <= ph.hi[st])
-				w[j] = INV ? W::inv_step(st, w[j], w[j - 1], w[j + 1]) : W::fwd_step(st, w[j], w[j - 1], w[j + 1]);
+			if (idx[j] >= ph.lo[st] && idx[j] <= ph.hi[st]) {
+				// (a line end: both taps are one sample, the reference adds (2c)*x -- dwt_lift.h)
+				const bool end = idx[j] == 0 || idx[j] == N - 1;
+				w[j] = INV ? inv_step_at<W>(st, end, w[j], w[j - 1], w[j + 1]) : fwd_step_at<W>(st, end, w[j], w[j - 1], w[j + 1]);
+			}
 	}
 	const int c0 = INV ? K - 1 : K; // window position of sample 2k
 #pragma unroll

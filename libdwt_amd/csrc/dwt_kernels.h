@@ -69,6 +69,8 @@ struct FwdLevelArgs {
 	long h_pitch, h_bstride;
 	int W, H, batch;
 	int interleaved = 0; // 1: write rows/columns interleaved to out_h (3-D path / in-place lifting layout)
+	int plain_ends = 0;  // 1: line ends as reflection gives them, c*(x+x), not the reference's end form (dwt_lift.h): the 3-D
+	                     // path's xy sweep, which must give the bits of the fused 3-D level kernels (they keep the reflected form)
 	int il_ll = 0;       // interleaved only: also write the LL samples densely to out_ll
 	int temporal = 0;    // 1: every store temporal (the outputs are read again at once: staging of an in-place call)
 	int pair_lo = 0, pair_hi = 0; // pair_hi > 0: only the tiles that start at a row pair in [pair_lo, pair_hi) -- multiples of 64 --
@@ -96,6 +98,7 @@ struct InvLevelArgs {
 	long out_pitch, out_bstride;
 	int W, H, batch;
 	int interleaved = 0; // 1: interleaved input: even rows at in_ll (row r/2), odd rows at in_h (row r/2)
+	int plain_ends = 0;  // see FwdLevelArgs
 	int temporal_out = 0; // Mallat: the result is the next level's low-pass input and fits the Infinity Cache: stored temporal
 	int pair_lo = 0, pair_hi = 0; // pair_hi > 0: only the tiles that start at a row pair in [pair_lo, pair_hi) run (see FwdLevelArgs)
 	const CopyRects *ride = nullptr; // see FwdLevelArgs

@@ -11,14 +11,17 @@
 //   CDF 5/3 float  src/libdwt.c:10986-11030 / 11785-11829, constants inline.h:331-335
 //
 // Conventions.  A line is an interleaved signal a[0..N): even samples become L
-// (s), odd samples become H (d).  Ends use whole-sample symmetric reflection, which
-// reproduces the reference's explicit end formulas (`2*c*x` == `c*(x+x)` in fp32; the
-// fixed-point 9/7 writes `a[N-2]+a[N-2]` itself).  The int 5/3 is the exception: its
-// line ends are `(d+1)>>1` and `-= s` (:10971-10976, :11768-11773), which differ from the
-// reflected `(d+d+2)>>2` / `(s+s)>>1` once the doubled term wraps (|x| >= 2^30), so that
-// policy carries explicit END FORMS (kEndForms, fwd_end / inv_end) and every kernel
-// applies them to the samples whose two taps are one and the same sample (index 0 and
-// N-1 after reflection).  Int arithmetic wraps modulo 2^32 like the compiled reference
+// (s), odd samples become H (d).  Ends use whole-sample symmetric reflection: at index 0 and
+// N-1 both taps of a sample are one and the same sample x.  The reference does not evaluate
+// its interior formula there but an END FORM of its own: the float and double kernels add
+// `2*c*x`, i.e. (2c)*x (:9545-9552, :9873-9907, :10994-11017, :2024-2083) -- the same bits as
+// c*(x+x) unless x+x overflows (|x| > FLT_MAX/2) --, the int 5/3 `(d+1)>>1` and `-= s`
+// (:10971-10976, :11768-11773), which differ from the reflected `(d+d+2)>>2` / `(s+s)>>1` once
+// the doubled term wraps (|x| >= 2^30); only the fixed-point 9/7 writes `a[N-2]+a[N-2]` itself.
+// So the policies carry explicit END FORMS (kEndForms, fwd_end / inv_end) and the kernels
+// apply them to the samples whose two taps are one and the same sample.  The tile sweeps do it
+// on a path of its own, taken by the waves whose tile holds a line end (wave-uniform tests: a
+// tile's columns, an iteration's rows), so that the interior pays nothing.  Int arithmetic wraps modulo 2^32 like the compiled reference
 // (done in unsigned here: signed overflow is undefined for the compiler).  A forward transform runs K lifting
 // steps, step s acting on samples of parity (s+1)&1, then scales; an inverse
 // transform descales, then runs K steps, step s acting on parity s&1.
@@ -29,7 +32,7 @@ namespace dwt {
 
 struct Cdf97S {
 	using T = float;
-	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
+	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
 	static constexpr int K = 4;          // lifting steps; also the halo in samples
 	static constexpr bool kScaleSingle = true;   // N==1 lines are scaled (:10757, :11546)
 	static constexpr bool kSkipSingleLine = true; // 2-D drivers skip a direction with one line (:12837)
@@ -54,6 +57,9 @@ struct Cdf97S {
 	// N==1: forward *s1 (:10759); inverse *s2 where s2 = (float)(1/1.1496043988602) (inline.h:315)
 	static __device__ __forceinline__ T fwd_single(T v) { return v * zeta(); }
 	static __device__ __forceinline__ T inv_single(T v) { return v * (float)(1 / 1.1496043988602); }
+	// line ends: both taps are the sample m; `2*alpha*(x)` as the reference writes it (:9545, :9552, :9873, :9879)
+	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return c + (2.0f * fc(s)) * m; }
+	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return c + (2.0f * ic(s)) * m; }
 };
 
 // Same wavelet with each lifting step contracted to one fused multiply-add.  NOT the
@@ -62,6 +68,8 @@ struct Cdf97S {
 struct Cdf97SFma : Cdf97S {
 	static __device__ __forceinline__ T fwd_step(int s, T c, T l, T r) { return __builtin_fmaf(fc(s), l + r, c); }
 	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r) { return __builtin_fmaf(ic(s), l + r, c); }
+	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return __builtin_fmaf(2.0f * fc(s), m, c); }
+	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return __builtin_fmaf(2.0f * ic(s), m, c); }
 };
 
 struct Cdf53I {
@@ -153,7 +161,7 @@ struct Cdf97IIp : Cdf97I {
 
 struct Cdf53S {
 	using T = float;
-	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
+	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
 	static constexpr int K = 2;
 	static constexpr bool kScaleSingle = true;    // :10998-11003, :11797-11802
 	static constexpr bool kSkipSingleLine = false; // :16507-16523 run unconditionally
@@ -172,6 +180,9 @@ struct Cdf53S {
 	static __device__ __forceinline__ T inv_scale(int parity, T v) { return parity ? v * s1() : v * s2(); }
 	static __device__ __forceinline__ T fwd_single(T v) { return v * s1(); }
 	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
+	// line ends (:11012-11017, :11811-11816): `-= 2*p1*x`, `+= 2*u1*x`
+	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.5f) * m : c + (2 * 0.25f) * m; }
+	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.25f) * m : c + (2 * 0.5f) * m; }
 };
 
 // dwt-simple.c's 5/3 (fdwt2_cdf53_*, :1031-1078, :1531-1570): same steps, but the odd
@@ -185,7 +196,7 @@ struct Cdf53SNew : Cdf53S {
 // two stored constants s1, s2 = 1/1.1496043988602.
 struct Cdf97D {
 	using T = double;
-	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
+	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
 	static constexpr int K = 4;
 	static constexpr bool kScaleSingle = true;
 	static constexpr bool kSkipSingleLine = false; // :12490-12506 run unconditionally
@@ -208,12 +219,15 @@ struct Cdf97D {
 	static __device__ __forceinline__ T inv_scale(int parity, T v) { return parity ? v * s1() : v * s2(); }
 	static __device__ __forceinline__ T fwd_single(T v) { return v * s1(); }
 	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
+	// line ends (:2040-2047, :11439-11446): `+= 2*u*x`, `-= 2*p*x`
+	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return s == 0 ? c - (2 * p1()) * m : s == 1 ? c + (2 * u1()) * m : s == 2 ? c - (2 * p2()) * m : c + (2 * u2()) * m; }
+	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return s == 0 ? c - (2 * u2()) * m : s == 1 ? c + (2 * p2()) * m : s == 2 ? c - (2 * u1()) * m : c + (2 * p1()) * m; }
 };
 
 // src/libdwt.c:2085-2130, 11484-11530; constants src/inline.h:337-341
 struct Cdf53D {
 	using T = double;
-	static constexpr bool kEndForms = false; // the reflected taps ARE the reference's end formulas
+	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
 	static constexpr int K = 2;
 	static constexpr bool kScaleSingle = true;
 	static constexpr bool kSkipSingleLine = false;
@@ -226,6 +240,8 @@ struct Cdf53D {
 	static __device__ __forceinline__ T inv_scale(int parity, T v) { return parity ? v * s1() : v * s2(); }
 	static __device__ __forceinline__ T fwd_single(T v) { return v * s1(); }
 	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
+	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.5) * m : c + (2 * 0.25) * m; }
+	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.25) * m : c + (2 * 0.5) * m; }
 };
 
 // Whole-sample symmetric reflection of i into [0, N), N >= 2, any i.

@@ -270,12 +270,22 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 		for (int v = 0; v < CPT; v++)
 			st[s][v] = 0;
 
-	// explicit line-end forms (int 5/3 only): which of the lane's columns c - K .. c + CPT + K - 1
-	// are a row's ends; the rows that are a column's ends are found per iteration (wave-uniform)
-	static_assert(!W::kEndForms || K == 2, "end forms are wired into the two-step vertical lift only");
+	// explicit line-end forms: which of the lane's columns c - K .. c + CPT + K - 1 are a row's ends -- only the tiles
+	// that hold column 0 or W - 1 have any (`h_any`, wave-uniform: the interior tiles run the plain lift) --; the rows that
+	// are a column's ends are found per iteration (wave-uniform as well)
 	[[maybe_unused]] unsigned hends = 0;
-	if constexpr (W::kEndForms)
+	[[maybe_unused]] bool h_any = false;
+	if constexpr (W::kEndForms) {
 		hends = end_mask<NARR>(c0 + lane * CPT - K, a.W);
+		h_any = !a.plain_ends && __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+	}
+	// row r (any r the sweep meets) is an end of its column: r == 0 or r == H - 1 after reflection (one bounce when tall)
+	[[maybe_unused]] auto row_is_end = [&](int r) {
+		if (tall)
+			return r == 0 || r == a.H - 1;
+		const int rr = reflect(r, a.H);
+		return rr == 0 || rr == a.H - 1;
+	};
 
 	for (int it = 0; it < kAhead && it < n_iter; it++)
 		issue(it);
@@ -338,7 +348,16 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 #pragma unroll
 			for (int e = 0; e < 4; e++)
 				x[K + e] = from_bits<T>(O0[e]);
-			lift_fwd_regs<W, NARR>(x, hends);
+			if constexpr (W::kEndForms) {
+				if (h_any) {
+					DWT_END_PATH();
+					lift_fwd_regs<W, NARR>(x, hends);
+				}
+				else
+					lift_fwd_regs<W, NARR>(x, 0u);
+			} else {
+				lift_fwd_regs<W, NARR>(x, 0u);
+			}
 #pragma unroll
 			for (int v = 0; v < CPT; v++)
 				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
@@ -347,35 +366,53 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 		rslot = rslot + 2 >= kRing ? 0 : rslot + 2;
 
 		// vertical pass: streaming lifting, state in registers
-		[[maybe_unused]] bool vend_o = false, vend_e = false; // rows 2q-1 / 2q-2 are column ends
+		// step s of this iteration acts on row 2q-1-s: which of them are column ends (wave-uniform; almost never any)
+		[[maybe_unused]] bool vend[K] = {};
+		[[maybe_unused]] bool v_any = false;
 		if constexpr (W::kEndForms) {
-			const int ro = reflect(2 * (q0 + it) - 1, a.H), re = reflect(2 * (q0 + it) - 2, a.H);
-			vend_o = ro == 0 || ro == a.H - 1;
-			vend_e = re == 0 || re == a.H - 1;
+#pragma unroll
+			for (int s_ = 0; s_ < K; s_++) {
+				vend[s_] = row_is_end(2 * (q0 + it) - 1 - s_);
+				v_any = !a.plain_ends && (v_any || vend[s_]);
+			}
 		}
 		T lo[CPT], hi[CPT];
+		// `ENDS`: the iteration meets a column end -- the steps on that row take the end form
+		auto vertical = [&](auto ends_tag) {
+			constexpr bool ENDS = decltype(ends_tag)::value;
 #pragma unroll
-		for (int v = 0; v < CPT; v++) {
-			const T ov = row[0][v], ev = row[1][v];
-			if constexpr (K == 4) {
-				const T d1n = W::fwd_step(0, ov, st[0][v], ev);
-				const T s1n = W::fwd_step(1, st[0][v], st[1][v], d1n);
-				const T d2n = W::fwd_step(2, st[1][v], st[2][v], s1n);
-				const T s2n = W::fwd_step(3, st[2][v], st[3][v], d2n);
-				lo[v] = W::fwd_scale(0, s2n);
-				hi[v] = W::fwd_scale(1, d2n);
-				st[0][v] = ev;
-				st[1][v] = d1n;
-				st[2][v] = s1n;
-				st[3][v] = d2n;
-			} else {
-				const T d1n = fwd_step_at<W>(0, vend_o, ov, st[0][v], ev);
-				const T s1n = fwd_step_at<W>(1, vend_e, st[0][v], st[1][v], d1n);
-				lo[v] = W::fwd_scale(0, s1n);
-				hi[v] = W::fwd_scale(1, d1n);
-				st[0][v] = ev;
-				st[1][v] = d1n;
+			for (int v = 0; v < CPT; v++) {
+				const T ov = row[0][v], ev = row[1][v];
+				if constexpr (K == 4) {
+					const T d1n = fwd_step_at<W>(0, ENDS && vend[0], ov, st[0][v], ev);
+					const T s1n = fwd_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], d1n);
+					const T d2n = fwd_step_at<W>(2, ENDS && vend[2], st[1][v], st[2][v], s1n);
+					const T s2n = fwd_step_at<W>(3, ENDS && vend[3], st[2][v], st[3][v], d2n);
+					lo[v] = W::fwd_scale(0, s2n);
+					hi[v] = W::fwd_scale(1, d2n);
+					st[0][v] = ev;
+					st[1][v] = d1n;
+					st[2][v] = s1n;
+					st[3][v] = d2n;
+				} else {
+					const T d1n = fwd_step_at<W>(0, ENDS && vend[0], ov, st[0][v], ev);
+					const T s1n = fwd_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], d1n);
+					lo[v] = W::fwd_scale(0, s1n);
+					hi[v] = W::fwd_scale(1, d1n);
+					st[0][v] = ev;
+					st[1][v] = d1n;
+				}
 			}
+		};
+		if constexpr (W::kEndForms) {
+			if (v_any) {
+				DWT_END_PATH();
+				vertical(std::true_type{});
+			}
+			else
+				vertical(std::false_type{});
+		} else {
+			vertical(std::false_type{});
 		}
 
 		if constexpr (IL) {

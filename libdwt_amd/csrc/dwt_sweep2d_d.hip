@@ -91,6 +91,16 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 
 	int islot = 0, rslot = 0;
 	const bool tall = a.H >= 64;
+	// line-end forms (dwt_lift.h; see k_fwd_sweep): the lane's columns c - K .. that are a row's ends, any in this tile,
+	// and the test for a row being a column's end
+	const unsigned hends = end_mask<NARR>(c0 + lane * CPT - K, a.W);
+	const bool h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+	auto row_is_end = [&](int r) {
+		if (tall)
+			return r == 0 || r == a.H - 1;
+		const int rr = reflect(r, a.H);
+		return rr == 0 || rr == a.H - 1;
+	};
 	auto issue = [&](int it) {
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
@@ -158,37 +168,58 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 			x[K + 1] = dbl(r[2][2], r[2][3]);
 			x[K + 2] = dbl(r[3][0], r[3][1]);
 			x[K + 3] = dbl(r[3][2], r[3][3]);
-			lift_fwd_regs<W, NARR>(x);
+			if (h_any) {
+				DWT_END_PATH();
+				lift_fwd_regs<W, NARR>(x, hends);
+			}
+			else
+				lift_fwd_regs<W, NARR>(x, 0u);
 #pragma unroll
 			for (int v = 0; v < CPT; v++)
 				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
 		}
 		rslot = rslot + 2 >= RING ? 0 : rslot + 2;
 
-		T lo[CPT], hi[CPT];
+		// step s of this iteration acts on row 2q-1-s: which of them are column ends (wave-uniform; almost never any)
+		bool vend[K], v_any = false;
 #pragma unroll
-		for (int v = 0; v < CPT; v++) {
-			const T ov = row[0][v], ev = row[1][v];
-			if constexpr (K == 4) {
-				const T d1n = W::fwd_step(0, ov, st[0][v], ev);
-				const T s1n = W::fwd_step(1, st[0][v], st[1][v], d1n);
-				const T d2n = W::fwd_step(2, st[1][v], st[2][v], s1n);
-				const T s2n = W::fwd_step(3, st[2][v], st[3][v], d2n);
-				lo[v] = W::fwd_scale(0, s2n);
-				hi[v] = W::fwd_scale(1, d2n);
-				st[0][v] = ev;
-				st[1][v] = d1n;
-				st[2][v] = s1n;
-				st[3][v] = d2n;
-			} else {
-				const T d1n = W::fwd_step(0, ov, st[0][v], ev);
-				const T s1n = W::fwd_step(1, st[0][v], st[1][v], d1n);
-				lo[v] = W::fwd_scale(0, s1n);
-				hi[v] = W::fwd_scale(1, d1n);
-				st[0][v] = ev;
-				st[1][v] = d1n;
-			}
+		for (int s_ = 0; s_ < K; s_++) {
+			vend[s_] = row_is_end(2 * (q0 + it) - 1 - s_);
+			v_any = v_any || vend[s_];
 		}
+		T lo[CPT], hi[CPT];
+		auto vertical = [&](auto ends_tag) {
+			constexpr bool ENDS = decltype(ends_tag)::value;
+#pragma unroll
+			for (int v = 0; v < CPT; v++) {
+				const T ov = row[0][v], ev = row[1][v];
+				if constexpr (K == 4) {
+					const T d1n = fwd_step_at<W>(0, ENDS && vend[0], ov, st[0][v], ev);
+					const T s1n = fwd_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], d1n);
+					const T d2n = fwd_step_at<W>(2, ENDS && vend[2], st[1][v], st[2][v], s1n);
+					const T s2n = fwd_step_at<W>(3, ENDS && vend[3], st[2][v], st[3][v], d2n);
+					lo[v] = W::fwd_scale(0, s2n);
+					hi[v] = W::fwd_scale(1, d2n);
+					st[0][v] = ev;
+					st[1][v] = d1n;
+					st[2][v] = s1n;
+					st[3][v] = d2n;
+				} else {
+					const T d1n = fwd_step_at<W>(0, ENDS && vend[0], ov, st[0][v], ev);
+					const T s1n = fwd_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], d1n);
+					lo[v] = W::fwd_scale(0, s1n);
+					hi[v] = W::fwd_scale(1, d1n);
+					st[0][v] = ev;
+					st[1][v] = d1n;
+				}
+			}
+		};
+		if (v_any) {
+			DWT_END_PATH();
+			vertical(std::true_type{});
+		}
+		else
+			vertical(std::false_type{});
 		if (it >= K) {
 			const int k = A + it - K;
 			// each quarter row of the Mallat layout is a buffer of its own
@@ -312,6 +343,17 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 	const int hd = (lane >> 1) & 7, hs = (lane >> 4) & 1;
 	const int hsub = hd < 4 ? cl0 - 4 + hd : cl0 + M + (hd - 4);
 	const int halo_col = reflect(2 * hsub + hs, a.W) >> 1;
+	// line-end forms (dwt_lift.h; see k_inv_sweep): the lane's samples c - K + 1 .. that are a row's ends, any in this
+	// tile, and the test for a row being a column's end
+	const unsigned hends = end_mask<NARR>(c0 + lane * CPT - K + 1, a.W);
+	const bool h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+	const bool tall = a.H >= 64;
+	auto row_is_end = [&](int r) {
+		if (tall)
+			return r == 0 || r == a.H - 1;
+		const int rr = reflect(r, a.H);
+		return rr == 0 || rr == a.H - 1;
+	};
 
 	auto issue = [&](int it) {
 		const int p = p0 + it;
@@ -407,35 +449,56 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 		T val[2][CPT];
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
-			lift_inv_regs<W, NARR>(x[rr]);
+			if (h_any) {
+				DWT_END_PATH();
+				lift_inv_regs<W, NARR>(x[rr], hends);
+			}
+			else
+				lift_inv_regs<W, NARR>(x[rr], 0u);
 #pragma unroll
 			for (int v = 0; v < CPT; v++)
 				val[rr][v] = W::inv_scale(rr, x[rr][K - 1 + v]);
 		}
-		T odd_row[CPT], even_row[CPT];
+		// step s of this iteration acts on row 2p-s: which of them are column ends (wave-uniform; almost never any)
+		bool vend[K], v_any = false;
 #pragma unroll
-		for (int v = 0; v < CPT; v++) {
-			const T s2 = val[0][v], d2 = val[1][v];
-			if constexpr (K == 4) {
-				const T s1n = W::inv_step(0, s2, st[0][v], d2);
-				const T d1n = W::inv_step(1, st[0][v], st[1][v], s1n);
-				const T en = W::inv_step(2, st[1][v], st[2][v], d1n);
-				const T on = W::inv_step(3, st[2][v], st[3][v], en);
-				odd_row[v] = on;
-				even_row[v] = en;
-				st[0][v] = d2;
-				st[1][v] = s1n;
-				st[2][v] = d1n;
-				st[3][v] = en;
-			} else {
-				const T en = W::inv_step(0, s2, st[0][v], d2);
-				const T on = W::inv_step(1, st[0][v], st[1][v], en);
-				odd_row[v] = on;
-				even_row[v] = en;
-				st[0][v] = d2;
-				st[1][v] = en;
-			}
+		for (int s_ = 0; s_ < K; s_++) {
+			vend[s_] = row_is_end(2 * p - s_);
+			v_any = v_any || vend[s_];
 		}
+		T odd_row[CPT], even_row[CPT];
+		auto vertical = [&](auto ends_tag) {
+			constexpr bool ENDS = decltype(ends_tag)::value;
+#pragma unroll
+			for (int v = 0; v < CPT; v++) {
+				const T s2 = val[0][v], d2 = val[1][v];
+				if constexpr (K == 4) {
+					const T s1n = inv_step_at<W>(0, ENDS && vend[0], s2, st[0][v], d2);
+					const T d1n = inv_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], s1n);
+					const T en = inv_step_at<W>(2, ENDS && vend[2], st[1][v], st[2][v], d1n);
+					const T on = inv_step_at<W>(3, ENDS && vend[3], st[2][v], st[3][v], en);
+					odd_row[v] = on;
+					even_row[v] = en;
+					st[0][v] = d2;
+					st[1][v] = s1n;
+					st[2][v] = d1n;
+					st[3][v] = en;
+				} else {
+					const T en = inv_step_at<W>(0, ENDS && vend[0], s2, st[0][v], d2);
+					const T on = inv_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], en);
+					odd_row[v] = on;
+					even_row[v] = en;
+					st[0][v] = d2;
+					st[1][v] = en;
+				}
+			}
+		};
+		if (v_any) {
+			DWT_END_PATH();
+			vertical(std::true_type{});
+		}
+		else
+			vertical(std::false_type{});
 		const int pe = (K == 4) ? p - 1 : p;
 		const int po = (K == 4) ? p - 2 : p - 1;
 		const bool ve = pe >= A && pe < B;

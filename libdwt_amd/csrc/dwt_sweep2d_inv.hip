@@ -240,15 +240,40 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 			for (int v = 0; v < NVG; v++)
 				st[s][gi][v] = 0;
 
-	// explicit line-end forms (int 5/3 only): the ends of a row among each group's samples
-	// c - K + 1 .. c + CG + K - 1; the rows that are a column's ends are found per iteration
-	static_assert(!W::kEndForms || (K == 2 && !IL), "end forms are wired into the two-step Mallat sweeps only");
+	// explicit line-end forms: the ends of a row among each group's samples c - K + 1 .. c + CG + K - 1 -- only the tiles
+	// that hold column 0 or W - 1 have any (`h_any`, wave-uniform: the interior tiles run the plain lift) --; the rows that
+	// are a column's ends are found per iteration (wave-uniform as well)
 	[[maybe_unused]] unsigned hends[G] = {};
+	[[maybe_unused]] bool h_any = false;
 	if constexpr (W::kEndForms) {
+		unsigned all = 0;
 #pragma unroll
-		for (int gi = 0; gi < G; gi++)
+		for (int gi = 0; gi < G; gi++) {
 			hends[gi] = end_mask<NARR>(c0 + 64 * CG * gi + lane * CG - K + 1, a.W);
+			all |= hends[gi];
+		}
+		h_any = !a.plain_ends && __builtin_amdgcn_ballot_w64(all != 0) != 0;
 	}
+	const bool tall = a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
+	[[maybe_unused]] auto row_is_end = [&](int r) {
+		if (tall)
+			return r == 0 || r == a.H - 1;
+		const int rr = reflect(r, a.H);
+		return rr == 0 || rr == a.H - 1;
+	};
+	// the horizontal inverse lift of one register row: the end forms only where the tile has a line end
+	auto hlift = [&](T (&xr)[NARR], int gi) {
+		if constexpr (W::kEndForms) {
+			if (h_any) {
+				DWT_END_PATH();
+				lift_inv_regs<W, NARR>(xr, hends[gi]);
+			}
+			else
+				lift_inv_regs<W, NARR>(xr, 0u);
+		} else {
+			lift_inv_regs<W, NARR>(xr, 0u);
+		}
+	};
 
 	for (int it = 0; it < kAhead && it < n_iter; it++)
 		issue(it);
@@ -330,7 +355,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 			if constexpr (!W::kInvColsFirst) {
 #pragma unroll
 				for (int rr = 0; rr < 2; rr++) {
-					lift_inv_regs<W, NARR>(x[rr][gi], hends[gi]);
+					hlift(x[rr][gi], gi);
 					// after the horizontal inverse the row is plain samples again; the
 					// vertical pass descales by ROW parity
 #pragma unroll
@@ -348,39 +373,56 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 
 		// vertical inverse, streaming.  K == 4: at step p the rows 2p-3 (odd) and
 		// 2p-2 (even) are final; K == 2: rows 2p-1 and 2p.
-		[[maybe_unused]] bool vend_e = false, vend_o = false; // rows 2p / 2p-1 are column ends
+		// step s of this iteration acts on row 2p-s: which of them are column ends (wave-uniform; almost never any)
+		[[maybe_unused]] bool vend[K] = {};
+		[[maybe_unused]] bool v_any = false;
 		if constexpr (W::kEndForms) {
-			const int re = reflect(2 * p, a.H), ro = reflect(2 * p - 1, a.H);
-			vend_e = re == 0 || re == a.H - 1;
-			vend_o = ro == 0 || ro == a.H - 1;
+#pragma unroll
+			for (int s_ = 0; s_ < K; s_++) {
+				vend[s_] = row_is_end(2 * p - s_);
+				v_any = !a.plain_ends && (v_any || vend[s_]);
+			}
 		}
 		T odd_row[G][NVG], even_row[G][NVG];
+		auto vertical = [&](auto ends_tag) {
+			constexpr bool ENDS = decltype(ends_tag)::value;
 #pragma unroll
-		for (int gi = 0; gi < G; gi++)
+			for (int gi = 0; gi < G; gi++)
 #pragma unroll
-		for (int v = 0; v < NVG; v++) {
-			const T s2 = val[0][gi][v], d2 = val[1][gi][v];
-			if constexpr (K == 4) {
-				// st: [0] d2[p-1], [1] s1[p-1], [2] d1[p-2], [3] e[p-2]
-				const T s1n = W::inv_step(0, s2, st[0][gi][v], d2);               // s1[p]
-				const T d1n = W::inv_step(1, st[0][gi][v], st[1][gi][v], s1n);    // d1[p-1]
-				const T en = W::inv_step(2, st[1][gi][v], st[2][gi][v], d1n);     // e[p-1]
-				const T on = W::inv_step(3, st[2][gi][v], st[3][gi][v], en);      // o[p-2]
-				odd_row[gi][v] = on;
-				even_row[gi][v] = en;
-				st[0][gi][v] = d2;
-				st[1][gi][v] = s1n;
-				st[2][gi][v] = d1n;
-				st[3][gi][v] = en;
-			} else {
-				// st: [0] d[p-1], [1] e[p-1]
-				const T en = inv_step_at<W>(0, vend_e, s2, st[0][gi][v], d2);                // e[p]
-				const T on = inv_step_at<W>(1, vend_o, st[0][gi][v], st[1][gi][v], en);      // o[p-1]
-				odd_row[gi][v] = on;
-				even_row[gi][v] = en;
-				st[0][gi][v] = d2;
-				st[1][gi][v] = en;
+			for (int v = 0; v < NVG; v++) {
+				const T s2 = val[0][gi][v], d2 = val[1][gi][v];
+				if constexpr (K == 4) {
+					// st: [0] d2[p-1], [1] s1[p-1], [2] d1[p-2], [3] e[p-2]
+					const T s1n = inv_step_at<W>(0, ENDS && vend[0], s2, st[0][gi][v], d2);               // s1[p]
+					const T d1n = inv_step_at<W>(1, ENDS && vend[1], st[0][gi][v], st[1][gi][v], s1n);    // d1[p-1]
+					const T en = inv_step_at<W>(2, ENDS && vend[2], st[1][gi][v], st[2][gi][v], d1n);     // e[p-1]
+					const T on = inv_step_at<W>(3, ENDS && vend[3], st[2][gi][v], st[3][gi][v], en);      // o[p-2]
+					odd_row[gi][v] = on;
+					even_row[gi][v] = en;
+					st[0][gi][v] = d2;
+					st[1][gi][v] = s1n;
+					st[2][gi][v] = d1n;
+					st[3][gi][v] = en;
+				} else {
+					// st: [0] d[p-1], [1] e[p-1]
+					const T en = inv_step_at<W>(0, ENDS && vend[0], s2, st[0][gi][v], d2);                // e[p]
+					const T on = inv_step_at<W>(1, ENDS && vend[1], st[0][gi][v], st[1][gi][v], en);      // o[p-1]
+					odd_row[gi][v] = on;
+					even_row[gi][v] = en;
+					st[0][gi][v] = d2;
+					st[1][gi][v] = en;
+				}
 			}
+		};
+		if constexpr (W::kEndForms) {
+			if (v_any) {
+				DWT_END_PATH();
+				vertical(std::true_type{});
+			}
+			else
+				vertical(std::false_type{});
+		} else {
+			vertical(std::false_type{});
 		}
 		// output rows and their validity inside this tile
 		const int pe = (K == 4) ? p - 1 : p;     // pair index of even_row
@@ -393,8 +435,8 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 #pragma unroll
 		for (int gi = 0; gi < G; gi++) {
 			if constexpr (W::kInvColsFirst) {
-				lift_inv_regs<W, NARR>(odd_row[gi], hends[gi]);
-				lift_inv_regs<W, NARR>(even_row[gi], hends[gi]);
+				hlift(odd_row[gi], gi);
+				hlift(even_row[gi], gi);
 #pragma unroll
 				for (int v = 0; v < CG; v++) {
 					orow[gi][v] = odd_row[gi][K - 1 + v];

@@ -75,8 +75,9 @@ def test_placed_batch_through_the_sharded_entry(dwt, oracle, wname):
         dwt.grant_access(dst, [0])
         assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
         got = np.empty_like(imgs)
+        zeros = np.zeros_like(imgs)  # (kept alive: the address of a temporary would dangle by the time the copy reads it)
         for devices in ([0, 0, 0], [0], [0, 0, 0, 0, 0]):
-            assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+            assert L.dwt_hip_memcpy_h2d(dst, zeros.ctypes.data, imgs.nbytes) == 0
             assert dwt.transform2d_batch_sharded(wname, 0, src, dst, h * w * 4, nb, w * 4, w, h, J, devices) == J
             assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
             assert np.array_equal(bits(got), bits(want)), devices
@@ -163,7 +164,8 @@ def test_tuning_in_four_slots_at_once(dwt, oracle):
         dwt.tune_batch_multi("cdf97_s", 0, srcs, dsts, [per] * 4, [0] * 4, n * n * 4, n * 4, n, n, J)
         assert len(dwt.placement_report()[0]) >= 1 and dwt.get_option("tile_cache_size") >= 1   # (the caller's own slot)
         for p, s in zip(dsts, shards):
-            assert L.dwt_hip_memcpy_h2d(p, np.zeros_like(s).ctypes.data, s.nbytes) == 0
+            zero_img = np.zeros_like(s)  # (bound to a name: a temporary's address would dangle)
+            assert L.dwt_hip_memcpy_h2d(p, zero_img.ctypes.data, s.nbytes) == 0
         launches = dwt.get_option("stat_launches")
         assert dwt.transform2d_batch_multi("cdf97_s", 0, srcs, dsts, [per] * 4, [0] * 4, n * n * 4, n * 4, n, n, J) == J
         assert dwt.get_option("stat_launches") - launches == J
@@ -212,7 +214,8 @@ def test_a_transform_call_measures_nothing(dwt, oracle):
         dwt.dwt_util_finish()
         dwt.tune("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
         assert len(dwt.placement_report()[0]) >= 2 and dwt.get_option("tile_cache_size") >= 2
-        assert L.dwt_hip_memcpy_h2d(dst + 15 * n * n * 4, np.zeros((n, n), np.float32).ctypes.data, n * n * 4) == 0
+        zero_img = np.zeros((n, n), np.float32)  # (bound to a name: a temporary's address would dangle)
+        assert L.dwt_hip_memcpy_h2d(dst + 15 * n * n * 4, zero_img.ctypes.data, n * n * 4) == 0
         l0, a0 = dwt.get_option("stat_launches"), dwt.get_option("stat_allocs")
         assert dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J) == J
         dwt.sync()

@@ -1056,7 +1056,8 @@ def test_placement_entries(dwt, oracle):
         b1 = nb * ((w + 3) // 4 + 3) * ((h + 3) // 4) * 4 + 64
         w0, w1 = L.dwt_hip_malloc(b0), L.dwt_hip_malloc(b1)
         assert L.dwt_hip_set_workspace(w0, b0, w1, b1) == 0, dwt.last_error()
-        assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+        zero_img = np.zeros_like(imgs)  # (bound to a name: a temporary's address would dangle)
+        assert L.dwt_hip_memcpy_h2d(dst, zero_img.ctypes.data, imgs.nbytes) == 0
         assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
         assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
         assert np.array_equal(bits(got), bits(want))
@@ -1072,7 +1073,8 @@ def test_placement_entries(dwt, oracle):
         dwt.tune("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J)
         trials, kept = dwt.placement_report()
         assert len(trials) >= 1 and 0 <= kept < len(trials)
-        assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+        zero_img = np.zeros_like(imgs)  # (bound to a name: a temporary's address would dangle)
+        assert L.dwt_hip_memcpy_h2d(dst, zero_img.ctypes.data, imgs.nbytes) == 0
         assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
         assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
         assert np.array_equal(bits(got), bits(want))
@@ -1096,7 +1098,8 @@ def test_placement_entries(dwt, oracle):
         b1 = nb * ((w + 3) // 4 + 3) * ((h + 3) // 4) * 4 + 64
         w0, w1 = L.dwt_hip_malloc(b0), L.dwt_hip_malloc(b1)
         assert L.dwt_hip_set_workspace(w0, b0, w1, b1) == 0, dwt.last_error()
-        assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+        zero_img = np.zeros_like(imgs)  # (bound to a name: a temporary's address would dangle)
+        assert L.dwt_hip_memcpy_h2d(dst, zero_img.ctypes.data, imgs.nbytes) == 0
         assert dwt.transform2d_batch("cdf97_s", 0, src, dst, h * w * 4, nb, w * 4, w, h, J) == J
         assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
         assert np.array_equal(bits(got), bits(want))
@@ -1172,7 +1175,8 @@ def test_measured_tile_heights_do_not_change_the_bits(dwt, oracle):
             before = dwt.get_option("tile_cache_size")
             dwt.tune("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J)
             assert dwt.get_option("tile_cache_size") - before == (1 if tune else 0)  # level 0 is the one level beyond the Infinity Cache
-            assert L.dwt_hip_memcpy_h2d(dst, np.zeros_like(imgs).ctypes.data, imgs.nbytes) == 0
+            zero_img = np.zeros_like(imgs)  # (bound to a name: a temporary's address would dangle)
+            assert L.dwt_hip_memcpy_h2d(dst, zero_img.ctypes.data, imgs.nbytes) == 0
             launches = dwt.get_option("stat_launches")
             for _ in range(2):
                 assert dwt.transform2d_batch("cdf97_s", 0, src, dst, n * n * 4, nb, n * 4, n, n, J) == J

@@ -28,11 +28,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The float / double policies' line-end forms are a BUILD option.  0 (libdwt_hip.so, the default): their line ends are what
+// reflection gives, c*(x+x) -- the same bits as the reference's (2c)*x unless x+x overflows, the one listed difference of
+// DESIGN.md s2.  1 (`make exact` -> libdwt_hip_exact.so): every 2-D kernel applies the reference's own form, bit for bit over
+// the whole float range (tests/test_hip_float_range.py runs against that build too).  Why not always: the paths cost
+// nothing where they are not taken, but their code in the sweep kernels does -- one 8192^2 image 155 -> 168 us, a batch of
+// eight + 3.5 % (scripts/r06/ab_calls.py, alternated on one box; cold instruction fetches of the five launches of a call
+// and the border tiles' waves holding their workgroups back).  The int 5/3 needs its end forms in every build.
+#ifndef DWT_FLOAT_END_FORMS
+#define DWT_FLOAT_END_FORMS 0
+#endif
+
 namespace dwt {
 
 struct Cdf97S {
 	using T = float;
-	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
+	static constexpr bool kEndForms = DWT_FLOAT_END_FORMS != 0; // the reference adds (2c)*x at a line end
 	static constexpr int K = 4;          // lifting steps; also the halo in samples
 	static constexpr bool kScaleSingle = true;   // N==1 lines are scaled (:10757, :11546)
 	static constexpr bool kSkipSingleLine = true; // 2-D drivers skip a direction with one line (:12837)
@@ -161,7 +172,7 @@ struct Cdf97IIp : Cdf97I {
 
 struct Cdf53S {
 	using T = float;
-	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
+	static constexpr bool kEndForms = DWT_FLOAT_END_FORMS != 0; // the reference adds (2c)*x at a line end
 	static constexpr int K = 2;
 	static constexpr bool kScaleSingle = true;    // :10998-11003, :11797-11802
 	static constexpr bool kSkipSingleLine = false; // :16507-16523 run unconditionally
@@ -196,7 +207,7 @@ struct Cdf53SNew : Cdf53S {
 // two stored constants s1, s2 = 1/1.1496043988602.
 struct Cdf97D {
 	using T = double;
-	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
+	static constexpr bool kEndForms = DWT_FLOAT_END_FORMS != 0; // the reference adds (2c)*x at a line end
 	static constexpr int K = 4;
 	static constexpr bool kScaleSingle = true;
 	static constexpr bool kSkipSingleLine = false; // :12490-12506 run unconditionally
@@ -227,7 +238,7 @@ struct Cdf97D {
 // src/libdwt.c:2085-2130, 11484-11530; constants src/inline.h:337-341
 struct Cdf53D {
 	using T = double;
-	static constexpr bool kEndForms = true; // the reference adds (2c)*x at a line end
+	static constexpr bool kEndForms = DWT_FLOAT_END_FORMS != 0; // the reference adds (2c)*x at a line end
 	static constexpr int K = 2;
 	static constexpr bool kScaleSingle = true;
 	static constexpr bool kSkipSingleLine = false;
@@ -287,6 +298,13 @@ static __device__ __forceinline__ typename W::T inv_step_at(int s, bool end, typ
 template <int n>
 static __device__ __forceinline__ unsigned end_mask(int g0, int N)
 {
+	// A window that leaves [0, N) by less than N on either side (every window of a tile sweep over a line of 64 samples or
+	// more): a sample is an end iff it IS sample 0 or N - 1 -- one bounce maps no other index onto them.  Two shifts instead
+	// of n reflections with their integer divisions (which cost the small, latency-bound levels of one image 2-3 us each).
+	if (N >= 64 && g0 > -N && g0 + n <= 2 * N - 1) {
+		const int j0 = -g0, j1 = N - 1 - g0;
+		return ((unsigned)j0 < (unsigned)n ? 1u << j0 : 0u) | ((unsigned)j1 < (unsigned)n ? 1u << j1 : 0u);
+	}
 	unsigned m = 0;
 #pragma unroll
 	for (int j = 0; j < n; j++) {
@@ -300,28 +318,31 @@ static __device__ __forceinline__ unsigned end_mask(int g0, int N)
 // whose element 0 is an EVEN sample.  After step s, entries j in [s+1, n-2-s] of
 // parity (s+1)&1 are valid; the caller takes the centre it needs.  Fully unrolled:
 // all indices are compile-time constants.
-// `ends`: end_mask of the array (used by policies with explicit end forms only).
-template <class W, int n>
+// `ends`: end_mask of the array (used by policies with explicit end forms only).  CAND: the entries that CAN be a line
+// end for this caller (compile time): only they test their bit of `ends`, the others take the plain step -- a tile sweep
+// whose tiles start at multiples of its width meets column 0 and the last column at two fixed entries, so that its
+// border tiles pay two tests per step pair instead of one per entry (measured: the full mask cost the sweeps 10 %).
+template <class W, int n, unsigned CAND = ~0u>
 static __device__ __forceinline__ void lift_fwd_regs(typename W::T (&a)[n], unsigned ends = 0)
 {
 #pragma unroll
 	for (int s = 0; s < W::K; s++) {
 #pragma unroll
 		for (int j = s + 1; j <= n - 2 - s; j += 2)
-			a[j] = fwd_step_at<W>(s, (ends >> j) & 1, a[j], a[j - 1], a[j + 1]);
+			a[j] = fwd_step_at<W>(s, ((CAND >> j) & 1) && ((ends >> j) & 1), a[j], a[j - 1], a[j + 1]);
 	}
 }
 
 // Inverse steps over a[0..n) whose element 0 is an ODD sample (so step 0, which
 // acts on even samples, again starts at j = 1).  Entries must be descaled first.
-template <class W, int n>
+template <class W, int n, unsigned CAND = ~0u>
 static __device__ __forceinline__ void lift_inv_regs(typename W::T (&a)[n], unsigned ends = 0)
 {
 #pragma unroll
 	for (int s = 0; s < W::K; s++) {
 #pragma unroll
 		for (int j = s + 1; j <= n - 2 - s; j += 2)
-			a[j] = inv_step_at<W>(s, (ends >> j) & 1, a[j], a[j - 1], a[j + 1]);
+			a[j] = inv_step_at<W>(s, ((CAND >> j) & 1) && ((ends >> j) & 1), a[j], a[j - 1], a[j + 1]);
 	}
 }
 

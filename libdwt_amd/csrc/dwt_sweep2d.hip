@@ -274,10 +274,14 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	// that hold column 0 or W - 1 have any (`h_any`, wave-uniform: the interior tiles run the plain lift) --; the rows that
 	// are a column's ends are found per iteration (wave-uniform as well)
 	[[maybe_unused]] unsigned hends = 0;
-	[[maybe_unused]] bool h_any = false;
+	[[maybe_unused]] bool h_any = false, h_simple = false;
+	// the two entries of a lane's window that meet a line end when the level's width is a multiple of CPT: column 0 is
+	// lane 0's own first column, column W - 1 a lane's own last one (entries 0 and NARR - 1 are never acted on)
+	constexpr unsigned kCand = (1u << K) | (1u << (K + CPT - 1));
 	if constexpr (W::kEndForms) {
 		hends = end_mask<NARR>(c0 + lane * CPT - K, a.W);
 		h_any = !a.plain_ends && __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+		h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
 	}
 	// row r (any r the sweep meets) is an end of its column: r == 0 or r == H - 1 after reflection (one bounce when tall)
 	[[maybe_unused]] auto row_is_end = [&](int r) {
@@ -349,12 +353,15 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 			for (int e = 0; e < 4; e++)
 				x[K + e] = from_bits<T>(O0[e]);
 			if constexpr (W::kEndForms) {
-				if (h_any) {
+				if (__builtin_expect(!h_any, 1)) {
+					lift_fwd_regs<W, NARR>(x, 0u);
+				} else if (h_simple) {
+					DWT_END_PATH();
+					lift_fwd_regs<W, NARR, kCand>(x, hends);
+				} else {
 					DWT_END_PATH();
 					lift_fwd_regs<W, NARR>(x, hends);
 				}
-				else
-					lift_fwd_regs<W, NARR>(x, 0u);
 			} else {
 				lift_fwd_regs<W, NARR>(x, 0u);
 			}
@@ -405,7 +412,7 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 			}
 		};
 		if constexpr (W::kEndForms) {
-			if (v_any) {
+			if (__builtin_expect(v_any, 0)) {
 				DWT_END_PATH();
 				vertical(std::true_type{});
 			}

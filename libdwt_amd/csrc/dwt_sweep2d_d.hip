@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 	// and the test for a row being a column's end
 	const unsigned hends = end_mask<NARR>(c0 + lane * CPT - K, a.W);
 	const bool h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+	constexpr unsigned kCand = (1u << K) | (1u << (K + CPT - 1)); // the two entries that meet a line end when W is a multiple of CPT
+	const bool h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
 	auto row_is_end = [&](int r) {
 		if (tall)
 			return r == 0 || r == a.H - 1;
@@ -168,12 +170,15 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 			x[K + 1] = dbl(r[2][2], r[2][3]);
 			x[K + 2] = dbl(r[3][0], r[3][1]);
 			x[K + 3] = dbl(r[3][2], r[3][3]);
-			if (h_any) {
+			if (__builtin_expect(!h_any, 1)) {
+				lift_fwd_regs<W, NARR>(x, 0u);
+			} else if (h_simple) {
+				DWT_END_PATH();
+				lift_fwd_regs<W, NARR, kCand>(x, hends);
+			} else {
 				DWT_END_PATH();
 				lift_fwd_regs<W, NARR>(x, hends);
 			}
-			else
-				lift_fwd_regs<W, NARR>(x, 0u);
 #pragma unroll
 			for (int v = 0; v < CPT; v++)
 				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 				}
 			}
 		};
-		if (v_any) {
+		if (__builtin_expect(v_any, 0)) {
 			DWT_END_PATH();
 			vertical(std::true_type{});
 		}
@@ -347,6 +352,8 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 	// tile, and the test for a row being a column's end
 	const unsigned hends = end_mask<NARR>(c0 + lane * CPT - K + 1, a.W);
 	const bool h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+	constexpr unsigned kCand = (1u << (K - 1)) | (1u << (K + CPT - 2)); // the two entries that meet a line end when W is a multiple of CPT
+	const bool h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
 	const bool tall = a.H >= 64;
 	auto row_is_end = [&](int r) {
 		if (tall)
@@ -449,12 +456,15 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 		T val[2][CPT];
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
-			if (h_any) {
+			if (__builtin_expect(!h_any, 1)) {
+				lift_inv_regs<W, NARR>(x[rr], 0u);
+			} else if (h_simple) {
+				DWT_END_PATH();
+				lift_inv_regs<W, NARR, kCand>(x[rr], hends);
+			} else {
 				DWT_END_PATH();
 				lift_inv_regs<W, NARR>(x[rr], hends);
 			}
-			else
-				lift_inv_regs<W, NARR>(x[rr], 0u);
 #pragma unroll
 			for (int v = 0; v < CPT; v++)
 				val[rr][v] = W::inv_scale(rr, x[rr][K - 1 + v]);
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 				}
 			}
 		};
-		if (v_any) {
+		if (__builtin_expect(v_any, 0)) {
 			DWT_END_PATH();
 			vertical(std::true_type{});
 		}

@@ -244,7 +244,10 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	// that hold column 0 or W - 1 have any (`h_any`, wave-uniform: the interior tiles run the plain lift) --; the rows that
 	// are a column's ends are found per iteration (wave-uniform as well)
 	[[maybe_unused]] unsigned hends[G] = {};
-	[[maybe_unused]] bool h_any = false;
+	[[maybe_unused]] bool h_any = false, h_simple = false;
+	// the two entries of a group's window that meet a line end when the level's width is a multiple of CG: column 0 is the
+	// group's own first sample, column W - 1 its own last one (entries 0 and NARR - 1 are never acted on)
+	constexpr unsigned kCand = (1u << (K - 1)) | (1u << (K + CG - 2));
 	if constexpr (W::kEndForms) {
 		unsigned all = 0;
 #pragma unroll
@@ -253,6 +256,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 			all |= hends[gi];
 		}
 		h_any = !a.plain_ends && __builtin_amdgcn_ballot_w64(all != 0) != 0;
+		h_simple = __builtin_amdgcn_ballot_w64((all & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
 	}
 	const bool tall = a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
 	[[maybe_unused]] auto row_is_end = [&](int r) {
@@ -264,12 +268,15 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	// the horizontal inverse lift of one register row: the end forms only where the tile has a line end
 	auto hlift = [&](T (&xr)[NARR], int gi) {
 		if constexpr (W::kEndForms) {
-			if (h_any) {
+			if (__builtin_expect(!h_any, 1)) {
+				lift_inv_regs<W, NARR>(xr, 0u);
+			} else if (h_simple) {
+				DWT_END_PATH();
+				lift_inv_regs<W, NARR, kCand>(xr, hends[gi]);
+			} else {
 				DWT_END_PATH();
 				lift_inv_regs<W, NARR>(xr, hends[gi]);
 			}
-			else
-				lift_inv_regs<W, NARR>(xr, 0u);
 		} else {
 			lift_inv_regs<W, NARR>(xr, 0u);
 		}
@@ -415,7 +422,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 			}
 		};
 		if constexpr (W::kEndForms) {
-			if (v_any) {
+			if (__builtin_expect(v_any, 0)) {
 				DWT_END_PATH();
 				vertical(std::true_type{});
 			}

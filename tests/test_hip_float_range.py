@@ -5,12 +5,12 @@ pins to the reference on the same inputs (tests/test_float_range.py, tests/golde
 Criterion `same_floats`: same bits wherever neither side is a NaN, NaNs at the same positions.
 
 Line ends.  The reference adds (2c)*x where both taps of a sample are the one sample x
-(src/libdwt.c:9545-9552, 9873-9907).  Every 2-D kernel does the same (explicit end forms, dwt_lift.h): all 2-D
-entries are compared with the faithful oracle and with the reference's own outputs (the fixtures) on EVERY class.
-The 3-D level kernels reflect their load addresses and evaluate c*(x+x): `v_add_f32 t, x, x` overflows to Inf for
-|x| > FLT_MAX/2 where (2c)*x with |2c| < 1 stays finite -- the one listed difference (the end forms
-cost those kernels, bound by instruction issue and instruction cache, 25 %).  They are compared with the oracle's
-reflected-ends form on the two classes that reach that range ("huge", "mixed") and with the fixtures on the others."""
+(src/libdwt.c:9545-9552, 9873-9907); reflection -- which the kernels apply to their load addresses -- gives c*(x+x):
+`v_add_f32 t, x, x` overflows to Inf for |x| > FLT_MAX/2 where (2c)*x with |2c| < 1 stays finite.  That is the one
+listed difference of the default build: its float and double entries are compared with the oracle's
+reflected-ends form on the two classes that reach that range ("huge", "mixed") and with the reference's own outputs
+(the fixtures) on the others.  The EXACT build (`make exact`: explicit end forms in every 2-D kernel, dwt_lift.h) is
+compared with the faithful oracle and the fixtures on EVERY class; this file runs against both builds."""
 import warnings
 
 import numpy as np
@@ -23,10 +23,14 @@ pytestmark = pytest.mark.gpu
 warnings.filterwarnings("ignore", category=RuntimeWarning)
 
 OVERFLOWING = {"huge", "mixed"}
-# the entries whose kernels still evaluate a line end as c*(x+x) (reflected load addresses): the 3-D level kernels.  Every
-# 2-D entry -- Mallat and interleaved layout, float and double, fused sweeps, border strips and line passes -- applies
-# the reference's own end form (2c)*x on a path taken by the waves that hold a line end (dwt_lift.h).
-ENDS_REFLECTED = {"cdf97_3d"}
+# Which entries evaluate a line end as c*(x+x) (reflected load addresses) depends on the BUILD (dwt_lift.h,
+# DWT_FLOAT_END_FORMS): the default library does for every float / double entry; `make exact` (libdwt_hip_exact.so,
+# selected with DWT_HIP_LIB -- test_exact_build_over_the_whole_float_range runs this file against it) applies the
+# reference's own (2c)*x in every 2-D kernel and keeps the reflected form in the 3-D level kernels only.
+import os
+
+EXACT_BUILD = os.path.basename(os.environ.get("DWT_HIP_LIB", "")).startswith("libdwt_hip_exact")
+ENDS_REFLECTED = {"cdf97_3d"} if EXACT_BUILD else {"cdf97_s", "cdf53_s", "cdf97_d", "cdf53_d", "cdf97_il", "cdf53_il", "cdf97_3d"}
 WID = {"cdf97_s": "cdf97_s", "cdf53_s": "cdf53_s", "cdf97_d": "cdf97_d", "cdf53_d": "cdf53_d"}
 
 
@@ -204,9 +208,11 @@ def test_large_image_seams_over_the_whole_float_range(dwt, oracle, klass, nf):
     for ff, fi, f, i in (("cdf97_2f_s", "cdf97_2i_s", dwt.dwt_cdf97_2f_s, dwt.dwt_cdf97_2i_s),
                          ("cdf97_2f_inplace_s", "cdf97_2i_inplace_s", dwt.dwt_cdf97_2f_inplace_s, dwt.dwt_cdf97_2i_inplace_s)):
         want = a.copy()
-        oracle.fwd(ff, want, 4)
-        back = want.copy()
-        oracle.inv(fi, back, 4)
+        ctx = warnings.catch_warnings() if EXACT_BUILD else oracle.reflected_ends()
+        with ctx:
+            oracle.fwd(ff, want, 4)
+            back = want.copy()
+            oracle.inv(fi, back, 4)
         d = dwt.DeviceImage(h, w).upload(a)
         f(d.ptr, d.stride_x, 4, w, h, w, h, 4)
         assert same_floats(d.download(np.float32), want), ff
@@ -214,3 +220,20 @@ def test_large_image_seams_over_the_whole_float_range(dwt, oracle, klass, nf):
         i(d.ptr, d.stride_x, 4, w, h, w, h, 4)
         assert same_floats(d.download(np.float32), back), fi
         d.free()
+
+
+def test_exact_build_over_the_whole_float_range():
+    """The same file against libdwt_hip_exact.so (`make exact`: the reference's line-end forms in every 2-D float /
+    double kernel): there the 2-D entries equal the FAITHFUL oracle and the reference's fixtures on every class.  Own
+    process: the library is chosen at import (DWT_HIP_LIB)."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), "libdwt_amd", "libdwt_hip_exact.so")
+    if EXACT_BUILD:
+        pytest.skip("already running against the exact build")
+    assert os.path.exists(lib), "libdwt_amd/libdwt_hip_exact.so is missing: make -C libdwt_amd/csrc exact"
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__)],
+                         env=dict(os.environ, DWT_HIP_LIB=lib), capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
+    assert out.returncode == 0 and " passed" in out.stdout, (out.stdout[-2500:], out.stderr[-1500:])

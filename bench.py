@@ -678,7 +678,9 @@ def extra_legs(torch, dwt, src, dst, n, J, nb, budget_s=6.0):
         out["host_pointer"] = {"forward_ms": round(min(ts["fwd"]), 3), "inverse_ms": round(min(ts["inv"]), 3),
                                "gsamples_per_s_forward": round(n * n / (min(ts["fwd"]) * 1e-3) / 1e9, 2),
                                "how": "dwt_cdf97_2f_s / dwt_cdf97_2i_s on one image in pageable HOST memory, wall clock of the synchronous call, "
-                                      "best of 3: PCIe both ways included -- not comparable with `value`"}
+                                      "best of 3: PCIe both ways included -- not comparable with `value`.  (Inside this process, after the placement search's 100+ GiB "
+                                      "arena, transfers both ways at once run at about half their rate: the same call takes 7.2-7.4 ms in a plain process, "
+                                      "profiles/r06_entries_wallclock_unprofiled.txt)"}
     return out
 
 

@@ -508,9 +508,12 @@ int inverse2d(Wavelet w, Img src, Img dst, const Geom &ge, int j_max, int decomp
 				a.out = ll_band(ll_out);
 				a.out_pitch = ll_pitch_elems(Wo);
 				a.out_bstride = a.out_pitch * Ho;
-				a.temporal_out = g.tune.inv_ll_temporal && (size_t)Wo * Ho * es * batch <= ((size_t)128 << 20);
+				// (not for an in-place call: its staged subbands want the cache, 221 -> 224 us with both)
+				a.temporal_out = g.tune.inv_ll_temporal && src.p != dst.p && (size_t)Wo * Ho * es * batch <= ((size_t)128 << 20);
 			}
 			SweepTuning tune = g.tune;
+			if (tune.inv_pairs <= 0)
+				tune.inv_pairs = src.p == dst.p ? 32 : 16; // (in place: 32 pairs, 230.7 against 234.0 us; scripts/r06/inv_call_ab.py)
 			if (!dbl && tune.tile_pairs <= 0)
 				apply_tile_choice(tuned_tile_pairs(w, a), &tune, true);
 			if (ride.on && !last && ride.next < ride.total && sweep_ride_ok(tune, Wo, Ho, batch, true)) {

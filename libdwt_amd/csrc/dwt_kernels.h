@@ -24,7 +24,7 @@ struct SweepTuning {
 	                     // stores temporal (the next level reads it), bit 3 takes the neighbour taps by wavefront shifts
 	int nt_auto = 1;     // forward: drop bit 2 of `nt` when the launch's LL bands exceed the Infinity Cache
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
-	int inv_pairs = 16;  // inverse: tile height (row pairs) of the large levels under the launcher's rule
+	int inv_pairs = 0;   // inverse: tile height (row pairs) of the large levels under the launcher's rule; 0 = 16 (32 for the levels of an in-place call)
 	int inv_ll_temporal = 1; // inverse: a level that is not the last stores its result temporal when it fits the Infinity Cache
 };
 

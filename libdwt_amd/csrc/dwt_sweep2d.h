@@ -27,7 +27,7 @@ static inline int pick_cpt(const SweepTuning &t, int W, bool inverse)
 	return W >= 2048 ? 8 : 4;
 }
 
-static inline int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batch, bool inverse = false)
+static inline int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, int batch, bool inverse = false, bool interleaved = false)
 {
 	if (t.tile_pairs > 0)
 		return t.tile_pairs;
@@ -49,7 +49,9 @@ static inline int pick_tile_pairs(const SweepTuning &t, int W, int H, int cpt, i
 	// boxes (scripts/r06/inv_geometry.py): 16 against 32 pairs 103 / 107 us for one 8192^2 image, 754 / 767 us for 8,
 	// 5974 / 6096 us for 64, 57 / 60 us at 8192 x 4096, 189 / 197 at 16384 x 8192, 74 / 84 at 7000 x 5000, 408 / 415 for
 	// 16 x 4096^2; 8, 12, 20, 24 pairs and 512-column tiles of any height are slower (rounds 3-5 ranked 32 first on 8 images)
-	int tp = inverse ? (t.inv_pairs >= 2 ? t.inv_pairs : 16) : 64;
+	// (the interleaved layout's inverse keeps 32: its in-place levels snapshot 9 rows per boundary between tile rows, and
+	// twice the boundaries cost the in-place entry 13 us of 271)
+	int tp = inverse ? (interleaved ? 32 : t.inv_pairs >= 2 ? t.inv_pairs : 16) : 64;
 	const long want = inverse ? 2048 : 1024; // inverse tiles are half as wide
 	while (tp > 8 && ntx * ((Hd + tp - 1) / tp) * batch < want)
 		tp >>= 1;

@@ -690,7 +690,7 @@ bool sweep_ride_ok(const SweepTuning &t, int W, int H, int batch, bool inverse)
 
 int il_sweep_tile_pairs(const SweepTuning &t, int W, int H, bool inverse)
 {
-	return pick_tile_pairs(t, W, H, 4, 1, inverse);
+	return pick_tile_pairs(t, W, H, 4, 1, inverse, true);
 }
 
 hipError_t launch_fwd_level(Wavelet w, const FwdLevelArgs &a, const SweepTuning &t, hipStream_t s, const IlStripArgs *strip)

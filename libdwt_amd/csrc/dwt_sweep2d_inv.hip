@@ -581,7 +581,7 @@ static hipError_t inv_level_t(const InvLevelArgs &a, const SweepTuning &t, hipSt
 	const int cpt = a.interleaved ? 4 : pick_cpt(t, a.W, true);
 	const int TW = 64 * cpt;
 	SweepGeom g;
-	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch, true);
+	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch, true, a.interleaved != 0);
 	g.ntx = (a.W + TW - 1) / TW;
 	g.swz = t.xcd_swizzle;
 	const int Hd = (a.H + 1) / 2;

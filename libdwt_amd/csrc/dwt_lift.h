@@ -86,7 +86,11 @@ struct Cdf97SFma : Cdf97S {
 struct Cdf53I {
 	using T = int;
 	static constexpr int K = 2;
+#ifdef DWT_DEBUG_NO_INT_END_FORMS
+	static constexpr bool kEndForms = false;
+#else
 	static constexpr bool kEndForms = true;       // :10971-10976, :11768-11773
+#endif
 	static constexpr bool kScaleSingle = false;   // N<2 untouched (:10961)
 	static constexpr bool kSkipSingleLine = false;
 	static constexpr bool kInvColsFirst = true;   // inverse: columns then rows (:18178-18195)

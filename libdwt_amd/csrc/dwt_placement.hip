@@ -150,12 +150,62 @@ static bool set_access(void *va, size_t bytes, int owner, bool peers)
 	return v.size() > 1 && hipMemSetAccess(va, bytes, v.data(), 1) == hipSuccess;
 }
 
+// A virtual range is never handed out twice.  hipMemAddressReserve without a hint returns the range it returned last time
+// once that has been freed -- and a range that was freed, reserved again and mapped to OTHER physical chunks was accessed
+// through stale translations: kernels wrote the old chunks, copies read the new ones (round 6, scripts/r06/sharded_stress.py:
+// wrong results from the second alloc / free cycle of a placed batch on; never with fresh addresses).  Keeping the ranges
+// reserved instead is no cure: the runtime then holds on to the physical memory as well.  So every reservation gets a
+// hint below everything this process has reserved before (the runtime honours hints; 47 bits of address space hold
+// thousands of arenas), and a reservation that lands on a used range nevertheless is given up for the next hint.
+// DWT_HIP_VMM_REUSE_RANGES=1: no hints (the behaviour of rounds 4-5; for the soak that shows why not).
+static hipError_t reserve_fresh(void **out, size_t bytes)
+{
+	static std::mutex mu;
+	static std::vector<std::pair<uintptr_t, uintptr_t>> used; // [lo, hi) of every range ever reserved here
+	static uintptr_t lowest = 0;
+	static const bool reuse = getenv("DWT_HIP_VMM_REUSE_RANGES") && atoi(getenv("DWT_HIP_VMM_REUSE_RANGES")) > 0;
+	std::lock_guard<std::mutex> lk(mu);
+	const size_t gap = (size_t)1 << 30, al = (size_t)2 << 20;
+	auto overlaps = [&](uintptr_t lo, uintptr_t hi) {
+		for (auto &r : used)
+			if (lo < r.second && r.first < hi)
+				return true;
+		return false;
+	};
+	hipError_t e = hipSuccess;
+	for (int attempt = 0; attempt < 8; attempt++) {
+		void *va = nullptr;
+		void *hint = (lowest && !reuse) ? (void *)((lowest - bytes - gap * (attempt + 1)) / al * al) : nullptr;
+		e = hipMemAddressReserve(&va, bytes, 0, hint, 0);
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			if (!hint)
+				return e;
+			continue; // (a hint the system cannot serve: the next one, further down)
+		}
+		const uintptr_t lo = (uintptr_t)va, hi = lo + bytes;
+		if (!reuse && overlaps(lo, hi) && attempt < 7) {
+			hipMemAddressFree(va, bytes);
+			if (!lowest || lo < lowest)
+				lowest = lo;
+			continue;
+		}
+		used.push_back({lo, hi});
+		if (!lowest || lo < lowest)
+			lowest = lo;
+		*out = va;
+		return hipSuccess;
+	}
+	return e != hipSuccess ? e : hipErrorOutOfMemory;
+}
+
 static int vmm_release(void *va, VmmBuf &b, size_t mapped_pieces)
 {
 	for (size_t i = 0; i < mapped_pieces; i++)
 		hipMemUnmap((char *)va + i * b.piece, b.piece);
 	for (auto h : b.handles)
 		hipMemRelease(h);
+	// (the range goes back to the system; reserve_fresh never asks for these addresses again)
 	if (b.arena) {
 		std::lock_guard<std::mutex> lk(g_vmm_mu);
 		if (--b.arena->live == 0) {
@@ -189,7 +239,7 @@ static void *vmm_alloc(size_t bytes, size_t piece, int slices, size_t ballast)
 	b.piece = piece;
 	b.bytes = n * piece;
 	void *va = nullptr;
-	if (hipMemAddressReserve(&va, b.bytes, 0, nullptr, 0) != hipSuccess) {
+	if (reserve_fresh(&va, b.bytes) != hipSuccess) {
 		fail("hipMemAddressReserve(%zu) failed", b.bytes);
 		return nullptr;
 	}
@@ -270,7 +320,7 @@ static void *spread_alloc(size_t bytes, size_t piece, size_t reserve)
 	const size_t spare = free_b > b.bytes + reserve ? free_b - b.bytes - reserve : 0;
 	const size_t filler = spare / n / gran * gran;
 	void *va = nullptr;
-	if (hipMemAddressReserve(&va, b.bytes, 0, nullptr, 0) != hipSuccess) {
+	if (reserve_fresh(&va, b.bytes) != hipSuccess) {
 		fail("hipMemAddressReserve(%zu) failed", b.bytes);
 		return nullptr;
 	}
@@ -439,7 +489,7 @@ static int arena_place(const ArenaJob &job, void **out)
 		return -1;
 	}
 	char *arena = nullptr;
-	if (hipMemAddressReserve((void **)&arena, n_chunks * C, 0, nullptr, 0) != hipSuccess) {
+	if (reserve_fresh((void **)&arena, n_chunks * C) != hipSuccess) {
 		release_chunks();
 		return fail("hipMemAddressReserve(%zu) failed", n_chunks * C);
 	}

@@ -383,3 +383,41 @@ def test_bench_distributed_branch_with_one_rank_over_rccl():
     split = line["batch_split"]
     assert "error" not in split and split["round_trip_intact"] is True and split["scatter_ms"] > 0 and split["gather_ms"] > 0, split
     assert split["bytes_each_way"] == 4 * 2048 * 2048 * 4
+
+
+def test_placed_batches_allocated_and_freed_repeatedly(dwt, oracle):
+    """dwt_hip_alloc_batch / dwt_hip_free cycles: every arena gets virtual addresses this process has not used before.
+    hipMemAddressReserve returns a freed range again, and a range reserved again and mapped to OTHER physical chunks was
+    accessed through stale translations (kernels wrote the old chunks, copies read the new ones: wrong results from the
+    second cycle on -- round 6, scripts/r06/sharded_stress.py).  Eight cycles, both wavelets, one slot and three."""
+    L = dwt.lib
+    nb, h, w, J = 7, 260, 520, 3
+    try:
+        dwt.set_option("place_min_mib", 0)
+        dwt.set_option("place_tries", 2)
+        dwt.set_option("place_max_gib", 16)
+        bases = set()
+        for rnd in range(8):
+            wname = ("cdf97_s", "cdf53_i")[rnd & 1]
+            ff, fi, dt = NAMES[wname]
+            imgs = rand(np.random.default_rng(900 + rnd), (nb, h, w), dt)
+            want = imgs.copy()
+            for k in range(nb):
+                oracle.fwd(ff, want[k], J)
+            dwt.dwt_util_finish()
+            src, dst = dwt.alloc_batch(wname, nb, w, h, J)
+            assert dwt.alloc_batch_note() == "", dwt.alloc_batch_note()
+            assert src not in bases, "an address range was handed out twice"
+            bases.add(src)
+            assert L.dwt_hip_memcpy_h2d(src, imgs.ctypes.data, imgs.nbytes) == 0
+            got = np.empty_like(imgs)
+            for devices in ([0], [0, 0, 0]):
+                assert dwt.transform2d_batch_sharded(wname, 0, src, dst, h * w * 4, nb, w * 4, w, h, J, devices) == J
+                assert L.dwt_hip_memcpy_d2h(got.ctypes.data, dst, got.nbytes) == 0
+                assert np.array_equal(bits(got), bits(want)), (rnd, wname, devices)
+            L.dwt_hip_free(src)
+            L.dwt_hip_free(dst)
+    finally:
+        dwt.set_option("place_min_mib", 1024)
+        dwt.set_option("place_tries", 4)
+        dwt.set_option("place_max_gib", 0)

@@ -638,9 +638,8 @@ def single_image_stats(torch, dwt, src, dst, n, J):
 
 def extra_legs(torch, dwt, src, dst, n, J, nb, budget_s=6.0):
     """What SURVEY.md s8(d) asks for beside the headline, each a few calls under one small time budget:
-    `batch_inverse` (the resident batch back: dwt_cdf97_2i_s2 semantics, one batched call per step), `inplace_batch`
-    (the in-place entry dwt_cdf97_2f_s image by image over the batch) and `host_pointer` (the drop-in call on an image
-    in HOST memory, end to end incl. PCIe both ways: never `value`)."""
+    `batch_inverse` (the resident batch back: dwt_cdf97_2i_s2 semantics, one batched call per step) and `inplace_batch`
+    (the in-place entry dwt_cdf97_2f_s image by image over the batch)."""
     import numpy as np
 
     t_end = time.perf_counter() + budget_s
@@ -662,26 +661,31 @@ def extra_legs(torch, dwt, src, dst, n, J, nb, budget_s=6.0):
                 dwt.dwt_cdf97_2f_s(dst[k], n * 4, 4, n, n, n, n, J)
         ms = _event_times(torch, inplace_step, 3, 1)
         out["inplace_batch"] = dict(rate(statistics.median(ms), nb), images=nb, how="dwt_cdf97_2f_s per image over the batch, median of 3 steps")
-    if time.perf_counter() < t_end:
-        host = np.random.default_rng(1234).random((n, n), dtype=np.float32)
-        ts = {"fwd": [], "inv": []}
-        for rep in range(4):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            dwt.dwt_cdf97_2f_s(host, n * 4, 4, n, n, n, n, J)
-            t1 = time.perf_counter()
-            dwt.dwt_cdf97_2i_s(host, n * 4, 4, n, n, n, n, J)
-            t2 = time.perf_counter()
-            if rep:  # (the first call pins the image and allocates the staging)
-                ts["fwd"].append((t1 - t0) * 1e3)
-                ts["inv"].append((t2 - t1) * 1e3)
-        out["host_pointer"] = {"forward_ms": round(min(ts["fwd"]), 3), "inverse_ms": round(min(ts["inv"]), 3),
-                               "gsamples_per_s_forward": round(n * n / (min(ts["fwd"]) * 1e-3) / 1e9, 2),
-                               "how": "dwt_cdf97_2f_s / dwt_cdf97_2i_s on one image in pageable HOST memory, wall clock of the synchronous call, "
-                                      "best of 3: PCIe both ways included -- not comparable with `value`.  (Inside this process, after the placement search's 100+ GiB "
-                                      "arena, transfers both ways at once run at about half their rate: the same call takes 7.2-7.4 ms in a plain process, "
-                                      "profiles/r06_entries_wallclock_unprofiled.txt)"}
     return out
+
+
+def host_pointer_leg(torch, dwt, n, J):
+    """The drop-in call on an image in HOST memory (pageable, as a libdwt program has it), end to end incl. PCIe both ways.
+    Measured at the START of the run: after the placement search's 100+ GiB arena has been mapped and returned, transfers
+    in both directions at once run at about half their rate in this process (14.6 ms instead of 7.4: profiles/r06_notes.md s4)."""
+    import numpy as np
+
+    host = np.random.default_rng(1234).random((n, n), dtype=np.float32)
+    ts = {"fwd": [], "inv": []}
+    for rep in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dwt.dwt_cdf97_2f_s(host, n * 4, 4, n, n, n, n, J)
+        t1 = time.perf_counter()
+        dwt.dwt_cdf97_2i_s(host, n * 4, 4, n, n, n, n, J)
+        t2 = time.perf_counter()
+        if rep:  # (the first call pins the image and allocates the staging)
+            ts["fwd"].append((t1 - t0) * 1e3)
+            ts["inv"].append((t2 - t1) * 1e3)
+    return {"forward_ms": round(min(ts["fwd"]), 3), "inverse_ms": round(min(ts["inv"]), 3),
+            "gsamples_per_s_forward": round(n * n / (min(ts["fwd"]) * 1e-3) / 1e9, 2),
+            "how": "dwt_cdf97_2f_s / dwt_cdf97_2i_s on one image in pageable HOST memory, wall clock of the synchronous call, best of 3, "
+                   "before anything else of the run: PCIe both ways included -- not comparable with `value`"}
 
 
 def shard_sweep(torch, dwt, src, dst, n, J, nb):
@@ -1076,6 +1080,12 @@ def run_rank(args):
             dwt.tune("cdf97_s", 0, src[:c], dst[:c], img_bytes, c, n * 4, n, n, J)
         return round(time.perf_counter() - t0, 3)
 
+    host_leg = None
+    if world == 1 and not args.no_single and not args.inplace:
+        try:
+            host_leg = host_pointer_leg(torch, dwt, n, J)
+        except Exception as e:  # noqa: BLE001
+            host_leg = {"error": f"{type(e).__name__}: {e}"}
     dwt.set_option("place_tries", 1)
     src = seeded_images(torch, gen, torch.empty((nb, n, n), device=dev, dtype=torch.float32), lo)
     dst = src.clone() if args.inplace else torch.empty_like(src)
@@ -1228,6 +1238,8 @@ def run_rank(args):
             try:
                 dwt.transform2d_batch("cdf97_s", 0, src, dst, img_bytes, nb, n * 4, n, n, J)  # coefficients of the whole batch in dst again
                 out.update(extra_legs(torch, dwt, src, dst, n, J, nb))
+                if host_leg is not None:
+                    out["host_pointer"] = host_leg
             except Exception as e:  # noqa: BLE001
                 out["extra_legs"] = {"error": f"{type(e).__name__}: {e}"}
             STATE["line"] = dict(out)

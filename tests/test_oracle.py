@@ -300,3 +300,45 @@ def test_oracle_3d_equals_reference_seeded(oracle, reference, seed):
         assert np.all(big[:, shp[1]:, :] == -1.0) and np.all(big[:, :, shp[2]:] == -1.0)
         reference.lib.cdf97_3i_ip_sep_horizontal_s(C.byref(vol(ip)))
         assert np.array_equal(bits(ip), bits(oracle.vol("cdf97_3i_s", want.copy()))), shp
+
+
+VOL_SCHEDULE_SCRIPT = r"""
+import sys, ctypes as C
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from oraclelib import Reference
+r = Reference()
+class Vol(C.Structure):
+    _fields_ = [("size_x", C.c_int), ("size_y", C.c_int), ("size_z", C.c_int), ("stride_x", C.c_size_t), ("stride_y", C.c_size_t), ("stride_z", C.c_size_t), ("data", C.c_void_p)]
+def vol(a): return Vol(a.shape[2], a.shape[1], a.shape[0], a.strides[2], a.strides[1], a.strides[0], a.ctypes.data)
+n, ap = int(sys.argv[2]), int(sys.argv[3])
+v = np.random.default_rng(1).random((n, n, n), dtype=np.float32) * 2 - 1
+out = []
+for a in (0, ap):
+    d = np.zeros_like(v); s = v.copy()
+    r.lib.cdf97_3f_op_wrapper_s(C.byref(vol(s)), C.byref(vol(d)), a)
+    out.append(d)
+print(float(np.abs(out[1] - out[0]).max()), int((out[1].view(np.uint32) != out[0].view(np.uint32)).sum()), float(np.abs(out[0]).max()))
+"""
+
+
+@pytest.mark.parametrize("approach", range(1, 10))
+def test_distance_between_the_references_own_3d_schedules(reference, approach):
+    """`enum volume_approach` (src/volume-dwt.h:210-225): the product returns the bits of VOL_SEP_HORIZONTAL (0) for every
+    schedule (include/volume-dwt.h).  What that means, measured on the reference itself, 32^3 uniform [-1, 1): VOL_SEP_VERTICAL
+    (1) has the same bits; the non-separable schedules 2 .. 9 reorder the lifting arithmetic and differ from schedule 0 in
+    ~80 % of the samples by at most 1e-6 absolute (4e-7 of the largest coefficient) -- inside the 1e-5 relative bar, and
+    the reference's own perf test compares them with abs 1e-3.  Each schedule in a process of its own (some of the
+    reference's cube cores corrupt the heap when several run in one process)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-c", VOL_SCHEDULE_SCRIPT, here, "32", str(approach)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    dist, n_diff, peak = (float(x) for x in out.stdout.split())
+    if approach == 1:
+        assert dist == 0 and n_diff == 0
+    else:
+        assert 0 < dist <= 2e-6 and dist <= 1e-6 * peak and n_diff > 0, (dist, n_diff, peak)

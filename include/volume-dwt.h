@@ -8,7 +8,9 @@
  * of the out-of-place forward transform (its `enum volume_approach` 0..9: separable, slice-wise,
  * 2x2x2 / 4x4x2 / 4x4x4 cores, ...).  They are the same transform; here all of them run the ONE
  * fused x+y+z kernel and return the bits of the separable schedules cdf97_3f_op_sep_horizontal_s /
- * _vertical_s (which the reference's core schedules match to ~1e-6, measured: tests/test_oracle.py::test_distance_between_the_references_own_3d_schedules -- at most 1.07e-6 absolute = 4e-7 of the largest coefficient; VOL_SEP_VERTICAL has the same bits).  A failure (no
+ * _vertical_s (the two have the same bits; the reference's core schedules 2..9 differ from them by at
+ * most 1.07e-6 absolute = 4e-7 of the largest coefficient, measured on the reference itself:
+ * tests/test_oracle.py::test_distance_between_the_references_own_3d_schedules).  A failure (no
  * usable device, bad strides) is logged and abort()s, as dwt_util_error does in the reference.
  */
 #ifndef VOLUME_DWT_H

@@ -200,7 +200,7 @@ struct Opt {
 const Opt kOpts[] = {
 	DWT_OPT("generic", force_generic, kSweep), DWT_OPT("cpt", tune.cpt, kSweep), DWT_OPT("tile_pairs", tune.tile_pairs, kSweep),
 	DWT_OPT("waves", tune.waves, kSweep), DWT_OPT("xcd_swizzle", tune.xcd_swizzle, kSweep), DWT_OPT("ring", tune.ring, kSweep),
-	DWT_OPT("ring_inv", tune.ring_inv, kSweep), DWT_OPT("inv_ll_temporal", tune.inv_ll_temporal, kSweep), DWT_OPT("inv_pairs", tune.inv_pairs, kSweep), DWT_OPT("nt", tune.nt, kSweep), DWT_OPT("nt_auto", tune.nt_auto, kSweep),
+	DWT_OPT("ring_inv", tune.ring_inv, kSweep), DWT_OPT("inv_ll_temporal", tune.inv_ll_temporal, kSweep), DWT_OPT("inv_pairs", tune.inv_pairs, kSweep), DWT_OPT("probe_fuse1", tune.probe_fuse1, kSweep), DWT_OPT("nt", tune.nt, kSweep), DWT_OPT("nt_auto", tune.nt_auto, kSweep),
 	DWT_OPT("fma", fma, kSweep), DWT_OPT("fused_d", fused_d, kPlain), DWT_OPT("ride_copy", ride_copy, kBool), DWT_OPT("ride_mib", ride_mib, kNonNegative), DWT_OPT("il_exact_borders", il_exact_borders, kPlain),
 	DWT_OPT("il_inplace_shell", il_inplace_shell, kPlain), DWT_OPT("host_pipeline", host_pipeline, kPlain),
 	DWT_OPT("tune_tiles", tune_tiles, kPlain), DWT_OPT("tune_in_call", tune_in_call, kBool), DWT_OPT("place_tries", place_tries, kPlain),

@@ -337,6 +337,7 @@ int forward2d(Wavelet w, Img src, Img dst, const Geom &ge, int *jp, int decompos
 				a.ride_hi = ride.next + ride.share((size_t)Wo * Ho * es, carriers_from(j + 1));
 				ride.next = a.ride_hi;
 			}
+			a.probe_fuse1 = (DWT_PROBES && j == 0 && !dbl && w == kCdf97S && !a.temporal) ? g.tune.probe_fuse1 : 0;
 			prof_before(j);
 			hipError_t e = dbl ? launch_fwd_level_d(w, a, tune, g.stream)
 			                   : launch_fwd_level((g.fma && w == kCdf97S) ? kCdf97SFma : w, a, tune, g.stream);

@@ -4,6 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+// 1: timing probes are compiled in (`make probes` -> ../libdwt_hip_probes.so; scripts/r06/probe_fuse1.py).  A probe gives
+// WRONG RESULTS by design; the shipped libraries are built without them and ignore the options that select them.
+#ifndef DWT_PROBES
+#define DWT_PROBES 0
+#endif
+
 namespace dwt {
 
 enum Wavelet { kCdf97S = 0, kCdf53I = 1, kCdf53S = 2, kCdf97D = 3, kCdf53D = 4, kCdf97I = 5,
@@ -24,6 +30,7 @@ struct SweepTuning {
 	                     // stores temporal (the next level reads it), bit 3 takes the neighbour taps by wavefront shifts
 	int nt_auto = 1;     // forward: drop bit 2 of `nt` when the launch's LL bands exceed the Infinity Cache
 	int ring_inv = 8;    // inverse sweep ring rows (8 or 16)
+	int probe_fuse1 = 0; // see FwdLevelArgs (timing probe, wrong results)
 	int inv_pairs = 0;   // inverse: tile height (row pairs) of the large levels under the launcher's rule; 0 = 16 (32 for the levels of an in-place call)
 	int inv_ll_temporal = 1; // inverse: a level that is not the last stores its result temporal when it fits the Infinity Cache
 };
@@ -81,6 +88,8 @@ struct FwdLevelArgs {
 	// while the small, latency-bound levels run: launch_copy_rects_plan)
 	const CopyRects *ride = nullptr;
 	int ride_lo = 0, ride_hi = 0;
+	int probe_fuse1 = 0; // PROBE ONLY (option "probe_fuse1"): level 0 also runs level 1's arithmetic on its LL rows and stores level 1's
+	                     // four quarter rows instead of the LL band -- WRONG RESULTS (no halo between tiles), the cost of a fused level 0 + 1
 	int out_step = 1;    // interleaved only: elements between neighbouring samples of an output row -- 2^j when the level
 	                     // is written straight to the lattice it lives on in a larger image (h_pitch: that lattice's row
 	                     // pitch); with il_ll the samples at (even row, even column) are then left to the deeper levels

@@ -146,6 +146,8 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	// bit 3: take the 4-sample neighbour taps from the adjacent lanes' registers with
 	// wavefront shifts (DPP) instead of re-reading them from LDS
 	constexpr bool kShuffle = (NT & 8) != 0;
+	// bit 4: TIMING PROBE of a fused level 0 + 1 (FwdLevelArgs::probe_fuse1): wrong results
+	[[maybe_unused]] constexpr bool kProbe = DWT_PROBES && (NT & 16) != 0;
 	constexpr int TW = 64 * CPT;
 	constexpr int RS = TW + 8; // LDS row slot: [main TW | left halo 4 | right halo 4]
 	constexpr int NARR = CPT + 2 * K;
@@ -173,9 +175,13 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	if (a.pair_hi > 0 && (A < a.pair_lo || A >= a.pair_hi))
 		return; // this launch computes a band of the level only
 	const int B = min(A + g.tile_pairs, Hd);
-	const int c0 = tx * TW;
-	const int n_iter = (B - A) + K;
-	const int q0 = A - K / 2;
+	// (probe level 2: what a REAL fused level 0 + 1 adds to the geometry -- level 1's warm-up of 4 LL row pairs = 8 more
+	// level-0 pairs above every tile, and tiles 496 columns apart whose outer lanes recompute the neighbours' 8 columns)
+	// (2: both, 3: the warm-up alone, 4: the tile pitch alone)
+	[[maybe_unused]] const int pw = (kProbe && (a.probe_fuse1 == 2 || a.probe_fuse1 == 3)) ? 8 : 0;
+	const int c0 = (kProbe && (a.probe_fuse1 == 2 || a.probe_fuse1 == 4)) ? tx * (TW - 16) - 8 : tx * TW;
+	const int n_iter = (B - A) + K + pw;
+	const int q0 = A - K / 2 - pw;
 
 	const T *in = (const T *)a.in + (long)img * a.in_bstride;
 	T *out_ll = (T *)a.out_ll + (long)img * a.ll_bstride;
@@ -269,6 +275,8 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 #pragma unroll
 		for (int v = 0; v < CPT; v++)
 			st[s][v] = 0;
+	// (probe) level 1's vertical state on this lane's four LL columns, and the odd LL row waiting for its partner
+	[[maybe_unused]] T st1[K][4] = {}, p1[4] = {};
 
 	// explicit line-end forms: which of the lane's columns c - K .. c + CPT + K - 1 are a row's ends -- only the tiles
 	// that hold column 0 or W - 1 have any (`h_any`, wave-uniform: the interior tiles run the plain lift) --; the rows that
@@ -482,16 +490,59 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 				}
 			}
 		} else
-		if (it >= K) {
+		if (it >= K + pw) {
 			// Mallat rows: [LL (Wd) | HL (W/2)] at row k, [LH | HH] at row Hd + k; each quarter row is a
 			// buffer of its own, so the lanes (and dwords) beyond its end are dropped
-			const int k = A + it - K;
+			const int k = A + it - K - pw;
 			const unsigned clb = (unsigned)((c0 + lane * CPT) >> 1) * 4;
 			const T *top = out_h + (long)k * a.h_pitch, *bot = out_h + (long)(Hd + k) * a.h_pitch;
 			const unsigned nlb = (unsigned)Wd * 4, nhb = (unsigned)(a.W >> 1) * 4;
 			const row_rsrc_t dll = row_rsrc(out_ll + (long)k * a.ll_pitch, nlb), dhl = row_rsrc(top + Wd, nhb);
 			const bool hrow = k < (a.H >> 1);
 			if constexpr (CPT == 8) {
+				if constexpr (kProbe && K == 4 && std::is_floating_point<T>::value) {
+					// level 1 on the LL row this iteration produced: neighbours' samples by wavefront shifts, horizontal lift,
+					// then -- every second row -- the vertical step and the four quarter-row stores of level 1
+					T x1[12];
+#pragma unroll
+					for (int e = 0; e < 4; e++) {
+						x1[e] = from_bits<T>(from_left_lane(to_bits(lo[2 * e])));
+						x1[4 + e] = lo[2 * e];
+						x1[8 + e] = from_bits<T>(from_right_lane(to_bits(lo[2 * e])));
+					}
+					lift_fwd_regs<W, 12>(x1, 0u);
+					T r1[4];
+#pragma unroll
+					for (int v = 0; v < 4; v++)
+						r1[v] = W::fwd_scale(v & 1, x1[4 + v]);
+					if (!((it - K - pw) & 1)) {
+#pragma unroll
+						for (int v = 0; v < 4; v++)
+							p1[v] = r1[v];
+					} else {
+						T lo1[4], hi1[4];
+#pragma unroll
+						for (int v = 0; v < 4; v++) {
+							const T d1n = W::fwd_step(0, p1[v], st1[0][v], r1[v]);
+							const T s1n = W::fwd_step(1, st1[0][v], st1[1][v], d1n);
+							const T d2n = W::fwd_step(2, st1[1][v], st1[2][v], s1n);
+							const T s2n = W::fwd_step(3, st1[2][v], st1[3][v], d2n);
+							lo1[v] = W::fwd_scale(0, s2n);
+							hi1[v] = W::fwd_scale(1, d2n);
+							st1[0][v] = r1[v];
+							st1[1][v] = d1n;
+							st1[2][v] = s1n;
+							st1[3][v] = d2n;
+						}
+						const int k1 = k >> 1, Wq = (Wd + 1) >> 1, Hq = (Hd + 1) >> 1;
+						const unsigned qb = (unsigned)((c0 + lane * CPT) >> 2) * 4, nqb = (unsigned)Wq * 4;
+						const T *t1 = out_h + (long)k1 * a.h_pitch, *b1 = out_h + (long)(Hq + k1) * a.h_pitch;
+						store8_row<kNtStoreLL>(row_rsrc(out_ll + (long)k1 * a.ll_pitch, nqb), qb, u2{to_bits(lo1[0]), to_bits(lo1[2])});
+						store8_row<kNtStore>(row_rsrc(t1 + Wq, nqb), qb, u2{to_bits(lo1[1]), to_bits(lo1[3])});
+						store8_row<kNtStore>(row_rsrc(b1, nqb), qb, u2{to_bits(hi1[0]), to_bits(hi1[2])});
+						store8_row<kNtStore>(row_rsrc(b1 + Wq, nqb), qb, u2{to_bits(hi1[1]), to_bits(hi1[3])});
+					}
+				} else
 				store16_row<kNtStoreLL>(dll, clb, u4{to_bits(lo[0]), to_bits(lo[2]), to_bits(lo[4]), to_bits(lo[6])});
 				store16_row<kNtStore>(dhl, clb, u4{to_bits(lo[1]), to_bits(lo[3]), to_bits(lo[5]), to_bits(lo[7])});
 				if (hrow) {
@@ -573,6 +624,15 @@ static hipError_t fwd_pick(const FwdLevelArgs &a, const SweepGeom &g, dim3 grid,
 	// by wavefront shifts instead of LDS reads: bit-identical, 0.8 % slower, the cross-check variant).  The
 	// other policies and ring depths of rounds 1-3 measured slower and are gone (profiles/archive/r02_experiments.md).
 	const int nt = a.temporal ? 6 : (t.nt & 8) ? 15 : (t.nt & 4) ? 7 : 3;
+#if DWT_PROBES
+	if constexpr (CPT == 8 && std::is_same<W, Cdf97S>::value) {
+		if (a.probe_fuse1 && (nt == 3 || nt == 7)) { // the timing probe of a fused level 0 + 1 (wrong results)
+			if (t.ring == 16)
+				return nt == 3 ? fwd_launch<W, CPT, 16, 19>(a, g, grid, waves, s) : fwd_launch<W, CPT, 16, 23>(a, g, grid, waves, s);
+			return nt == 3 ? fwd_launch<W, CPT, 8, 19>(a, g, grid, waves, s) : fwd_launch<W, CPT, 8, 23>(a, g, grid, waves, s);
+		}
+	}
+#endif
 	if (t.ring == 16) {
 		switch (nt) {
 		case 6: return fwd_launch<W, CPT, 16, 6>(a, g, grid, waves, s);
@@ -611,6 +671,8 @@ static hipError_t fwd_level_t(const FwdLevelArgs &a, const SweepTuning &t, hipSt
 	SweepGeom g;
 	g.tile_pairs = pick_tile_pairs(t, a.W, a.H, cpt, a.batch);
 	g.ntx = (a.W + TW - 1) / TW;
+	if ((a.probe_fuse1 == 2 || a.probe_fuse1 == 4) && !a.interleaved && cpt == 8)
+		g.ntx = (a.W + 16 + (TW - 16) - 1) / (TW - 16); // (probe: tiles 496 columns apart)
 	g.swz = t.xcd_swizzle;
 	g.wave_horiz = 0;
 	const int Hd = (a.H + 1) / 2;

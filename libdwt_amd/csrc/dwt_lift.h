@@ -19,24 +19,26 @@
 // (:10971-10976, :11768-11773), which differ from the reflected `(d+d+2)>>2` / `(s+s)>>1` once
 // the doubled term wraps (|x| >= 2^30); only the fixed-point 9/7 writes `a[N-2]+a[N-2]` itself.
 // So the policies carry explicit END FORMS (kEndForms, fwd_end / inv_end) and the kernels
-// apply them to the samples whose two taps are one and the same sample.  The tile sweeps do it
-// on a path of its own, taken by the waves whose tile holds a line end (wave-uniform tests: a
-// tile's columns, an iteration's rows), so that the interior pays nothing.  Int arithmetic wraps modulo 2^32 like the compiled reference
+// apply them to the samples whose two taps are one and the same sample.  The float tile sweeps do it by SELECTION
+// (SelEnds below: the end step is the plain step with the coefficient doubled and the virtual tap replaced by -0.0 --
+// straight-line code, no second formula); the int 5/3 and the shapes SelEnds leaves out on a path of its own, taken by
+// the waves whose tile holds a line end (wave-uniform tests).  Int arithmetic wraps modulo 2^32 like the compiled reference
 // (done in unsigned here: signed overflow is undefined for the compiler).  A forward transform runs K lifting
 // steps, step s acting on samples of parity (s+1)&1, then scales; an inverse
 // transform descales, then runs K steps, step s acting on parity s&1.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
-// The float / double policies' line-end forms are a BUILD option.  0 (libdwt_hip.so, the default): their line ends are what
-// reflection gives, c*(x+x) -- the same bits as the reference's (2c)*x unless x+x overflows, the one listed difference of
-// DESIGN.md s2.  1 (`make exact` -> libdwt_hip_exact.so): every 2-D kernel applies the reference's own form, bit for bit over
-// the whole float range (tests/test_hip_float_range.py runs against that build too).  Why not always: the paths cost
-// nothing where they are not taken, but their code in the sweep kernels does -- one 8192^2 image 155 -> 168 us, a batch of
-// eight + 3.5 % (scripts/r06/ab_calls.py, alternated on one box; cold instruction fetches of the five launches of a call
-// and the border tiles' waves holding their workgroups back).  The int 5/3 needs its end forms in every build.
+// The float / double policies' line-end forms are a BUILD option, for A/B timing.  1 (libdwt_hip.so, the default): every 2-D
+// kernel applies the reference's own form, bit for bit over the whole float range (tests/test_hip_float_range.py).  0
+// (`make plain` -> libdwt_hip_plain.so): the line ends are what reflection gives, c*(x+x) -- the same bits unless x+x
+// overflows; what shipped until the select form made the exact ends free (round 6, alternated on one box: forward call of
+// one 8192^2 image 155 = 155 us, the bench's batch of 32 unchanged within its noise, inverse calls + 1-3 %; the
+// branching forms had cost 8-11 % and 3.5 %: profiles/r06_notes.md).  The 3-D level kernels keep the reflected form in
+// either build.  The int 5/3 needs its end forms in every build.
 #ifndef DWT_FLOAT_END_FORMS
-#define DWT_FLOAT_END_FORMS 0
+#define DWT_FLOAT_END_FORMS 1
 #endif
 
 namespace dwt {
@@ -71,6 +73,10 @@ struct Cdf97S {
 	// line ends: both taps are the sample m; `2*alpha*(x)` as the reference writes it (:9545, :9552, :9873, :9879)
 	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return c + (2.0f * fc(s)) * m; }
 	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return c + (2.0f * ic(s)) * m; }
+	// the steps as c + k (l + r) with k a value (SelEnds below): fk / ik = the signed coefficient of step s
+	static __device__ __forceinline__ T fk(int s) { return fc(s); }
+	static __device__ __forceinline__ T ik(int s) { return ic(s); }
+	static __device__ __forceinline__ T step_k(T k, T c, T l, T r) { return c + k * (l + r); }
 };
 
 // Same wavelet with each lifting step contracted to one fused multiply-add.  NOT the
@@ -81,6 +87,7 @@ struct Cdf97SFma : Cdf97S {
 	static __device__ __forceinline__ T inv_step(int s, T c, T l, T r) { return __builtin_fmaf(ic(s), l + r, c); }
 	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return __builtin_fmaf(2.0f * fc(s), m, c); }
 	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return __builtin_fmaf(2.0f * ic(s), m, c); }
+	static __device__ __forceinline__ T step_k(T k, T c, T l, T r) { return __builtin_fmaf(k, l + r, c); }
 };
 
 struct Cdf53I {
@@ -198,6 +205,10 @@ struct Cdf53S {
 	// line ends (:11012-11017, :11811-11816): `-= 2*p1*x`, `+= 2*u1*x`
 	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.5f) * m : c + (2 * 0.25f) * m; }
 	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.25f) * m : c + (2 * 0.5f) * m; }
+	// (c - p t and c + (-p) t are the same float for every c, t)
+	static __device__ __forceinline__ T fk(int s) { return s == 0 ? -0.5f : 0.25f; }
+	static __device__ __forceinline__ T ik(int s) { return s == 0 ? -0.25f : 0.5f; }
+	static __device__ __forceinline__ T step_k(T k, T c, T l, T r) { return c + k * (l + r); }
 };
 
 // dwt-simple.c's 5/3 (fdwt2_cdf53_*, :1031-1078, :1531-1570): same steps, but the odd
@@ -277,6 +288,62 @@ static __device__ __forceinline__ int reflect1(int i, int N)
 	return i >= N ? 2 * (N - 1) - i : i;
 }
 
+// W with its line ends as reflection gives them (FwdLevelArgs::plain_ends: the xy sweeps of the 3-D transforms)
+template <class W>
+struct PlainEnds : W {
+	static constexpr bool kEndForms = false;
+};
+
+// W with its line-end forms by SELECTION instead of by branches (float policies with fk / ik / step_k): at a line end the
+// reference adds (2c) x where both taps of the plain step are that x.  c + k (l + r) gives those very bits with k = 2c and
+// the virtual tap replaced by -0.0 (x + -0.0 == x for every x, +-0, Inf and NaN included) -- a select on the coefficient
+// and one on a tap instead of a second formula behind a branch.  The tile sweeps run this instantiation on every tile
+// of a level whose width is a multiple of the columns per lane: straight-line code, the same for all waves (the
+// branching forms cost the sweeps 4-10 %, most of it code layout and scheduling, not arithmetic: profiles/r06_notes.md).
+template <class W>
+struct SelEnds : W {
+	static constexpr bool kEndForms = false;
+};
+template <class W> constexpr bool kIsSelEnds = false;
+template <class W> constexpr bool kIsSelEnds<SelEnds<W>> = true;
+template <class W, class = void> struct has_coef_ends : std::false_type {};
+template <class W> struct has_coef_ends<W, std::void_t<decltype(W::fk(0))>> : std::true_type {};
+
+// The K lifting steps over a[0..n) as lift_fwd_regs / lift_inv_regs run them, with two entries that can be line ends:
+// J0 (column 0: its LEFT tap is virtual) when e0, J1 (the last column: its RIGHT tap is virtual) when e1.  kk[s]: the
+// lane's coefficient of step s for those entries (doubled where the entry the step reaches is an end).
+template <class W, int n, bool INV, int J0, int J1>
+static __device__ __forceinline__ void lift_regs_sel(typename W::T (&a)[n], bool e0, bool e1, const typename W::T (&kk)[W::K])
+{
+	using T = typename W::T;
+	static_assert(((J0 ^ J1) & 1) == 1, "the two candidates are reached by different steps");
+#pragma unroll
+	for (int s = 0; s < W::K; s++) {
+#pragma unroll
+		for (int j = s + 1; j <= n - 2 - s; j += 2) {
+			if (j == J0)
+				a[j] = W::step_k(kk[s], a[j], e0 ? T(-0.0) : a[j - 1], a[j + 1]);
+			else if (j == J1)
+				a[j] = W::step_k(kk[s], a[j], a[j - 1], e1 ? T(-0.0) : a[j + 1]);
+			else
+				a[j] = INV ? W::inv_step(s, a[j], a[j - 1], a[j + 1]) : W::fwd_step(s, a[j], a[j - 1], a[j + 1]);
+		}
+	}
+}
+
+// the lane's coefficients for lift_regs_sel
+template <class W, bool INV, int J0>
+static __device__ __forceinline__ void sel_coefs(typename W::T (&kk)[W::K], bool e0, bool e1)
+{
+	using T = typename W::T;
+#pragma unroll
+	for (int s = 0; s < W::K; s++) {
+		const T k = INV ? W::ik(s) : W::fk(s);
+		const bool e = ((J0 - (s + 1)) & 1) == 0 ? e0 : e1; // the candidate step s reaches
+		kk[s] = e ? T(2) * k : k;
+	}
+}
+
 // Step s on a sample whose taps are l and r; `end`: the sample sits on a line end (index 0 or
 // N-1 after reflection), where l and r are one and the same sample.  Only policies with explicit
 // end forms look at `end`.
@@ -316,6 +383,15 @@ static __device__ __forceinline__ unsigned end_mask(int g0, int N)
 		m |= (unsigned)(i == 0 || i == N - 1) << j;
 	}
 	return m;
+}
+
+// end_mask for a window of a tile sweep over a line of 64 samples or more that starts at g0 > -N: the one-bounce form
+// alone (windows that reach beyond 2N - 1 belong to lanes right of the line, whose results are dropped)
+template <int n>
+static __device__ __forceinline__ unsigned end_mask_long(int g0, int N)
+{
+	const int j0 = -g0, j1 = N - 1 - g0;
+	return ((unsigned)j0 < (unsigned)n ? 1u << j0 : 0u) | ((unsigned)j1 < (unsigned)n ? 1u << j1 : 0u);
 }
 
 // Run the K lifting steps of a forward transform over a register array a[0..n)

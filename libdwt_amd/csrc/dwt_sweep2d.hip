@@ -291,9 +291,18 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 		h_any = !a.plain_ends && __builtin_amdgcn_ballot_w64(hends != 0) != 0;
 		h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
 	}
+	// (SelEnds) the same two entries by selection: the lane's flags and its coefficients for the steps that reach them
+	[[maybe_unused]] bool e0 = false, e1 = false;
+	[[maybe_unused]] T kh[K];
+	if constexpr (kIsSelEnds<W>) {
+		const unsigned m = end_mask_long<NARR>(c0 + lane * CPT - K, a.W);
+		e0 = (m >> K) & 1;
+		e1 = (m >> (K + CPT - 1)) & 1;
+		sel_coefs<W, false, K>(kh, e0, e1);
+	}
 	// row r (any r the sweep meets) is an end of its column: r == 0 or r == H - 1 after reflection (one bounce when tall)
 	[[maybe_unused]] auto row_is_end = [&](int r) {
-		if (tall)
+		if (tall || kIsSelEnds<W>) // (SelEnds runs on levels of 64 rows or more)
 			return r == 0 || r == a.H - 1;
 		const int rr = reflect(r, a.H);
 		return rr == 0 || rr == a.H - 1;
@@ -370,6 +379,8 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 					DWT_END_PATH();
 					lift_fwd_regs<W, NARR>(x, hends);
 				}
+			} else if constexpr (kIsSelEnds<W>) {
+				lift_regs_sel<W, NARR, false, K, K + CPT - 1>(x, e0, e1, kh);
 			} else {
 				lift_fwd_regs<W, NARR>(x, 0u);
 			}
@@ -425,6 +436,54 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 				vertical(std::true_type{});
 			}
 			else
+				vertical(std::false_type{});
+		} else if constexpr (kIsSelEnds<W>) {
+			// step s acts on row 2q-1-s; where that row is an end of its column (wave-uniform, the top and bottom tiles'
+			// first / last iterations) the step's coefficient is doubled and its state tap -- the same values as the other
+			// tap there -- gives way to -0.0.  Deep ring: the iterations that meet no end take the plain body.
+			bool ve[K], any = false;
+#pragma unroll
+			for (int s_ = 0; s_ < K; s_++) {
+				ve[s_] = row_is_end(2 * (q0 + it) - 1 - s_);
+				any = any || ve[s_];
+			}
+			auto vertical_sel = [&]() {
+				T kv[K];
+#pragma unroll
+				for (int s_ = 0; s_ < K; s_++)
+					kv[s_] = ve[s_] ? T(2) * W::fk(s_) : W::fk(s_);
+#pragma unroll
+				for (int v = 0; v < CPT; v++) {
+					const T ov = row[0][v], ev = row[1][v];
+					if constexpr (K == 4) {
+						const T d1n = W::step_k(kv[0], ov, ve[0] ? T(-0.0) : st[0][v], ev);
+						const T s1n = W::step_k(kv[1], st[0][v], ve[1] ? T(-0.0) : st[1][v], d1n);
+						const T d2n = W::step_k(kv[2], st[1][v], ve[2] ? T(-0.0) : st[2][v], s1n);
+						const T s2n = W::step_k(kv[3], st[2][v], ve[3] ? T(-0.0) : st[3][v], d2n);
+						lo[v] = W::fwd_scale(0, s2n);
+						hi[v] = W::fwd_scale(1, d2n);
+						st[0][v] = ev;
+						st[1][v] = d1n;
+						st[2][v] = s1n;
+						st[3][v] = d2n;
+					} else {
+						const T d1n = W::step_k(kv[0], ov, ve[0] ? T(-0.0) : st[0][v], ev);
+						const T s1n = W::step_k(kv[1], st[0][v], ve[1] ? T(-0.0) : st[1][v], d1n);
+						lo[v] = W::fwd_scale(0, s1n);
+						hi[v] = W::fwd_scale(1, d1n);
+						st[0][v] = ev;
+						st[1][v] = d1n;
+					}
+				}
+			};
+			// (shallow ring: the launches of a few rounds of waves, bound by the longest wave -- the top tiles', for whom a
+			// second body means instructions fetched cold from HBM, 1 us a launch; there every iteration selects)
+			if constexpr (RING == 8)
+				vertical_sel();
+			else if (__builtin_expect(any, 0)) {
+				DWT_END_PATH();
+				vertical_sel();
+			} else
 				vertical(std::false_type{});
 		} else {
 			vertical(std::false_type{});
@@ -561,10 +620,25 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	}
 }
 
+// the tile by the instantiation of the policy's line ends the level needs (dwt_lift.h)
+template <class W, int CPT, int RING, int NT, bool IL, bool X>
+static __device__ __forceinline__ void fwd_sweep_any_tile(const FwdLevelArgs &a, const SweepGeom &g)
+{
+	if constexpr (W::kEndForms && has_coef_ends<W>::value && !(DWT_PROBES && (NT & 16))) {
+		if (a.plain_ends)
+			fwd_sweep_tile<PlainEnds<W>, CPT, RING, NT, IL, X>(a, g);
+		else if (a.W % CPT == 0 && a.W >= 64 && a.H >= 64)
+			fwd_sweep_tile<SelEnds<W>, CPT, RING, NT, IL, X>(a, g);
+		else // (a width that puts the last column anywhere in a lane's window; short lines, reflected more than once)
+			fwd_sweep_tile<W, CPT, RING, NT, IL, X>(a, g);
+	} else
+		fwd_sweep_tile<W, CPT, RING, NT, IL, X>(a, g);
+}
+
 template <class W, int CPT, int RING, int NT, bool IL = false>
 __global__ __launch_bounds__(256) void k_fwd_sweep(FwdLevelArgs a, SweepGeom g)
 {
-	fwd_sweep_tile<W, CPT, RING, NT, IL, false>(a, g);
+	fwd_sweep_any_tile<W, CPT, RING, NT, IL, false>(a, g);
 }
 
 // a level with a rectangle copy riding along: the workgroups behind the tiles' copy blocks of `r` (FwdLevelArgs::ride)
@@ -575,7 +649,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_r(FwdLevelArgs a, SweepGeom g
 		ride_copy_block(r, (int)blockIdx.x - g.tile_blocks);
 		return;
 	}
-	fwd_sweep_tile<W, CPT, RING, NT, false, false>(a, g);
+	fwd_sweep_any_tile<W, CPT, RING, NT, false, false>(a, g);
 }
 
 // one level of a phase-ordered interleaved transform, exact: workgroups [0, g.first) compute the border strips
@@ -586,7 +660,7 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_x(FwdLevelArgs a, SweepGeom g
 		il_strip_wave<W, false>(strip, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 		return;
 	}
-	fwd_sweep_tile<W, CPT, RING, NT, true, true>(a, g);
+	fwd_sweep_any_tile<W, CPT, RING, NT, true, true>(a, g);
 }
 
 // ---- launch wrappers -------------------------------------------------------------

@@ -258,9 +258,22 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 		h_any = !a.plain_ends && __builtin_amdgcn_ballot_w64(all != 0) != 0;
 		h_simple = __builtin_amdgcn_ballot_w64((all & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
 	}
+	// (SelEnds) the same two entries by selection: per group the lane's flags and its coefficients for the steps that reach them
+	[[maybe_unused]] bool e0[G] = {}, e1[G] = {};
+	[[maybe_unused]] T kh[G][K];
+	if constexpr (kIsSelEnds<W>) {
+		static_assert(!W::kInvColsFirst, "float policies undo the rows first");
+#pragma unroll
+		for (int gi = 0; gi < G; gi++) {
+			const unsigned m = end_mask_long<NARR>(c0 + 64 * CG * gi + lane * CG - K + 1, a.W);
+			e0[gi] = (m >> (K - 1)) & 1;
+			e1[gi] = (m >> (K + CG - 2)) & 1;
+			sel_coefs<W, true, K - 1>(kh[gi], e0[gi], e1[gi]);
+		}
+	}
 	const bool tall = a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
 	[[maybe_unused]] auto row_is_end = [&](int r) {
-		if (tall)
+		if (tall || kIsSelEnds<W>) // (SelEnds runs on levels of 64 rows or more)
 			return r == 0 || r == a.H - 1;
 		const int rr = reflect(r, a.H);
 		return rr == 0 || rr == a.H - 1;
@@ -277,6 +290,8 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				DWT_END_PATH();
 				lift_inv_regs<W, NARR>(xr, hends[gi]);
 			}
+		} else if constexpr (kIsSelEnds<W>) {
+			lift_regs_sel<W, NARR, true, K - 1, K + CG - 2>(xr, e0[gi], e1[gi], kh[gi]);
 		} else {
 			lift_inv_regs<W, NARR>(xr, 0u);
 		}
@@ -428,6 +443,56 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 			}
 			else
 				vertical(std::false_type{});
+		} else if constexpr (kIsSelEnds<W>) {
+			// step s acts on row 2p-s; where that row is an end of its column (wave-uniform, the top and bottom tiles' first /
+			// last iterations) the step's coefficient is doubled and its state tap -- the same values as the other tap
+			// there -- gives way to -0.0.  Deep ring: the iterations that meet no end take the plain body.
+			bool ve[K], any = false;
+#pragma unroll
+			for (int s_ = 0; s_ < K; s_++) {
+				ve[s_] = row_is_end(2 * p - s_);
+				any = any || ve[s_];
+			}
+			auto vertical_sel = [&]() {
+				T kv[K];
+#pragma unroll
+				for (int s_ = 0; s_ < K; s_++)
+					kv[s_] = ve[s_] ? T(2) * W::ik(s_) : W::ik(s_);
+#pragma unroll
+				for (int gi = 0; gi < G; gi++)
+#pragma unroll
+				for (int v = 0; v < NVG; v++) {
+					const T s2 = val[0][gi][v], d2 = val[1][gi][v];
+					if constexpr (K == 4) {
+						const T s1n = W::step_k(kv[0], s2, ve[0] ? T(-0.0) : st[0][gi][v], d2);
+						const T d1n = W::step_k(kv[1], st[0][gi][v], ve[1] ? T(-0.0) : st[1][gi][v], s1n);
+						const T en = W::step_k(kv[2], st[1][gi][v], ve[2] ? T(-0.0) : st[2][gi][v], d1n);
+						const T on = W::step_k(kv[3], st[2][gi][v], ve[3] ? T(-0.0) : st[3][gi][v], en);
+						odd_row[gi][v] = on;
+						even_row[gi][v] = en;
+						st[0][gi][v] = d2;
+						st[1][gi][v] = s1n;
+						st[2][gi][v] = d1n;
+						st[3][gi][v] = en;
+					} else {
+						const T en = W::step_k(kv[0], s2, ve[0] ? T(-0.0) : st[0][gi][v], d2);
+						const T on = W::step_k(kv[1], st[0][gi][v], ve[1] ? T(-0.0) : st[1][gi][v], en);
+						odd_row[gi][v] = on;
+						even_row[gi][v] = en;
+						st[0][gi][v] = d2;
+						st[1][gi][v] = en;
+					}
+				}
+			};
+			// (shallow ring: the launches of a few rounds of waves, bound by the longest wave -- the top tiles', for whom a
+			// second body means instructions fetched cold from HBM, 1 us a launch; there every iteration selects)
+			if constexpr (RING == 0)
+				vertical_sel();
+			else if (__builtin_expect(any, 0)) {
+				DWT_END_PATH();
+				vertical_sel();
+			} else
+				vertical(std::false_type{});
 		} else {
 			vertical(std::false_type{});
 		}
@@ -476,10 +541,26 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	}
 }
 
+// the tile by the instantiation of the policy's line ends the level needs (dwt_lift.h)
+template <class W, int CPT, int RING, int NT, bool IL, bool X, bool SP = false>
+static __device__ __forceinline__ void inv_sweep_any_tile(const InvLevelArgs &a, const SweepGeom &g)
+{
+	if constexpr (W::kEndForms && has_coef_ends<W>::value) {
+		constexpr int CG = (!IL && CPT == 8) ? 4 : CPT; // columns per group, as in the tile
+		if (a.plain_ends)
+			inv_sweep_tile<PlainEnds<W>, CPT, RING, NT, IL, X, SP>(a, g);
+		else if (a.W % CG == 0 && a.W >= 64 && a.H >= 64)
+			inv_sweep_tile<SelEnds<W>, CPT, RING, NT, IL, X, SP>(a, g);
+		else // (a width that puts the last column anywhere in a group's window; short lines, reflected more than once)
+			inv_sweep_tile<W, CPT, RING, NT, IL, X, SP>(a, g);
+	} else
+		inv_sweep_tile<W, CPT, RING, NT, IL, X, SP>(a, g);
+}
+
 template <class W, int CPT, int RING, int NT, bool IL = false>
 __global__ __launch_bounds__(256) void k_inv_sweep(InvLevelArgs a, SweepGeom g)
 {
-	inv_sweep_tile<W, CPT, RING, NT, IL, false>(a, g);
+	inv_sweep_any_tile<W, CPT, RING, NT, IL, false>(a, g);
 }
 
 // interleaved input, 4 columns per lane; SP: split even rows (InvLevelArgs::in_ll2)
@@ -491,13 +572,13 @@ __global__ __launch_bounds__(256) void k_inv_sweep_r(InvLevelArgs a, SweepGeom g
 		ride_copy_block(r, (int)blockIdx.x - g.tile_blocks);
 		return;
 	}
-	inv_sweep_tile<W, CPT, RING, NT, false, false>(a, g);
+	inv_sweep_any_tile<W, CPT, RING, NT, false, false>(a, g);
 }
 
 template <class W, int RING, int NT, bool SP>
 __global__ __launch_bounds__(256) void k_inv_sweep_il(InvLevelArgs a, SweepGeom g)
 {
-	inv_sweep_tile<W, 4, RING, NT, true, false, SP>(a, g);
+	inv_sweep_any_tile<W, 4, RING, NT, true, false, SP>(a, g);
 }
 
 template <class W, int RING, int NT, bool SP>
@@ -507,7 +588,7 @@ __global__ __launch_bounds__(256) void k_inv_sweep_x(InvLevelArgs a, SweepGeom g
 		il_strip_wave<W, true>(strip, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 		return;
 	}
-	inv_sweep_tile<W, 4, RING, NT, true, true, SP>(a, g);
+	inv_sweep_any_tile<W, 4, RING, NT, true, true, SP>(a, g);
 }
 
 // ---- launch wrappers -------------------------------------------------------------

@@ -5,12 +5,14 @@ pins to the reference on the same inputs (tests/test_float_range.py, tests/golde
 Criterion `same_floats`: same bits wherever neither side is a NaN, NaNs at the same positions.
 
 Line ends.  The reference adds (2c)*x where both taps of a sample are the one sample x
-(src/libdwt.c:9545-9552, 9873-9907); reflection -- which the kernels apply to their load addresses -- gives c*(x+x):
-`v_add_f32 t, x, x` overflows to Inf for |x| > FLT_MAX/2 where (2c)*x with |2c| < 1 stays finite.  That is the one
-listed difference of the default build: its float and double entries are compared with the oracle's
-reflected-ends form on the two classes that reach that range ("huge", "mixed") and with the reference's own outputs
-(the fixtures) on the others.  The EXACT build (`make exact`: explicit end forms in every 2-D kernel, dwt_lift.h) is
-compared with the faithful oracle and the fixtures on EVERY class; this file runs against both builds."""
+(src/libdwt.c:9545-9552, 9873-9907); reflection alone -- which the kernels apply to their load addresses -- would give
+c*(x+x): `v_add_f32 t, x, x` overflows to Inf for |x| > FLT_MAX/2 where (2c)*x with |2c| < 1 stays finite.  Every 2-D
+kernel of the library applies the reference's own form (dwt_lift.h: SelEnds in the tile sweeps, fwd_end / inv_end
+elsewhere): the 2-D entries are compared with the FAITHFUL oracle and the reference's own outputs (the fixtures) on
+every class.  The 3-D level kernels keep the reflected form, the one listed difference: the 3-D entries are
+compared with the oracle's reflected-ends form on the two classes that reach that range ("huge", "mixed") and with the
+fixtures on the others.  `make plain` (libdwt_hip_plain.so, DWT_FLOAT_END_FORMS=0: an A/B timing build, reflected ends
+in every float kernel) can be put under this file with DWT_HIP_LIB; it is then held to the reflected form throughout."""
 import warnings
 
 import numpy as np
@@ -24,13 +26,11 @@ warnings.filterwarnings("ignore", category=RuntimeWarning)
 
 OVERFLOWING = {"huge", "mixed"}
 # Which entries evaluate a line end as c*(x+x) (reflected load addresses) depends on the BUILD (dwt_lift.h,
-# DWT_FLOAT_END_FORMS): the default library does for every float / double entry; `make exact` (libdwt_hip_exact.so,
-# selected with DWT_HIP_LIB -- test_exact_build_over_the_whole_float_range runs this file against it) applies the
-# reference's own (2c)*x in every 2-D kernel and keeps the reflected form in the 3-D level kernels only.
+# DWT_FLOAT_END_FORMS): the library only in its 3-D level kernels; the A/B build `make plain` in every float / double entry.
 import os
 
-EXACT_BUILD = os.path.basename(os.environ.get("DWT_HIP_LIB", "")).startswith("libdwt_hip_exact")
-ENDS_REFLECTED = {"cdf97_3d"} if EXACT_BUILD else {"cdf97_s", "cdf53_s", "cdf97_d", "cdf53_d", "cdf97_il", "cdf53_il", "cdf97_3d"}
+PLAIN_BUILD = os.path.basename(os.environ.get("DWT_HIP_LIB", "")).startswith("libdwt_hip_plain")
+ENDS_REFLECTED = {"cdf97_s", "cdf53_s", "cdf97_d", "cdf53_d", "cdf97_il", "cdf53_il", "cdf97_3d"} if PLAIN_BUILD else {"cdf97_3d"}
 WID = {"cdf97_s": "cdf97_s", "cdf53_s": "cdf53_s", "cdf97_d": "cdf97_d", "cdf53_d": "cdf53_d"}
 
 
@@ -208,7 +208,7 @@ def test_large_image_seams_over_the_whole_float_range(dwt, oracle, klass, nf):
     for ff, fi, f, i in (("cdf97_2f_s", "cdf97_2i_s", dwt.dwt_cdf97_2f_s, dwt.dwt_cdf97_2i_s),
                          ("cdf97_2f_inplace_s", "cdf97_2i_inplace_s", dwt.dwt_cdf97_2f_inplace_s, dwt.dwt_cdf97_2i_inplace_s)):
         want = a.copy()
-        ctx = warnings.catch_warnings() if EXACT_BUILD else oracle.reflected_ends()
+        ctx = oracle.reflected_ends() if PLAIN_BUILD else warnings.catch_warnings()
         with ctx:
             oracle.fwd(ff, want, 4)
             back = want.copy()
@@ -222,18 +222,19 @@ def test_large_image_seams_over_the_whole_float_range(dwt, oracle, klass, nf):
         d.free()
 
 
-def test_exact_build_over_the_whole_float_range():
-    """The same file against libdwt_hip_exact.so (`make exact`: the reference's line-end forms in every 2-D float /
-    double kernel): there the 2-D entries equal the FAITHFUL oracle and the reference's fixtures on every class.  Own
-    process: the library is chosen at import (DWT_HIP_LIB)."""
+def test_plain_build_over_the_whole_float_range():
+    """The same file against libdwt_hip_plain.so where it has been built (`make -C libdwt_amd/csrc plain`, the A/B timing
+    build with reflected line ends in every float kernel): there every float entry equals the oracle's reflected-ends form.
+    Own process: the library is chosen at import (DWT_HIP_LIB)."""
     import subprocess
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(os.path.dirname(here), "libdwt_amd", "libdwt_hip_exact.so")
-    if EXACT_BUILD:
-        pytest.skip("already running against the exact build")
-    assert os.path.exists(lib), "libdwt_amd/libdwt_hip_exact.so is missing: make -C libdwt_amd/csrc exact"
+    lib = os.path.join(os.path.dirname(here), "libdwt_amd", "libdwt_hip_plain.so")
+    if PLAIN_BUILD:
+        pytest.skip("already running against the plain build")
+    if not os.path.exists(lib):
+        pytest.skip("libdwt_amd/libdwt_hip_plain.so not built (make -C libdwt_amd/csrc plain): an A/B artefact, not shipped")
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__)],
                          env=dict(os.environ, DWT_HIP_LIB=lib), capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
     assert out.returncode == 0 and " passed" in out.stdout, (out.stdout[-2500:], out.stderr[-1500:])

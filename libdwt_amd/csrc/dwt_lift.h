@@ -294,6 +294,16 @@ struct PlainEnds : W {
 	static constexpr bool kEndForms = false;
 };
 
+// reflect() without the division, for an index within a few samples of a line of 16 samples or more -- one bounce; whatever
+// lies further out (the columns of lanes beyond the line's end, whose results are dropped) is clamped into the line so
+// that it stays a valid address
+static __device__ __forceinline__ int reflect_near(int i, int N)
+{
+	i = i < 0 ? -i : i;
+	i = i >= N ? 2 * (N - 1) - i : i;
+	return i < 0 ? 0 : i;
+}
+
 // W with its line-end forms by SELECTION instead of by branches (float policies with fk / ik / step_k): at a line end the
 // reference adds (2c) x where both taps of the plain step are that x.  c + k (l + r) gives those very bits with k = 2c and
 // the virtual tap replaced by -0.0 (x + -0.0 == x for every x, +-0, Inf and NaN included) -- a select on the coefficient

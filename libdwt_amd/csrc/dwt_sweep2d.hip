@@ -197,11 +197,13 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	// or not -- takes the same 16-byte path; the up to four reflected columns right of the edge
 	// that a valid output can reach come by one 4-byte DMA per row.
 	const int n_edge = min(4, c0 + TW - a.W); // columns of this tile's main block right of the edge (<= 0: none)
-	const int edge_col = reflect(a.W + min(lane, 3), a.W);
-	const int halo_col = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
+	// (SelEnds: levels of 64 x 64 and more -- no index is reflected twice, no integer division in the wave's instruction stream)
+	const int edge_col = kIsSelEnds<W> ? a.W - 2 - min(lane, 3) : reflect(a.W + min(lane, 3), a.W);
+	const int halo_i = lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3);
+	const int halo_col = kIsSelEnds<W> ? reflect_near(halo_i, a.W) : reflect(halo_i, a.W);
 
 	int islot = 0, rslot = 0; // ring slots of the next rows to fill / to consume
-	const bool tall = a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
+	const bool tall = kIsSelEnds<W> || a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
 	// In place (interleaved layout, a.sh): this tile's own rows and columns come from the image -- its stores trail its
 	// loads --, everything else from the snapshot: a neighbour's row as a whole from the row shell, a neighbour's
 	// column of an own row from the column shell (offset in that shell's row, or -1: an own column)

@@ -82,17 +82,21 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	const int nL = Wd, nH = a.W >> 1; // valid columns of an L / H segment
 	// lanes 0,1: the reflected L columns nL, nL+1; lanes 2,3: the H columns nH, nH+1
 	const int edge_sub = (lane & 2) ? nH + (lane & 1) : nL + (lane & 1);
-	const int edge_col = reflect(2 * edge_sub + ((lane >> 1) & 1), a.W) >> 1;
+	// (SelEnds: levels of 64 x 64 and more -- no index is reflected twice, no integer division in the wave's instruction stream)
+	constexpr bool kNear = kIsSelEnds<W>;
+	const bool tall = kNear || a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
+	const int edge_col = (kNear ? reflect_near(2 * edge_sub + ((lane >> 1) & 1), a.W) : reflect(2 * edge_sub + ((lane >> 1) & 1), a.W)) >> 1;
 	// halo lanes 0..7 -> L halo, 8..15 -> H halo
 	const int hsub = (lane & 7) < 4 ? cl0 - 4 + (lane & 7) : cl0 + M + (lane & 3);
-	const int halo_col = reflect(2 * hsub + ((lane >> 3) & 1), a.W) >> 1;
+	const int halo_col = (kNear ? reflect_near(2 * hsub + ((lane >> 3) & 1), a.W) : reflect(2 * hsub + ((lane >> 3) & 1), a.W)) >> 1;
 	const bool halo_is_h = (lane >> 3) & 1;
 
 	// pointers to the four subbands' row starts are formed per source row
 	// interleaved input: source columns of the element-wise loader and of the halo
 	int halo_colI = 0;
 	if constexpr (IL) {
-		halo_colI = reflect(lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3), a.W);
+		const int hi_ = lane < 4 ? c0 - 4 + lane : c0 + TW + (lane & 3);
+		halo_colI = kNear ? reflect_near(hi_, a.W) : reflect(hi_, a.W);
 	}
 	const int step = IL ? a.in_step : 1;
 	const unsigned src_row_bytes = ((unsigned)(a.W - 1) * step + 1) * 4; // a source row up to its last sample
@@ -112,7 +116,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 		if constexpr (IL) {
 #pragma unroll
 			for (int rr = 0; rr < 2; rr++) {
-				const int r = reflect(2 * p + rr, a.H);
+				const int r = tall ? reflect1(2 * p + rr, a.H) : reflect(2 * p + rr, a.H);
 				char *lrow = ring + (size_t)((2 * it + rr) & (kRing - 1)) * RS * 4;
 				// even rows come from in_ll, odd rows from in_h (reflection keeps the parity): the
 				// two may be different buffers
@@ -176,7 +180,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				if (fix_right && lane < kIlKeepRight)
 					dma4<kLdAux>(rgt + (wr + lane), lrow + (wr - c0) * 4);
 				if (lane < min(4, c0 + TW - a.W))
-					dma4<kLdAux>((rgt ? rgt : grow) + (long)reflect(a.W + min(lane, 3), a.W) * step, lrow + (a.W - c0) * 4);
+					dma4<kLdAux>((rgt ? rgt : grow) + (long)(kNear ? a.W - 2 - min(lane, 3) : reflect(a.W + min(lane, 3), a.W)) * step, lrow + (a.W - c0) * 4);
 				if (lane < 8)
 					dma4<kLdAux>((crow && halo_shI >= 0) ? crow + halo_shI : (rgt && halo_colI >= wr) ? rgt + halo_colI : grow + (long)halo_colI * step, lrow + TW * 4);
 			}
@@ -185,7 +189,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
 			// rr = 0: L row p (interleaved row 2p); rr = 1: H row p (row 2p+1)
-			const int rs = reflect(2 * p + rr, a.H);
+			const int rs = tall ? reflect1(2 * p + rr, a.H) : reflect(2 * p + rr, a.H);
 			const int sub = rs >> 1;
 			// reflection keeps parity, so an L row stays an L row
 			const T *gl, *gh; // [left half | right half] of this Mallat row
@@ -271,7 +275,6 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 			sel_coefs<W, true, K - 1>(kh[gi], e0[gi], e1[gi]);
 		}
 	}
-	const bool tall = a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
 	[[maybe_unused]] auto row_is_end = [&](int r) {
 		if (tall || kIsSelEnds<W>) // (SelEnds runs on levels of 64 rows or more)
 			return r == 0 || r == a.H - 1;

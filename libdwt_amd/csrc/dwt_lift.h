@@ -319,22 +319,45 @@ template <class W> constexpr bool kIsSelEnds<SelEnds<W>> = true;
 template <class W, class = void> struct has_coef_ends : std::false_type {};
 template <class W> struct has_coef_ends<W, std::void_t<decltype(W::fk(0))>> : std::true_type {};
 
+// One step of the select form on a sample that can be a line end (`e`): `virt` is the tap that is virtual there, `real` the
+// other (the same values at an end).  Float policies: the plain step with the lane's coefficient kk (doubled where e) and
+// the virtual tap dropped; the int 5/3, whose end forms are formulas of their own, evaluates both and selects.
+template <class W, bool INV>
+static __device__ __forceinline__ typename W::T sel_step(int s, bool e, typename W::T kk, typename W::T c, typename W::T virt, typename W::T real)
+{
+	using T = typename W::T;
+	if constexpr (has_coef_ends<W>::value)
+		return W::step_k(kk, c, e ? T(-0.0) : virt, real);
+	else
+		return e ? (INV ? W::inv_end(s, c, real) : W::fwd_end(s, c, real)) : (INV ? W::inv_step(s, c, virt, real) : W::fwd_step(s, c, virt, real));
+}
+// the coefficient of step s for sel_step: doubled where the sample is an end (float policies; nothing for the int 5/3)
+template <class W, bool INV>
+static __device__ __forceinline__ typename W::T sel_coef(int s, bool e)
+{
+	using T = typename W::T;
+	if constexpr (has_coef_ends<W>::value) {
+		const T k = INV ? W::ik(s) : W::fk(s);
+		return e ? T(2) * k : k;
+	} else
+		return T(0);
+}
+
 // The K lifting steps over a[0..n) as lift_fwd_regs / lift_inv_regs run them, with two entries that can be line ends:
 // J0 (column 0: its LEFT tap is virtual) when e0, J1 (the last column: its RIGHT tap is virtual) when e1.  kk[s]: the
 // lane's coefficient of step s for those entries (doubled where the entry the step reaches is an end).
 template <class W, int n, bool INV, int J0, int J1>
 static __device__ __forceinline__ void lift_regs_sel(typename W::T (&a)[n], bool e0, bool e1, const typename W::T (&kk)[W::K])
 {
-	using T = typename W::T;
 	static_assert(((J0 ^ J1) & 1) == 1, "the two candidates are reached by different steps");
 #pragma unroll
 	for (int s = 0; s < W::K; s++) {
 #pragma unroll
 		for (int j = s + 1; j <= n - 2 - s; j += 2) {
 			if (j == J0)
-				a[j] = W::step_k(kk[s], a[j], e0 ? T(-0.0) : a[j - 1], a[j + 1]);
+				a[j] = sel_step<W, INV>(s, e0, kk[s], a[j], a[j - 1], a[j + 1]);
 			else if (j == J1)
-				a[j] = W::step_k(kk[s], a[j], a[j - 1], e1 ? T(-0.0) : a[j + 1]);
+				a[j] = sel_step<W, INV>(s, e1, kk[s], a[j], a[j + 1], a[j - 1]);
 			else
 				a[j] = INV ? W::inv_step(s, a[j], a[j - 1], a[j + 1]) : W::fwd_step(s, a[j], a[j - 1], a[j + 1]);
 		}
@@ -345,13 +368,9 @@ static __device__ __forceinline__ void lift_regs_sel(typename W::T (&a)[n], bool
 template <class W, bool INV, int J0>
 static __device__ __forceinline__ void sel_coefs(typename W::T (&kk)[W::K], bool e0, bool e1)
 {
-	using T = typename W::T;
 #pragma unroll
-	for (int s = 0; s < W::K; s++) {
-		const T k = INV ? W::ik(s) : W::fk(s);
-		const bool e = ((J0 - (s + 1)) & 1) == 0 ? e0 : e1; // the candidate step s reaches
-		kk[s] = e ? T(2) * k : k;
-	}
+	for (int s = 0; s < W::K; s++)
+		kk[s] = sel_coef<W, INV>(s, ((J0 - (s + 1)) & 1) == 0 ? e0 : e1); // (the candidate step s reaches)
 }
 
 // Step s on a sample whose taps are l and r; `end`: the sample sits on a line end (index 0 or

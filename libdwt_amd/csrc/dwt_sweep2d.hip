@@ -453,15 +453,15 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 				T kv[K];
 #pragma unroll
 				for (int s_ = 0; s_ < K; s_++)
-					kv[s_] = ve[s_] ? T(2) * W::fk(s_) : W::fk(s_);
+					kv[s_] = sel_coef<W, false>(s_, ve[s_]);
 #pragma unroll
 				for (int v = 0; v < CPT; v++) {
 					const T ov = row[0][v], ev = row[1][v];
 					if constexpr (K == 4) {
-						const T d1n = W::step_k(kv[0], ov, ve[0] ? T(-0.0) : st[0][v], ev);
-						const T s1n = W::step_k(kv[1], st[0][v], ve[1] ? T(-0.0) : st[1][v], d1n);
-						const T d2n = W::step_k(kv[2], st[1][v], ve[2] ? T(-0.0) : st[2][v], s1n);
-						const T s2n = W::step_k(kv[3], st[2][v], ve[3] ? T(-0.0) : st[3][v], d2n);
+						const T d1n = sel_step<W, false>(0, ve[0], kv[0], ov, st[0][v], ev);
+						const T s1n = sel_step<W, false>(1, ve[1], kv[1], st[0][v], st[1][v], d1n);
+						const T d2n = sel_step<W, false>(2, ve[2], kv[2], st[1][v], st[2][v], s1n);
+						const T s2n = sel_step<W, false>(3, ve[3], kv[3], st[2][v], st[3][v], d2n);
 						lo[v] = W::fwd_scale(0, s2n);
 						hi[v] = W::fwd_scale(1, d2n);
 						st[0][v] = ev;
@@ -469,8 +469,8 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 						st[2][v] = s1n;
 						st[3][v] = d2n;
 					} else {
-						const T d1n = W::step_k(kv[0], ov, ve[0] ? T(-0.0) : st[0][v], ev);
-						const T s1n = W::step_k(kv[1], st[0][v], ve[1] ? T(-0.0) : st[1][v], d1n);
+						const T d1n = sel_step<W, false>(0, ve[0], kv[0], ov, st[0][v], ev);
+						const T s1n = sel_step<W, false>(1, ve[1], kv[1], st[0][v], st[1][v], d1n);
 						lo[v] = W::fwd_scale(0, s1n);
 						hi[v] = W::fwd_scale(1, d1n);
 						st[0][v] = ev;
@@ -480,7 +480,7 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 			};
 			// (shallow ring: the launches of a few rounds of waves, bound by the longest wave -- the top tiles', for whom a
 			// second body means instructions fetched cold from HBM, 1 us a launch; there every iteration selects)
-			if constexpr (RING == 8)
+			if constexpr (RING == 8 && has_coef_ends<W>::value)
 				vertical_sel();
 			else if (__builtin_expect(any, 0)) {
 				DWT_END_PATH();
@@ -626,7 +626,7 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 template <class W, int CPT, int RING, int NT, bool IL, bool X>
 static __device__ __forceinline__ void fwd_sweep_any_tile(const FwdLevelArgs &a, const SweepGeom &g)
 {
-	if constexpr (W::kEndForms && has_coef_ends<W>::value && !(DWT_PROBES && (NT & 16))) {
+	if constexpr (W::kEndForms && !(DWT_PROBES && (NT & 16))) {
 		if (a.plain_ends)
 			fwd_sweep_tile<PlainEnds<W>, CPT, RING, NT, IL, X>(a, g);
 		else if (a.W % CPT == 0 && a.W >= 64 && a.H >= 64)

@@ -266,7 +266,6 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	[[maybe_unused]] bool e0[G] = {}, e1[G] = {};
 	[[maybe_unused]] T kh[G][K];
 	if constexpr (kIsSelEnds<W>) {
-		static_assert(!W::kInvColsFirst, "float policies undo the rows first");
 #pragma unroll
 		for (int gi = 0; gi < G; gi++) {
 			const unsigned m = end_mask_long<NARR>(c0 + 64 * CG * gi + lane * CG - K + 1, a.W);
@@ -460,17 +459,17 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				T kv[K];
 #pragma unroll
 				for (int s_ = 0; s_ < K; s_++)
-					kv[s_] = ve[s_] ? T(2) * W::ik(s_) : W::ik(s_);
+					kv[s_] = sel_coef<W, true>(s_, ve[s_]);
 #pragma unroll
 				for (int gi = 0; gi < G; gi++)
 #pragma unroll
 				for (int v = 0; v < NVG; v++) {
 					const T s2 = val[0][gi][v], d2 = val[1][gi][v];
 					if constexpr (K == 4) {
-						const T s1n = W::step_k(kv[0], s2, ve[0] ? T(-0.0) : st[0][gi][v], d2);
-						const T d1n = W::step_k(kv[1], st[0][gi][v], ve[1] ? T(-0.0) : st[1][gi][v], s1n);
-						const T en = W::step_k(kv[2], st[1][gi][v], ve[2] ? T(-0.0) : st[2][gi][v], d1n);
-						const T on = W::step_k(kv[3], st[2][gi][v], ve[3] ? T(-0.0) : st[3][gi][v], en);
+						const T s1n = sel_step<W, true>(0, ve[0], kv[0], s2, st[0][gi][v], d2);
+						const T d1n = sel_step<W, true>(1, ve[1], kv[1], st[0][gi][v], st[1][gi][v], s1n);
+						const T en = sel_step<W, true>(2, ve[2], kv[2], st[1][gi][v], st[2][gi][v], d1n);
+						const T on = sel_step<W, true>(3, ve[3], kv[3], st[2][gi][v], st[3][gi][v], en);
 						odd_row[gi][v] = on;
 						even_row[gi][v] = en;
 						st[0][gi][v] = d2;
@@ -478,8 +477,8 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 						st[2][gi][v] = d1n;
 						st[3][gi][v] = en;
 					} else {
-						const T en = W::step_k(kv[0], s2, ve[0] ? T(-0.0) : st[0][gi][v], d2);
-						const T on = W::step_k(kv[1], st[0][gi][v], ve[1] ? T(-0.0) : st[1][gi][v], en);
+						const T en = sel_step<W, true>(0, ve[0], kv[0], s2, st[0][gi][v], d2);
+						const T on = sel_step<W, true>(1, ve[1], kv[1], st[0][gi][v], st[1][gi][v], en);
 						odd_row[gi][v] = on;
 						even_row[gi][v] = en;
 						st[0][gi][v] = d2;
@@ -548,7 +547,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 template <class W, int CPT, int RING, int NT, bool IL, bool X, bool SP = false>
 static __device__ __forceinline__ void inv_sweep_any_tile(const InvLevelArgs &a, const SweepGeom &g)
 {
-	if constexpr (W::kEndForms && has_coef_ends<W>::value) {
+	if constexpr (W::kEndForms) {
 		constexpr int CG = (!IL && CPT == 8) ? 4 : CPT; // columns per group, as in the tile
 		if (a.plain_ends)
 			inv_sweep_tile<PlainEnds<W>, CPT, RING, NT, IL, X, SP>(a, g);

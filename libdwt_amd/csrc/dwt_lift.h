@@ -19,10 +19,11 @@
 // (:10971-10976, :11768-11773), which differ from the reflected `(d+d+2)>>2` / `(s+s)>>1` once
 // the doubled term wraps (|x| >= 2^30); only the fixed-point 9/7 writes `a[N-2]+a[N-2]` itself.
 // So the policies carry explicit END FORMS (kEndForms, fwd_end / inv_end) and the kernels
-// apply them to the samples whose two taps are one and the same sample.  The float tile sweeps do it by SELECTION
-// (SelEnds below: the end step is the plain step with the coefficient doubled and the virtual tap replaced by -0.0 --
-// straight-line code, no second formula); the int 5/3 and the shapes SelEnds leaves out on a path of its own, taken by
-// the waves whose tile holds a line end (wave-uniform tests).  Int arithmetic wraps modulo 2^32 like the compiled reference
+// apply them to the samples whose two taps are one and the same sample.  The tile sweeps do it by SELECTION at the two
+// window entries that can be a line end (SelEnds below; float: the end step is the plain step with the coefficient doubled
+// and the virtual tap replaced by -0.0 -- straight-line code, no second formula; int 5/3: both formulas, one select); the
+// shapes SelEnds leaves out take a path of their own in the waves whose tile holds a line end (wave-uniform tests).
+// Int arithmetic wraps modulo 2^32 like the compiled reference
 // (done in unsigned here: signed overflow is undefined for the compiler).  A forward transform runs K lifting
 // steps, step s acting on samples of parity (s+1)&1, then scales; an inverse
 // transform descales, then runs K steps, step s acting on parity s&1.
@@ -36,7 +37,7 @@
 // overflows; what shipped until the select form made the exact ends free (round 6, alternated on one box: forward call of
 // one 8192^2 image 155 = 155 us, the bench's batch of 32 unchanged within its noise, inverse calls + 1-3 %; the
 // branching forms had cost 8-11 % and 3.5 %: profiles/r06_notes.md).  The 3-D level kernels keep the reflected form in
-// either build.  The int 5/3 needs its end forms in every build.
+// either build.  The int 5/3 has its end forms in every build.
 #ifndef DWT_FLOAT_END_FORMS
 #define DWT_FLOAT_END_FORMS 1
 #endif

@@ -222,6 +222,49 @@ def test_large_image_seams_over_the_whole_float_range(dwt, oracle, klass, nf):
         d.free()
 
 
+# Shapes on both sides of the rules that pick a tile sweep's instantiation (dwt_sweep2d.hip, fwd_sweep_any_tile /
+# inv_sweep_any_tile): the select form runs levels of 64 x 64 and more whose width is a multiple of the columns per lane
+# (8 forward from 2048 columns on, else 4; groups of 4 inverse), everything else the branching form -- and a multi-level
+# call crosses from one to the other on its way down.
+DISPATCH_SHAPES = [(64, 64), (64, 72), (66, 64), (63, 64), (64, 60), (64, 68), (128, 66), (65, 136), (130, 2048), (96, 2056),
+                   (72, 2052), (256, 126), (127, 128), (512, 520)]
+
+
+@pytest.mark.parametrize("klass", ["huge", "mixed"])
+@pytest.mark.parametrize("shape", DISPATCH_SHAPES, ids=lambda s: "%dx%d" % s)
+def test_both_sides_of_the_instantiation_rules(dwt, oracle, shape, klass):
+    """Float 9/7, float 5/3 (device-resident, 3 levels, forward and inverse) and int 5/3 over the whole range on the shapes
+    above, against the faithful oracle: whichever instantiation a level takes, the line ends are the reference's."""
+    from conftest import full_range_ints
+    h, w = shape
+    rng = np.random.default_rng(h * 4099 + w)
+    a = full_range_floats(rng, (h, w), np.float32, klass, klass == "mixed")
+    for name, ff, fi in (("cdf97_s", "cdf97_2f_s", "cdf97_2i_s"), ("cdf53_s", "cdf53_2f_s", "cdf53_2i_s")):
+        want = a.copy()
+        j = oracle.fwd(ff, want, 3)
+        back = want.copy()
+        oracle.inv(fi, back, j)
+        d = dwt.DeviceImage(h, w).upload(a)
+        assert dwt.FORWARD[name](d.ptr, d.stride_x, 4, w, h, w, h, 3) == j
+        assert same_floats(d.download(np.float32), want), name + " forward"
+        d.upload(want)
+        dwt.INVERSE[name](d.ptr, d.stride_x, 4, w, h, w, h, j)
+        assert same_floats(d.download(np.float32), back), name + " inverse"
+        d.free()
+    b = full_range_ints(rng, (h, w))
+    want = b.copy()
+    j = oracle.fwd("cdf53_2f_i", want, 3)
+    back = want.copy()
+    oracle.inv("cdf53_2i_i", back, j)
+    d = dwt.DeviceImage(h, w).upload(b)
+    assert dwt.FORWARD["cdf53_i"](d.ptr, d.stride_x, 4, w, h, w, h, 3) == j
+    assert np.array_equal(d.download(np.int32), want), "int 5/3 forward"
+    d.upload(want)
+    dwt.INVERSE["cdf53_i"](d.ptr, d.stride_x, 4, w, h, w, h, j)
+    assert np.array_equal(d.download(np.int32), back), "int 5/3 inverse"
+    d.free()
+
+
 def test_plain_build_over_the_whole_float_range():
     """The same file against libdwt_hip_plain.so where it has been built (`make -C libdwt_amd/csrc plain`, the A/B timing
     build with reflected line ends in every float kernel): there every float entry equals the oracle's reflected-ends form.

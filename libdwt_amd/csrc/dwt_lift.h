@@ -249,6 +249,10 @@ struct Cdf97D {
 	// line ends (:2040-2047, :11439-11446): `+= 2*u*x`, `-= 2*p*x`
 	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return s == 0 ? c - (2 * p1()) * m : s == 1 ? c + (2 * u1()) * m : s == 2 ? c - (2 * p2()) * m : c + (2 * u2()) * m; }
 	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return s == 0 ? c - (2 * u2()) * m : s == 1 ? c + (2 * p2()) * m : s == 2 ? c - (2 * u1()) * m : c + (2 * p1()) * m; }
+	// the steps as c + k (l + r) (SelEnds; c - p t and c + (-p) t are the same double for every c, t)
+	static __device__ __forceinline__ T fk(int s) { return s == 0 ? -p1() : s == 1 ? u1() : s == 2 ? -p2() : u2(); }
+	static __device__ __forceinline__ T ik(int s) { return s == 0 ? -u2() : s == 1 ? p2() : s == 2 ? -u1() : p1(); }
+	static __device__ __forceinline__ T step_k(T k, T c, T l, T r) { return c + k * (l + r); }
 };
 
 // src/libdwt.c:2085-2130, 11484-11530; constants src/inline.h:337-341
@@ -269,6 +273,9 @@ struct Cdf53D {
 	static __device__ __forceinline__ T inv_single(T v) { return v * s2(); }
 	static __device__ __forceinline__ T fwd_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.5) * m : c + (2 * 0.25) * m; }
 	static __device__ __forceinline__ T inv_end(int s, T c, T m) { return s == 0 ? c - (2 * 0.25) * m : c + (2 * 0.5) * m; }
+	static __device__ __forceinline__ T fk(int s) { return s == 0 ? -0.5 : 0.25; }
+	static __device__ __forceinline__ T ik(int s) { return s == 0 ? -0.25 : 0.5; }
+	static __device__ __forceinline__ T step_k(T k, T c, T l, T r) { return c + k * (l + r); }
 };
 
 // Whole-sample symmetric reflection of i into [0, N), N >= 2, any i.

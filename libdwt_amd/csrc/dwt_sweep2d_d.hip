@@ -45,7 +45,7 @@ struct SweepGeomD {
 // ---- forward ---------------------------------------------------------------------------
 // LDS row slot (bytes): [main 2048 | left halo 32 | right halo 32]
 template <class W, int RING>
-__global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD g)
+static __device__ __forceinline__ void fwd_sweep_d_tile(const FwdLevelArgs &a, const SweepGeomD &g)
 {
 	using T = double;
 	constexpr int K = W::K, CPT = 4, TW = 64 * CPT, RSB = TW * 8 + 64, NARR = CPT + 2 * K;
@@ -84,19 +84,34 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 	// row's end zero-filled / dropped by the hardware; the up to four reflected columns right of
 	// the image's edge come as 4-byte DMAs (lane l: word l & 1 of column W + (l >> 1))
 	const int n_edge = 2 * min(4, c0 + TW - a.W); // lanes of that DMA (<= 0: none)
-	const int edge_col = reflect(a.W + min(lane >> 1, 3), a.W);
+	// (SelEnds: levels of 64 x 64 and more -- no index is reflected twice, no integer division in the wave's instruction stream)
+	constexpr bool kSel = kIsSelEnds<W>;
+	const int edge_col = kSel ? a.W - 2 - min(lane >> 1, 3) : reflect(a.W + min(lane >> 1, 3), a.W);
 	// halo: lanes 0..7 the four columns left of the tile, 8..15 the four to its right (two words each)
-	const int halo_col = reflect(lane < 8 ? c0 - 4 + (lane >> 1) : c0 + TW + ((lane >> 1) & 3), a.W);
+	const int halo_i = lane < 8 ? c0 - 4 + (lane >> 1) : c0 + TW + ((lane >> 1) & 3);
+	const int halo_col = kSel ? reflect_near(halo_i, a.W) : reflect(halo_i, a.W);
 	const int word = lane & 1;
 
 	int islot = 0, rslot = 0;
-	const bool tall = a.H >= 64;
+	const bool tall = kSel || a.H >= 64;
 	// line-end forms (dwt_lift.h; see k_fwd_sweep): the lane's columns c - K .. that are a row's ends, any in this tile,
 	// and the test for a row being a column's end
-	const unsigned hends = end_mask<NARR>(c0 + lane * CPT - K, a.W);
-	const bool h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+	[[maybe_unused]] unsigned hends = 0;
+	[[maybe_unused]] bool h_any = false, h_simple = false;
 	constexpr unsigned kCand = (1u << K) | (1u << (K + CPT - 1)); // the two entries that meet a line end when W is a multiple of CPT
-	const bool h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
+	// (SelEnds) the same two entries by selection: the lane's flags and its coefficients for the steps that reach them
+	[[maybe_unused]] bool e0 = false, e1 = false;
+	[[maybe_unused]] T kh[K];
+	if constexpr (kSel) {
+		const unsigned m = end_mask_long<NARR>(c0 + lane * CPT - K, a.W);
+		e0 = (m >> K) & 1;
+		e1 = (m >> (K + CPT - 1)) & 1;
+		sel_coefs<W, false, K>(kh, e0, e1);
+	} else if constexpr (W::kEndForms) {
+		hends = end_mask<NARR>(c0 + lane * CPT - K, a.W);
+		h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+		h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
+	}
 	auto row_is_end = [&](int r) {
 		if (tall)
 			return r == 0 || r == a.H - 1;
@@ -170,7 +185,9 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 			x[K + 1] = dbl(r[2][2], r[2][3]);
 			x[K + 2] = dbl(r[3][0], r[3][1]);
 			x[K + 3] = dbl(r[3][2], r[3][3]);
-			if (__builtin_expect(!h_any, 1)) {
+			if constexpr (kSel) {
+				lift_regs_sel<W, NARR, false, K, K + CPT - 1>(x, e0, e1, kh);
+			} else if (__builtin_expect(!h_any, 1)) {
 				lift_fwd_regs<W, NARR>(x, 0u);
 			} else if (h_simple) {
 				DWT_END_PATH();
@@ -193,16 +210,31 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 			v_any = v_any || vend[s_];
 		}
 		T lo[CPT], hi[CPT];
+		// (SelEnds: an end step is the plain step with the coefficient doubled and the state tap dropped)
+		[[maybe_unused]] T kv[K];
+		if constexpr (kSel) {
+#pragma unroll
+			for (int s_ = 0; s_ < K; s_++)
+				kv[s_] = sel_coef<W, false>(s_, vend[s_]);
+		}
 		auto vertical = [&](auto ends_tag) {
 			constexpr bool ENDS = decltype(ends_tag)::value;
+			auto vstep = [&](int s_, T c, T l, T r) {
+				if constexpr (kSel && ENDS)
+					return sel_step<W, false>(s_, vend[s_], kv[s_], c, l, r);
+				else if constexpr (kSel)
+					return W::fwd_step(s_, c, l, r);
+				else
+					return fwd_step_at<W>(s_, ENDS && vend[s_], c, l, r);
+			};
 #pragma unroll
 			for (int v = 0; v < CPT; v++) {
 				const T ov = row[0][v], ev = row[1][v];
 				if constexpr (K == 4) {
-					const T d1n = fwd_step_at<W>(0, ENDS && vend[0], ov, st[0][v], ev);
-					const T s1n = fwd_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], d1n);
-					const T d2n = fwd_step_at<W>(2, ENDS && vend[2], st[1][v], st[2][v], s1n);
-					const T s2n = fwd_step_at<W>(3, ENDS && vend[3], st[2][v], st[3][v], d2n);
+					const T d1n = vstep(0, ov, st[0][v], ev);
+					const T s1n = vstep(1, st[0][v], st[1][v], d1n);
+					const T d2n = vstep(2, st[1][v], st[2][v], s1n);
+					const T s2n = vstep(3, st[2][v], st[3][v], d2n);
 					lo[v] = W::fwd_scale(0, s2n);
 					hi[v] = W::fwd_scale(1, d2n);
 					st[0][v] = ev;
@@ -210,8 +242,8 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 					st[2][v] = s1n;
 					st[3][v] = d2n;
 				} else {
-					const T d1n = fwd_step_at<W>(0, ENDS && vend[0], ov, st[0][v], ev);
-					const T s1n = fwd_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], d1n);
+					const T d1n = vstep(0, ov, st[0][v], ev);
+					const T s1n = vstep(1, st[0][v], st[1][v], d1n);
 					lo[v] = W::fwd_scale(0, s1n);
 					hi[v] = W::fwd_scale(1, d1n);
 					st[0][v] = ev;
@@ -239,6 +271,19 @@ __global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD 
 			}
 		}
 	}
+}
+
+// the tile by the instantiation of the policy's line ends the level needs (dwt_lift.h; see fwd_sweep_any_tile)
+template <class W, int RING>
+__global__ __launch_bounds__(256) void k_fwd_sweep_d(FwdLevelArgs a, SweepGeomD g)
+{
+	if constexpr (W::kEndForms) {
+		if (a.W % 4 == 0 && a.W >= 64 && a.H >= 64)
+			fwd_sweep_d_tile<SelEnds<W>, RING>(a, g);
+		else
+			fwd_sweep_d_tile<W, RING>(a, g);
+	} else
+		fwd_sweep_d_tile<W, RING>(a, g);
 }
 
 template <class W, int RING>
@@ -300,7 +345,7 @@ hipError_t launch_fwd_level_d(Wavelet w, const FwdLevelArgs &a, const SweepTunin
 // [L main 512 | H main 512 | L halo 64 | H halo 64]; a halo block is [4 columns left of the tile |
 // 4 columns right of it].  A lane needs the 5 subband columns around its own of each half.
 template <class W, int RING>
-__global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD g)
+static __device__ __forceinline__ void inv_sweep_d_tile(const InvLevelArgs &a, const SweepGeomD &g)
 {
 	using T = double;
 	constexpr int K = W::K, CPT = 2, TW = 64 * CPT, M = TW / 2, RSB = 2 * M * 8 + 128, NARR = CPT + 2 * K - 1;
@@ -343,18 +388,30 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 	const bool edge_tile = c0 + TW > a.W;
 	const int nL = Wd, nH = a.W >> 1;
 	const int edge_sub = (lane & 4) ? nH + ((lane >> 1) & 1) : nL + ((lane >> 1) & 1);
-	const int edge_col = reflect(2 * edge_sub + ((lane >> 2) & 1), a.W) >> 1;
+	constexpr bool kSel = kIsSelEnds<W>; // (levels of 64 x 64 and more: one-bounce reflections, no integer division in the stream)
+	const int edge_col = (kSel ? reflect_near(2 * edge_sub + ((lane >> 2) & 1), a.W) : reflect(2 * edge_sub + ((lane >> 2) & 1), a.W)) >> 1;
 	// halo: lanes 0..15 the L halo block (8 doubles), 16..31 the H halo block
 	const int hd = (lane >> 1) & 7, hs = (lane >> 4) & 1;
 	const int hsub = hd < 4 ? cl0 - 4 + hd : cl0 + M + (hd - 4);
-	const int halo_col = reflect(2 * hsub + hs, a.W) >> 1;
+	const int halo_col = (kSel ? reflect_near(2 * hsub + hs, a.W) : reflect(2 * hsub + hs, a.W)) >> 1;
 	// line-end forms (dwt_lift.h; see k_inv_sweep): the lane's samples c - K + 1 .. that are a row's ends, any in this
 	// tile, and the test for a row being a column's end
-	const unsigned hends = end_mask<NARR>(c0 + lane * CPT - K + 1, a.W);
-	const bool h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+	[[maybe_unused]] unsigned hends = 0;
+	[[maybe_unused]] bool h_any = false, h_simple = false;
 	constexpr unsigned kCand = (1u << (K - 1)) | (1u << (K + CPT - 2)); // the two entries that meet a line end when W is a multiple of CPT
-	const bool h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
-	const bool tall = a.H >= 64;
+	[[maybe_unused]] bool e0 = false, e1 = false;
+	[[maybe_unused]] T kh[K];
+	if constexpr (kSel) {
+		const unsigned m = end_mask_long<NARR>(c0 + lane * CPT - K + 1, a.W);
+		e0 = (m >> (K - 1)) & 1;
+		e1 = (m >> (K + CPT - 2)) & 1;
+		sel_coefs<W, true, K - 1>(kh, e0, e1);
+	} else if constexpr (W::kEndForms) {
+		hends = end_mask<NARR>(c0 + lane * CPT - K + 1, a.W);
+		h_any = __builtin_amdgcn_ballot_w64(hends != 0) != 0;
+		h_simple = __builtin_amdgcn_ballot_w64((hends & ~(kCand | 1u | (1u << (NARR - 1)))) != 0) == 0;
+	}
+	const bool tall = kSel || a.H >= 64;
 	auto row_is_end = [&](int r) {
 		if (tall)
 			return r == 0 || r == a.H - 1;
@@ -366,7 +423,7 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 		const int p = p0 + it;
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
-			const int rs = reflect(2 * p + rr, a.H);
+			const int rs = tall ? reflect1(2 * p + rr, a.H) : reflect(2 * p + rr, a.H);
 			const int sub = rs >> 1;
 			const T *gl, *gh;
 			if (rr == 0) {
@@ -456,7 +513,9 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 		T val[2][CPT];
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
-			if (__builtin_expect(!h_any, 1)) {
+			if constexpr (kSel) {
+				lift_regs_sel<W, NARR, true, K - 1, K + CPT - 2>(x[rr], e0, e1, kh);
+			} else if (__builtin_expect(!h_any, 1)) {
 				lift_inv_regs<W, NARR>(x[rr], 0u);
 			} else if (h_simple) {
 				DWT_END_PATH();
@@ -477,16 +536,30 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 			v_any = v_any || vend[s_];
 		}
 		T odd_row[CPT], even_row[CPT];
+		[[maybe_unused]] T kv[K];
+		if constexpr (kSel) {
+#pragma unroll
+			for (int s_ = 0; s_ < K; s_++)
+				kv[s_] = sel_coef<W, true>(s_, vend[s_]);
+		}
 		auto vertical = [&](auto ends_tag) {
 			constexpr bool ENDS = decltype(ends_tag)::value;
+			auto vstep = [&](int s_, T c, T l, T r) {
+				if constexpr (kSel && ENDS)
+					return sel_step<W, true>(s_, vend[s_], kv[s_], c, l, r);
+				else if constexpr (kSel)
+					return W::inv_step(s_, c, l, r);
+				else
+					return inv_step_at<W>(s_, ENDS && vend[s_], c, l, r);
+			};
 #pragma unroll
 			for (int v = 0; v < CPT; v++) {
 				const T s2 = val[0][v], d2 = val[1][v];
 				if constexpr (K == 4) {
-					const T s1n = inv_step_at<W>(0, ENDS && vend[0], s2, st[0][v], d2);
-					const T d1n = inv_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], s1n);
-					const T en = inv_step_at<W>(2, ENDS && vend[2], st[1][v], st[2][v], d1n);
-					const T on = inv_step_at<W>(3, ENDS && vend[3], st[2][v], st[3][v], en);
+					const T s1n = vstep(0, s2, st[0][v], d2);
+					const T d1n = vstep(1, st[0][v], st[1][v], s1n);
+					const T en = vstep(2, st[1][v], st[2][v], d1n);
+					const T on = vstep(3, st[2][v], st[3][v], en);
 					odd_row[v] = on;
 					even_row[v] = en;
 					st[0][v] = d2;
@@ -494,8 +567,8 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 					st[2][v] = d1n;
 					st[3][v] = en;
 				} else {
-					const T en = inv_step_at<W>(0, ENDS && vend[0], s2, st[0][v], d2);
-					const T on = inv_step_at<W>(1, ENDS && vend[1], st[0][v], st[1][v], en);
+					const T en = vstep(0, s2, st[0][v], d2);
+					const T on = vstep(1, st[0][v], st[1][v], en);
 					odd_row[v] = on;
 					even_row[v] = en;
 					st[0][v] = d2;
@@ -519,6 +592,18 @@ __global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD 
 		if (ve)
 			store16_row<true>(row_rsrc(out + (long)(2 * pe) * a.out_pitch, (unsigned)a.W * 8), cb, pack2(even_row[0], even_row[1]));
 	}
+}
+
+template <class W, int RING>
+__global__ __launch_bounds__(256) void k_inv_sweep_d(InvLevelArgs a, SweepGeomD g)
+{
+	if constexpr (W::kEndForms) {
+		if (a.W % 2 == 0 && a.W >= 64 && a.H >= 64)
+			inv_sweep_d_tile<SelEnds<W>, RING>(a, g);
+		else
+			inv_sweep_d_tile<W, RING>(a, g);
+	} else
+		inv_sweep_d_tile<W, RING>(a, g);
 }
 
 template <class W, int RING>

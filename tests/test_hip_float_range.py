@@ -241,9 +241,10 @@ def test_both_sides_of_the_instantiation_rules(dwt, oracle, shape, klass):
     a = full_range_floats(rng, (h, w), np.float32, klass, klass == "mixed")
     for name, ff, fi in (("cdf97_s", "cdf97_2f_s", "cdf97_2i_s"), ("cdf53_s", "cdf53_2f_s", "cdf53_2i_s")):
         want = a.copy()
-        j = oracle.fwd(ff, want, 3)
-        back = want.copy()
-        oracle.inv(fi, back, j)
+        with (oracle.reflected_ends() if PLAIN_BUILD else warnings.catch_warnings()):
+            j = oracle.fwd(ff, want, 3)
+            back = want.copy()
+            oracle.inv(fi, back, j)
         d = dwt.DeviceImage(h, w).upload(a)
         assert dwt.FORWARD[name](d.ptr, d.stride_x, 4, w, h, w, h, 3) == j
         assert same_floats(d.download(np.float32), want), name + " forward"

@@ -84,6 +84,8 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 	const int edge_sub = (lane & 2) ? nH + (lane & 1) : nL + (lane & 1);
 	// (SelEnds: levels of 64 x 64 and more -- no index is reflected twice, no integer division in the wave's instruction stream)
 	constexpr bool kNear = kIsSelEnds<W>;
+	// (float policies whose step is c + k (l + r) rounded product-then-sum: the horizontal lift takes both rows at once)
+	constexpr bool kPairRows = kIsSelEnds<W> && std::is_same<T, float>::value && has_coef_ends<W>::value && !std::is_base_of<Cdf97SFma, W>::value;
 	const bool tall = kNear || a.H >= 64; // then a row index leaves [0,H) by less than H: one bounce
 	const int edge_col = (kNear ? reflect_near(2 * edge_sub + ((lane >> 1) & 1), a.W) : reflect(2 * edge_sub + ((lane >> 1) & 1), a.W)) >> 1;
 	// halo lanes 0..7 -> L halo, 8..15 -> H halo
@@ -376,7 +378,32 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 		T val[2][G][NVG]; // val[0] = L row p, val[1] = H row p as the vertical pass sees them
 #pragma unroll
 		for (int gi = 0; gi < G; gi++) {
-			if constexpr (!W::kInvColsFirst) {
+			if constexpr (kPairRows) {
+				// both rows of the iteration at once, as the halves of packed operations (the selects at the two candidate
+				// entries would otherwise split the pairs the compiler forms within a row): the same steps, the same rounding
+				typedef float f2 __attribute__((ext_vector_type(2)));
+				f2 x2[NARR];
+#pragma unroll
+				for (int j = 0; j < NARR; j++)
+					x2[j] = f2{x[0][gi][j], x[1][gi][j]};
+#pragma unroll
+				for (int s_ = 0; s_ < K; s_++) {
+#pragma unroll
+					for (int j = s_ + 1; j <= NARR - 2 - s_; j += 2) {
+						if (j == K - 1)
+							x2[j] = x2[j] + kh[gi][s_] * ((e0[gi] ? f2{-0.0f, -0.0f} : x2[j - 1]) + x2[j + 1]);
+						else if (j == K + CG - 2)
+							x2[j] = x2[j] + kh[gi][s_] * (x2[j - 1] + (e1[gi] ? f2{-0.0f, -0.0f} : x2[j + 1]));
+						else
+							x2[j] = x2[j] + W::ik(s_) * (x2[j - 1] + x2[j + 1]);
+					}
+				}
+#pragma unroll
+				for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+					for (int v = 0; v < CG; v++)
+						val[rr][gi][v] = W::inv_scale(rr, x2[K - 1 + v][rr]);
+			} else if constexpr (!W::kInvColsFirst) {
 #pragma unroll
 				for (int rr = 0; rr < 2; rr++) {
 					hlift(x[rr][gi], gi);

@@ -131,6 +131,47 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 // X (interleaved layout, phase-ordered wavelets): the tiles leave out the samples whose rounding depends on the
 // reference's phase order -- rows 0..7 and the last 8 columns of the level -- for the strip workgroups of the
 // same launch (dwt_il_strip.h).
+// The vertical pass of one iteration (no row of it a column end) on two adjacent columns at once, as the halves of packed
+// operations: the same steps and rounding as W::fwd_step / fwd_scale (float policies with fk: c + k (l + r)).
+// row[0] / row[1]: the odd / even row of the iteration; st: the streaming state; lo / hi: the scaled outputs.
+template <class W, int CPT, class T>
+static __device__ __forceinline__ void vertical_pairs(const T (&row)[2][CPT], T (&st)[W::K][CPT], T (&lo)[CPT], T (&hi)[CPT])
+{
+	typedef float f2 __attribute__((ext_vector_type(2)));
+	constexpr int K = W::K;
+	const float zl = W::fwd_scale(0, 1.0f), zh = W::fwd_scale(1, 1.0f); // (the scale factors themselves)
+#pragma unroll
+	for (int v = 0; v < CPT; v += 2) {
+		const f2 ov = f2{row[0][v], row[0][v + 1]}, ev = f2{row[1][v], row[1][v + 1]};
+		f2 s_[K], n_[K], lo2, hi2;
+#pragma unroll
+		for (int i = 0; i < K; i++)
+			s_[i] = f2{st[i][v], st[i][v + 1]};
+		n_[0] = ev;
+		n_[1] = ov + W::fk(0) * (s_[0] + ev); // d1n
+		if constexpr (K == 4) {
+			n_[2] = s_[0] + W::fk(1) * (s_[1] + n_[1]); // s1n
+			n_[3] = s_[1] + W::fk(2) * (s_[2] + n_[2]); // d2n
+			const f2 s2n = s_[2] + W::fk(3) * (s_[3] + n_[3]);
+			lo2 = s2n * zl;
+			hi2 = n_[3] * zh;
+		} else {
+			const f2 s1n = s_[0] + W::fk(1) * (s_[1] + n_[1]);
+			lo2 = s1n * zl;
+			hi2 = n_[1] * zh;
+		}
+#pragma unroll
+		for (int i = 0; i < K; i++) {
+			st[i][v] = n_[i][0];
+			st[i][v + 1] = n_[i][1];
+		}
+		lo[v] = lo2[0];
+		lo[v + 1] = lo2[1];
+		hi[v] = hi2[0];
+		hi[v + 1] = hi2[1];
+	}
+}
+
 template <class W, int CPT, int RING, int NT, bool IL, bool X>
 static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, const SweepGeom &g)
 {
@@ -152,6 +193,8 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 	constexpr int RS = TW + 8; // LDS row slot: [main TW | left halo 4 | right halo 4]
 	constexpr int NARR = CPT + 2 * K;
 	constexpr int kDmaPerIter = 2 * (CPT / 4 + 1); // fewest DMA instructions an iteration issues
+	// (float policies whose step is c + k (l + r) rounded product-then-sum: the horizontal lift takes both rows at once)
+	constexpr bool kPairRows = kIsSelEnds<W> && std::is_same<T, float>::value && has_coef_ends<W>::value && !std::is_base_of<Cdf97SFma, W>::value;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
 	const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
@@ -324,6 +367,7 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 
 		// horizontal pass of the two rows (2q-1, 2q)
 		T row[2][CPT];
+		[[maybe_unused]] T xs[2][kPairRows ? NARR : 1];
 #pragma unroll
 		for (int rr = 0; rr < 2; rr++) {
 			const unsigned base = ring_off + (unsigned)(rslot + rr) * RS * 4;
@@ -371,6 +415,12 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 #pragma unroll
 			for (int e = 0; e < 4; e++)
 				x[K + e] = from_bits<T>(O0[e]);
+			if constexpr (kPairRows) {
+#pragma unroll
+				for (int j = 0; j < NARR; j++)
+					xs[rr][j] = x[j];
+				continue; // (both rows are lifted together below)
+			}
 			if constexpr (W::kEndForms) {
 				if (__builtin_expect(!h_any, 1)) {
 					lift_fwd_regs<W, NARR>(x, 0u);
@@ -391,6 +441,32 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 				row[rr][v] = W::fwd_scale(v & 1, x[K + v]);
 		}
 
+		if constexpr (kPairRows) {
+			// both rows at once, as the halves of packed operations: the same steps, the same rounding (the compiler pairs
+			// within a row on its own, but not all of it, and the selects at the two candidate entries split its pairs)
+			typedef float f2 __attribute__((ext_vector_type(2)));
+			f2 x2[NARR];
+#pragma unroll
+			for (int j = 0; j < NARR; j++)
+				x2[j] = f2{xs[0][j], xs[1][j]};
+#pragma unroll
+			for (int s_ = 0; s_ < K; s_++) {
+#pragma unroll
+				for (int j = s_ + 1; j <= NARR - 2 - s_; j += 2) {
+					if (j == K)
+						x2[j] = x2[j] + kh[s_] * ((e0 ? f2{-0.0f, -0.0f} : x2[j - 1]) + x2[j + 1]);
+					else if (j == K + CPT - 1)
+						x2[j] = x2[j] + kh[s_] * (x2[j - 1] + (e1 ? f2{-0.0f, -0.0f} : x2[j + 1]));
+					else
+						x2[j] = x2[j] + W::fk(s_) * (x2[j - 1] + x2[j + 1]);
+				}
+			}
+#pragma unroll
+			for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+				for (int v = 0; v < CPT; v++)
+					row[rr][v] = W::fwd_scale(v & 1, x2[K + v][rr]);
+		}
 		rslot = rslot + 2 >= kRing ? 0 : rslot + 2;
 
 		// vertical pass: streaming lifting, state in registers
@@ -408,6 +484,10 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 		// `ENDS`: the iteration meets a column end -- the steps on that row take the end form
 		auto vertical = [&](auto ends_tag) {
 			constexpr bool ENDS = decltype(ends_tag)::value;
+			if constexpr (kPairRows && !ENDS) {
+				vertical_pairs<W, CPT>(row, st, lo, hi);
+				return;
+			}
 #pragma unroll
 			for (int v = 0; v < CPT; v++) {
 				const T ov = row[0][v], ev = row[1][v];

@@ -141,12 +141,15 @@ static __device__ __forceinline__ void vertical_pairs(const T (&row)[2][CPT], T 
 	constexpr int K = W::K;
 	const float zl = W::fwd_scale(0, 1.0f), zh = W::fwd_scale(1, 1.0f); // (the scale factors themselves)
 #pragma unroll
-	for (int v = 0; v < CPT; v += 2) {
-		const f2 ov = f2{row[0][v], row[0][v + 1]}, ev = f2{row[1][v], row[1][v + 1]};
+	for (int v = 0; v < CPT; v++) {
+		if (v & 2)
+			continue; // (columns v and v + 2: the stores take lo[0], lo[2], lo[4], lo[6] / lo[1], lo[3], ... as consecutive registers)
+		constexpr int P = 2;
+		const f2 ov = f2{row[0][v], row[0][v + P]}, ev = f2{row[1][v], row[1][v + P]};
 		f2 s_[K], n_[K], lo2, hi2;
 #pragma unroll
 		for (int i = 0; i < K; i++)
-			s_[i] = f2{st[i][v], st[i][v + 1]};
+			s_[i] = f2{st[i][v], st[i][v + P]};
 		n_[0] = ev;
 		n_[1] = ov + W::fk(0) * (s_[0] + ev); // d1n
 		if constexpr (K == 4) {
@@ -163,12 +166,12 @@ static __device__ __forceinline__ void vertical_pairs(const T (&row)[2][CPT], T 
 #pragma unroll
 		for (int i = 0; i < K; i++) {
 			st[i][v] = n_[i][0];
-			st[i][v + 1] = n_[i][1];
+			st[i][v + P] = n_[i][1];
 		}
 		lo[v] = lo2[0];
-		lo[v + 1] = lo2[1];
+		lo[v + P] = lo2[1];
 		hi[v] = hi2[0];
-		hi[v + 1] = hi2[1];
+		hi[v + P] = hi2[1];
 	}
 }
 
@@ -461,11 +464,13 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 						x2[j] = x2[j] + W::fk(s_) * (x2[j - 1] + x2[j + 1]);
 				}
 			}
+			const float ze = W::fwd_scale(0, 1.0f), zo = W::fwd_scale(1, 1.0f); // (the scale factors themselves)
 #pragma unroll
-			for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-				for (int v = 0; v < CPT; v++)
-					row[rr][v] = W::fwd_scale(v & 1, x2[K + v][rr]);
+			for (int v = 0; v < CPT; v++) {
+				const f2 sc = x2[K + v] * ((v & 1) ? zo : ze);
+				row[0][v] = sc[0];
+				row[1][v] = sc[1];
+			}
 		}
 		rslot = rslot + 2 >= kRing ? 0 : rslot + 2;
 

@@ -134,11 +134,17 @@ hipError_t launch_line_pass(Wavelet w, bool inverse, const void *src, void *dst,
 // The vertical pass of one iteration (no row of it a column end) on two adjacent columns at once, as the halves of packed
 // operations: the same steps and rounding as W::fwd_step / fwd_scale (float policies with fk: c + k (l + r)).
 // row[0] / row[1]: the odd / even row of the iteration; st: the streaming state; lo / hi: the scaled outputs.
-template <class W, int CPT, class T>
-static __device__ __forceinline__ void vertical_pairs(const T (&row)[2][CPT], T (&st)[W::K][CPT], T (&lo)[CPT], T (&hi)[CPT])
+// SEL: the select form of the line ends -- ve[s]: step s acts on a row that is a column's end (wave-uniform), kv[s] its
+// coefficient (doubled there); the state tap gives way to -0.0 (dwt_lift.h, SelEnds).
+template <class W, int CPT, bool SEL = false, class T>
+static __device__ __forceinline__ void vertical_pairs(const T (&row)[2][CPT], T (&st)[W::K][CPT], T (&lo)[CPT], T (&hi)[CPT],
+	const bool *ve = nullptr, const T *kv = nullptr)
 {
 	typedef float f2 __attribute__((ext_vector_type(2)));
 	constexpr int K = W::K;
+	[[maybe_unused]] const f2 nz = f2{-0.0f, -0.0f};
+	auto kk = [&](int s) { return SEL ? kv[s] : W::fk(s); };
+	auto tap = [&](int s, f2 v) { return (SEL && ve[s]) ? nz : v; };
 	const float zl = W::fwd_scale(0, 1.0f), zh = W::fwd_scale(1, 1.0f); // (the scale factors themselves)
 #pragma unroll
 	for (int v = 0; v < CPT; v++) {
@@ -151,15 +157,15 @@ static __device__ __forceinline__ void vertical_pairs(const T (&row)[2][CPT], T 
 		for (int i = 0; i < K; i++)
 			s_[i] = f2{st[i][v], st[i][v + P]};
 		n_[0] = ev;
-		n_[1] = ov + W::fk(0) * (s_[0] + ev); // d1n
+		n_[1] = ov + kk(0) * (tap(0, s_[0]) + ev); // d1n
 		if constexpr (K == 4) {
-			n_[2] = s_[0] + W::fk(1) * (s_[1] + n_[1]); // s1n
-			n_[3] = s_[1] + W::fk(2) * (s_[2] + n_[2]); // d2n
-			const f2 s2n = s_[2] + W::fk(3) * (s_[3] + n_[3]);
+			n_[2] = s_[0] + kk(1) * (tap(1, s_[1]) + n_[1]); // s1n
+			n_[3] = s_[1] + kk(2) * (tap(2, s_[2]) + n_[2]); // d2n
+			const f2 s2n = s_[2] + kk(3) * (tap(3, s_[3]) + n_[3]);
 			lo2 = s2n * zl;
 			hi2 = n_[3] * zh;
 		} else {
-			const f2 s1n = s_[0] + W::fk(1) * (s_[1] + n_[1]);
+			const f2 s1n = s_[0] + kk(1) * (tap(1, s_[1]) + n_[1]);
 			lo2 = s1n * zl;
 			hi2 = n_[1] * zh;
 		}
@@ -539,6 +545,10 @@ static __device__ __forceinline__ void fwd_sweep_tile(const FwdLevelArgs &a, con
 #pragma unroll
 				for (int s_ = 0; s_ < K; s_++)
 					kv[s_] = sel_coef<W, false>(s_, ve[s_]);
+				if constexpr (kPairRows) {
+					vertical_pairs<W, CPT, true>(row, st, lo, hi, ve, kv);
+					return;
+				}
 #pragma unroll
 				for (int v = 0; v < CPT; v++) {
 					const T ov = row[0][v], ev = row[1][v];

@@ -35,8 +35,8 @@
 // kernel applies the reference's own form, bit for bit over the whole float range (tests/test_hip_float_range.py).  0
 // (`make plain` -> libdwt_hip_plain.so): the line ends are what reflection gives, c*(x+x) -- the same bits unless x+x
 // overflows; what shipped until the select form made the exact ends free (round 6, alternated on one box: forward call of
-// one 8192^2 image 155 = 155 us, the bench's batch of 32 unchanged within its noise, inverse calls + 1-3 %; the
-// branching forms had cost 8-11 % and 3.5 %: profiles/r06_notes.md).  The 3-D level kernels keep the reflected form in
+// one 8192^2 image 155 = 155 us, the bench's batch of 64 unchanged within its noise, inverse calls + 2 % before the
+// packed two-row lift gave that back; the branching forms had cost 8-11 % and 3.5 %: profiles/r06_notes.md).  The 3-D level kernels keep the reflected form in
 // either build.  The int 5/3 has its end forms in every build.
 #ifndef DWT_FLOAT_END_FORMS
 #define DWT_FLOAT_END_FORMS 1

@@ -340,7 +340,7 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				for (int j = 0; j < NARR; j++) {
 					const int rel = j - K + 1;
 					const T v = rel < 0 ? from_bits<T>(L4[(4 + rel) & 3]) : rel < CPT ? ownv[rel < CPT ? (rel < 0 ? 0 : rel) : 0] : from_bits<T>(R4[(rel - CPT) & 3]);
-					x[rr][0][j] = W::inv_scale(rel & 1, v);
+					x[rr][0][j] = kPairRows ? v : W::inv_scale(rel & 1, v); // (kPairRows: descaled below, both rows at once)
 				}
 				continue;
 			}
@@ -368,9 +368,9 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				for (int j = 0; j < NARR; j++) {
 					const int rel = j - K + 1; // sample index relative to c (c even)
 					if (rel & 1)
-						x[rr][gi][j] = W::inv_scale(1, h[2 + ((rel - 1) >> 1)]);
+						x[rr][gi][j] = kPairRows ? h[2 + ((rel - 1) >> 1)] : W::inv_scale(1, h[2 + ((rel - 1) >> 1)]);
 					else
-						x[rr][gi][j] = W::inv_scale(0, l[2 + (rel >> 1)]);
+						x[rr][gi][j] = kPairRows ? l[2 + (rel >> 1)] : W::inv_scale(0, l[2 + (rel >> 1)]);
 				}
 			}
 		}
@@ -383,9 +383,10 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 				// entries would otherwise split the pairs the compiler forms within a row): the same steps, the same rounding
 				typedef float f2 __attribute__((ext_vector_type(2)));
 				f2 x2[NARR];
+				const float z0 = W::inv_scale(0, 1.0f), z1 = W::inv_scale(1, 1.0f); // (the descaling factors themselves)
 #pragma unroll
 				for (int j = 0; j < NARR; j++)
-					x2[j] = f2{x[0][gi][j], x[1][gi][j]};
+					x2[j] = f2{x[0][gi][j], x[1][gi][j]} * (((j - K + 1) & 1) ? z1 : z0);
 #pragma unroll
 				for (int s_ = 0; s_ < K; s_++) {
 #pragma unroll
@@ -399,10 +400,11 @@ static __device__ __forceinline__ void inv_sweep_tile(const InvLevelArgs &a, con
 					}
 				}
 #pragma unroll
-				for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-					for (int v = 0; v < CG; v++)
-						val[rr][gi][v] = W::inv_scale(rr, x2[K - 1 + v][rr]);
+				for (int v = 0; v < CG; v++) {
+					const f2 sc = x2[K - 1 + v] * f2{z0, z1}; // (the vertical pass descales by ROW parity)
+					val[0][gi][v] = sc[0];
+					val[1][gi][v] = sc[1];
+				}
 			} else if constexpr (!W::kInvColsFirst) {
 #pragma unroll
 				for (int rr = 0; rr < 2; rr++) {
